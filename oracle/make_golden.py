@@ -1,0 +1,251 @@
+"""TEST INFRASTRUCTURE -- generates tests/golden/*.npz by running the UNMODIFIED reference.
+
+Run in the authoring container only (needs /root/reference):   python oracle/make_golden.py
+The reference scripts are imported through oracle/ref_shim.py; inputs are
+injected by replacing the three output heads of RelightNet with constant modules, so the reference's
+own `forward` computes the render block (T8:352-524 / S1:326-505 / SLT:325-514) on exactly the
+tensors stored here.  The fixtures are data only: inputs and the reference's outputs / autograd grads.
+
+Files written:
+  inputs.npz       depth maps, masks (u8, 1 = reference mask != 0), one albedo map, camera matrices
+  t8_*.npz         training form (B=3, predicted light, z>=0 clamp, 160 samples)          T8:196,524
+  s1_*.npz         single-image relight form (B=1, target light, ambient-0.1, +5 bonus)    S1:169,505
+  slt_*.npz        lighting-transfer form (159 samples from 0.03, I=0.41, f=700, +1410)    SLT:169,514
+Every case stores the light/ambient it used, indices into inputs.npz, and outputs as f32
+(full_shading / final_shading / normals are f64 in the reference; they are stored rounded to f32).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+H = W = 256
+
+
+def camera(f):
+    K = np.zeros((1, 3, 3))
+    K[:, 0, 0] = K[:, 1, 1] = f
+    K[:, 2, 2] = 1.0
+    K[:, 0, 2] = W / 2.0
+    K[:, 1, 2] = H / 2.0
+    return torch.from_numpy(K)
+
+
+def synth_depth():
+    """Analytic ellipsoid + nose + ripple; stored, not regenerated, because libm
+    differences across hosts would change bits."""
+    r, c = np.mgrid[0:H, 0:W]
+    x = c - 128.0
+    y = r - 128.0
+    d = 80 * np.sqrt(np.maximum(1 - (x / 90) ** 2 - (y / 110) ** 2, 0)) \
+        + 35 * np.exp(-(x ** 2 / 288 + (y - 12) ** 2 / 648)) + 3 * np.sin(c / 7) * np.cos(r / 9)
+    return d.astype(np.float32)
+
+
+def ffhq_inputs(names):
+    """Realistic depth/albedo: the reference's lighting-transfer network + its shipped checkpoint
+    (model_lighting_transfer/model_epoch106.pth) on the shipped FFHQ samples."""
+    from PIL import Image
+    SLT = ref_shim.load("SLT")
+    model = SLT.RelightNet()
+    sd = torch.load(os.path.join(ref_shim.REFERENCE_ROOT, "model_lighting_transfer", "model_epoch106.pth"),
+                    map_location="cpu")
+    model.load_state_dict(sd)
+    model = model.float().eval()
+    depths, albedos, masks = [], [], []
+    for n in names:
+        img = Image.open(os.path.join(ref_shim.REFERENCE_ROOT, "sample_test_images_FFHQ", n)).convert("RGB")
+        img = np.asarray(img.resize((W, H), Image.BILINEAR), dtype=np.float64) / 255.0
+        mk = np.asarray(Image.open(os.path.join(ref_shim.REFERENCE_ROOT, "FFHQ_skin_masks", n)))
+        with torch.no_grad():
+            out = model(torch.from_numpy(img)[None].float(), 200, camera(700.0),
+                        torch.from_numpy(mk.reshape(H, W, 1) / 255.0),
+                        torch.tensor([0.0, 0.7071, 0.7071]).view(1, 3, 1, 1), torch.tensor([0.5]).view(1, 1, 1))
+        depths.append(out[1][0, 0].numpy().copy())
+        albedos.append(out[0][0].numpy().copy())
+        masks.append((mk != 0).astype(np.uint8))
+    return np.stack(depths), np.stack(albedos), np.stack(masks)
+
+
+def logit(a):
+    a = np.clip(a.astype(np.float64), 1e-4, 1 - 1e-4)
+    return np.log(a / (1 - a)).astype(np.float32)
+
+
+def run_t8(model, depth, albedo_target, light4, masks_u8, K, grads=None):
+    """depth (3,H,W) f32, light4 (3,4) [ambient, lx, ly, lz], masks_u8 (3,H,W)."""
+    d100 = torch.from_numpy(depth / np.float32(100.0))[:, None].clone()
+    lg = torch.from_numpy(logit(albedo_target)).clone()
+    sl = torch.from_numpy(light4.astype(np.float32)).view(3, 1, 1, 4).clone()
+    if grads:
+        d100.requires_grad_()
+        lg.requires_grad_()
+        sl.requires_grad_()
+    ref_shim.inject(model, d100, lg, sl)
+    masks = torch.from_numpy(masks_u8.astype(np.float64))[..., None]
+    ctx = torch.enable_grad() if grads else torch.no_grad()
+    with ctx:
+        out = model(torch.zeros(3, H, W, 3), 200, K, masks)
+    res = dict(albedo=out[0].detach().numpy(), depth=out[1].detach().numpy()[:, 0],
+               shadow_mask_weights=out[2].detach().numpy(), full_shading=out[4].detach().numpy().astype(np.float32),
+               rendered_images=out[5].detach().numpy(), unit_light_direction=out[6].detach().numpy().reshape(3, 3),
+               ambient_values=out[7].detach().numpy().reshape(3))
+    if grads:
+        for tag, seed in grads.items():
+            rng = np.random.default_rng(seed)
+            G_r = torch.from_numpy(rng.random((3, 3, H, W), dtype=np.float32))
+            G_w = torch.from_numpy(rng.random((3, H, W), dtype=np.float32))
+            loss = (out[2] * G_w).sum() if tag == "shadow" else (out[5] * G_r).sum() + (out[2] * G_w).sum()
+            for t in (d100, lg, sl):
+                t.grad = None
+            loss.backward(retain_graph=True)
+            res["grad_%s_depth" % tag] = (d100.grad[:, 0] / 100.0).numpy().copy()   # d/d depth = d/d(d100) / 100
+            res["grad_%s_light4" % tag] = sl.grad.view(3, 4).numpy().copy()
+            if tag == "full":
+                a = out[0].detach()
+                res["grad_full_albedo"] = (lg.grad / (a * (1 - a))).numpy().copy()
+            res["grad_%s_seed" % tag] = np.int64(seed)
+    return res
+
+
+def run_single(model, depth, albedo_target, raw4, target_light, target_amb, mask_u8, K, variant):
+    """S1 / SLT forward, B=1.  raw4 = what the (injected) lighting head returns: [amb, lx, ly, lz]."""
+    d100 = torch.from_numpy(depth / np.float32(100.0))[None, None].clone()
+    lg = torch.from_numpy(logit(albedo_target))[None].clone()
+    sl = torch.from_numpy(raw4.astype(np.float32)).view(1, 1, 1, 4).clone()
+    ref_shim.inject(model, d100, lg, sl)
+    mask = torch.from_numpy(mask_u8.astype(np.float64))[..., None]       # (H,W,1) as S1:580 / SLT:541
+    tl = torch.from_numpy(np.asarray(target_light, np.float32)).view(1, 3, 1, 1)
+    ta = torch.from_numpy(np.asarray([target_amb], np.float32)).view(1, 1, 1)
+    with torch.no_grad():
+        if variant == "S1":
+            out = model(torch.zeros(1, H, W, 3), 200, K, mask, tl, ta, mask[None])
+        else:
+            out = model(torch.zeros(1, H, W, 3), 200, K, mask, tl, ta)
+    return dict(albedo=out[0].numpy()[0], depth=out[1].numpy()[0, 0], shadow_mask_weights=out[2].numpy()[0],
+                full_shading=out[4].numpy()[0].astype(np.float32), rendered_images=out[5].numpy()[0],
+                unit_light_direction=out[6].numpy().reshape(3), ambient_values=out[7].numpy().reshape(1),
+                final_shading=out[8].numpy()[0].astype(np.float32),
+                surface_normals=out[9].numpy()[0].astype(np.float32))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    t_start = time.time()
+    names = ["00295.png", "00110.png", "00508.png"]
+    d_ffhq, a_ffhq, m_ffhq = ffhq_inputs(names)
+    r, c = np.mgrid[0:H, 0:W]
+    m_ell = ((((c - 128.0) / 80) ** 2 + ((r - 128.0) / 100) ** 2) < 1).astype(np.uint8)
+    m_one = np.ones((H, W), np.uint8)
+    depths = np.concatenate([synth_depth()[None], d_ffhq])              # index 0 = synthetic, 1..3 = FFHQ
+    # The reference multiplies the depth head by 100 (T8:350).  Snap every value to a fixed point of
+    # d -> f32(100*f32(d/100)) so that injecting d/100 reproduces exactly the stored depth.
+    for _ in range(8):
+        nxt = (np.float32(100.0) * (depths / np.float32(100.0))).astype(np.float32)
+        if np.array_equal(nxt, depths):
+            break
+        depths = nxt
+    assert np.array_equal((np.float32(100.0) * (depths / np.float32(100.0))).astype(np.float32), depths)
+    masks = np.concatenate([m_one[None], m_ell[None], m_ffhq])          # 0 ones, 1 ellipse, 2..4 FFHQ
+    albedo_t = np.round(a_ffhq[0] * 255.0) / 255.0                      # target; the albedo actually used is stored
+    np.savez_compressed(os.path.join(OUT, "inputs.npz"), depths=depths, masks=masks,
+                        K_1570=camera(1570.0).numpy(), K_700=camera(700.0).numpy(),
+                        ffhq_names=np.array(names))
+    print("inputs done %.1fs; depth ranges" % (time.time() - t_start),
+          [(float(d.min()), float(d.max())) for d in depths])
+
+    # ---------------- T8 (training form) ----------------
+    T8 = ref_shim.load("T8")
+    model = T8.RelightNet()
+    K = camera(1570.0)
+    amb3 = np.array([0.5, 0.35, 0.62], np.float32)
+    t8_cases = [
+        # (depth idx x3, mask idx x3, lights x3, grads)
+        ("t8_a", (0, 0, 0), (0, 1, 2), [(0, 0.7071, 0.7071), (0.8138, -0.3420, 0.4698), (-0.8138, -0.3420, 0.4698)],
+         {"shadow": 11, "full": 12}),
+        ("t8_b", (1, 2, 3), (2, 3, 4), [(0.7518, 0.0, 0.6594), (-0.7076, 0.3892, 0.5897), (0.0, -0.6, 0.8)],
+         {"shadow": 21, "full": 22}),
+        ("t8_c", (0, 1, 2), (1, 2, 3), [(0.01, 0.01, 0.9999), (0.6, 0.7, 0.2), (-0.6, 0.7, 0.1)], None),
+        ("t8_d", (3, 0, 1), (4, 1, 2), [(0.02, 0.9, 0.3), (0.5, -0.8, -0.3), (-0.5, -0.8, 0.3)], None),
+        ("t8_e", (1, 2, 3), (2, 3, 4), [(0.6893, 0.3991, 0.6047), (0.5145, 0.0, 0.8575), (-0.5843, 0.0, 0.8115)], None),
+    ]
+    albedo_used = None
+    for name, di, mi, lights, grads in t8_cases:
+        t = time.time()
+        light4 = np.concatenate([amb3[:, None], np.asarray(lights, np.float32)], 1)
+        alb_t = np.stack([np.roll(albedo_t, b, axis=0) for b in range(3)])     # channel-rolled copies of one map
+        res = run_t8(model, depths[list(di)], alb_t, light4, masks[list(mi)], K, grads)
+        assert np.array_equal(res["depth"], depths[list(di)]), "100*(d/100) did not round-trip"
+        if albedo_used is None:
+            albedo_used = res["albedo"][0].copy()
+        assert all(np.array_equal(res["albedo"][b], np.roll(albedo_used, b, axis=0)) for b in range(3))
+        save = {k: v for k, v in res.items() if k not in ("albedo", "depth")}
+        # keep the fixture set small: w + full_shading pin every case; rendered / albedo grads only in t8_a
+        if name != "t8_a":
+            save.pop("rendered_images")
+            save.pop("grad_full_albedo", None)
+            save.pop("grad_full_depth", None)
+        else:
+            save["grad_full_albedo"] = save["grad_full_albedo"][0]          # face 0 only
+        if name == "t8_e":
+            save.pop("full_shading")
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), depth_idx=np.array(di), mask_idx=np.array(mi),
+                            light4=light4, albedo_roll=np.arange(3), **save)
+        print(name, "%.1fs" % (time.time() - t))
+
+    # ---------------- S1 (single-image relight form) ----------------
+    S1 = ref_shim.load("S1")
+    model = S1.RelightNet()
+    s1_cases = [
+        ("s1_a", 1, 2, (0.0, 0.7071, 0.7071), 0.5, True),
+        ("s1_b", 2, 3, (-0.7574, 0.0, 0.6529), 0.5, False),
+        ("s1_c", 3, 4, (0.4478, 0.4925, 0.7463), 0.45, False),
+        ("s1_d", 0, 1, (-0.5151, 0.4722, 0.7154), 0.5, False),
+        ("s1_e", 1, 2, (0.01, 0.02, 0.9997), 0.5, False),          # light projects inside the image: +5 bonus
+    ]
+    for name, di, mi, tl, amb_raw, keep_all in s1_cases:
+        t = time.time()
+        raw4 = np.array([amb_raw, 0.3, -0.2, 0.9], np.float32)      # S1 uses only raw4[0] (ambient - 0.1, S1:342)
+        res = run_single(model, depths[di], albedo_t, raw4, tl, 0.0, masks[mi], K, "S1")
+        assert np.array_equal(res["albedo"], albedo_used) and np.array_equal(res["depth"], depths[di])
+        save = {k: v for k, v in res.items() if k not in ("albedo", "depth")}
+        # normals are regenerated in the tests by oracle/normals_restatement.py (they pin nothing: kornia is
+        # un-vendored); final_shading = w*full + (1-w)*amb follows from the stored tensors.
+        for k in ("surface_normals", "final_shading") + (() if keep_all else ("rendered_images",)):
+            save.pop(k)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), depth_idx=np.int64(di), mask_idx=np.int64(mi),
+                            target_light=np.asarray(tl, np.float32), raw4=raw4, **save)
+        print(name, "%.1fs" % (time.time() - t))
+
+    # ---------------- SLT (lighting-transfer form) ----------------
+    SLT = ref_shim.load("SLT")
+    model = SLT.RelightNet()
+    K7 = camera(700.0)
+    slt_cases = [
+        ("slt_a", 1, 2, (0.35, 0.25, 0.9), 0.55, True),
+        ("slt_b", 2, 3, (0.0, 0.0, 0.0), 0.0, False),                # pass-1 of SLT:543: zero target light
+    ]
+    for name, di, mi, tl, ta, keep_all in slt_cases:
+        t = time.time()
+        raw4 = np.array([0.4, 0.3, -0.2, 0.1], np.float32)
+        res = run_single(model, depths[di], albedo_t, raw4, tl, ta, masks[mi], K7, "SLT")
+        save = {k: v for k, v in res.items() if k not in ("albedo", "depth")}
+        for k in ("surface_normals", "final_shading") + (() if keep_all else ("rendered_images",)):
+            save.pop(k)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), depth_idx=np.int64(di), mask_idx=np.int64(mi),
+                            target_light=np.asarray(tl, np.float32), target_ambient=np.float32(ta), raw4=raw4, **save)
+        print(name, "%.1fs" % (time.time() - t))
+
+    np.savez_compressed(os.path.join(OUT, "albedo.npz"), albedo=albedo_used)
+    print("total %.1fs" % (time.time() - t_start))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+"""TEST INFRASTRUCTURE -- authoring-container only.
+
+Imports the *unmodified* reference scripts from /root/reference on CPU so that golden
+vectors can be generated from the reference itself.  Nothing in the
+product (geomconsistentfr_amd/), in `-m gpu` tests, in smoke() or in bench.py may import this
+module: /root/reference does not exist on the GPU box.  Only oracle/make_golden.py and the
+authoring-time validation tests (skipped when /root/reference is absent) use it.
+
+What the shim does (and why):
+  * sys.dont_write_bytecode: a plain import would write __pycache__ into the read-only tree.
+  * stubs cv2 / imageio / pytorch_msssim (T8:7,10,12) -- not installed, not on the hot path.
+  * stubs kornia.geometry.depth.depth_to_normals (T8:8, called at T8:353) with the restatement
+    in oracle/normals_restatement.py (kornia==0.4.1 is un-vendored -> normals parity UNPINNED).
+  * restores np.asscalar (T8:380-381; removed in NumPy>=1.23).
+  * makes Tensor.cuda / Module.cuda identity (T8:54-55, 358, 366, 390 ... call .cuda()).
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REFERENCE_ROOT = "/root/reference"
+
+SCRIPTS = {
+    "T8": "train_raytracing_relighting_CelebAHQ_DSSIM_8x.py",
+    "TLT": "train_lighting_transfer.py",
+    "S1": "test_relight_single_image.py",
+    "S8": "test_raytracing_relighting_CelebAHQ_DSSIM_8x.py",
+    "SLT": "test_relight_single_image_lighting_transfer.py",
+}
+
+
+def reference_available() -> bool:
+    return os.path.isfile(os.path.join(REFERENCE_ROOT, SCRIPTS["T8"]))
+
+
+def _install_stubs():
+    sys.dont_write_bytecode = True
+    for name in ("cv2", "imageio"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    if "pytorch_msssim" not in sys.modules:
+        m = types.ModuleType("pytorch_msssim")
+        m.ssim = m.ms_ssim = m.SSIM = m.MS_SSIM = None
+        sys.modules["pytorch_msssim"] = m
+    if "kornia.geometry.depth" not in sys.modules:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from normals_restatement import depth_to_normals  # noqa: E402
+        k = types.ModuleType("kornia")
+        kg = types.ModuleType("kornia.geometry")
+        kgd = types.ModuleType("kornia.geometry.depth")
+        kgd.depth_to_normals = depth_to_normals
+        k.geometry = kg
+        kg.depth = kgd
+        sys.modules["kornia"] = k
+        sys.modules["kornia.geometry"] = kg
+        sys.modules["kornia.geometry.depth"] = kgd
+    if not hasattr(np, "asscalar"):
+        np.asscalar = lambda a: a.item()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+
+
+_loaded = {}
+
+
+def load(script_key: str):
+    """Return the reference script `script_key` (see SCRIPTS) as a module (its main() is guarded)."""
+    if script_key in _loaded:
+        return _loaded[script_key]
+    if not reference_available():
+        raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
+    _install_stubs()
+    path = os.path.join(REFERENCE_ROOT, SCRIPTS[script_key])
+    spec = importlib.util.spec_from_file_location("gcfr_reference_" + script_key, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    _loaded[script_key] = mod
+    return mod
+
+
+class Const(torch.nn.Module):
+    """Module that ignores its input and returns a fixed leaf tensor (input injection, App. C-5)."""
+
+    def __init__(self, value: torch.Tensor):
+        super().__init__()
+        self.value = value
+
+    def forward(self, _x):
+        return self.value
+
+
+def inject(model, depth_over_100, albedo_logits, light_b114):
+    """Replace the three heads so forward() runs the render block on exactly these tensors."""
+    model.conv_depth_c2_o = Const(depth_over_100)
+    model.conv_albedo_c2_o = Const(albedo_logits)
+    model.linear_SL2 = Const(light_b114)
+    return model
