@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the render block on MI355X.
+
+Metric (BASELINE.json): ray-steps/s (whole job) + relit faces/s on 256x256 faces, 160 march steps.
+Workload at N=1: BASELINE configs[1] -- batch of 8 synthetic 256x256 faces, one light each,
+forward-only shadow + shade.  One "step" = one pass of the hot path over one batch:
+gcfr_light_prep -> gcfr_shadow_fwd -> gcfr_shade_fwd, inputs resident in HBM.
+ray_steps = B*L*H*W*N nominal, never "steps executed".
+
+Multi-GPU (`torchrun --nproc-per-node N bench.py --gpus N`): faces are independent, so each rank
+renders its own batch of 8 with no data-path collective ("weak" scaling); the timed region is
+bracketed by barrier + synchronize on both sides and the max over ranks is reported.
+
+The JSON line also carries
+  roofline     -- for the dominant kernel (shadow_fwd_kernel): algorithmic bytes (17.4 B per ray-step,
+                  SURVEY.md 8d) per launch / average launch duration measured with HIP events on the
+                  launch stream, against the 8 TB/s HBM peak; `traffic` = HBM bytes per launch from the
+                  rocprofv3 PMC pass committed under profiles/ (null if that file is absent);
+  cpu_baseline -- the oracle's materialised-torch port (same op sequence as the reference, which cannot
+                  travel to the GPU box) timed on this host's cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 256
+N_SAMPLES = 160
+FACES_PER_GPU = 8
+ALGO_BYTES_PER_RAY_STEP = 17.4      # 4 f32 depth corners + 1 u8 mask cell + 0.4 B amortised pixel I/O
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def synth_faces(B, seed0):
+    """Deterministic synthetic faces: jittered ellipsoid + nose + ripple."""
+    r, c = np.mgrid[0:H, 0:W]
+    x, y = c - 128.0, r - 128.0
+    lights11 = np.array([[.7518, 0, .6594], [.6893, .3991, .6047], [.5145, 0, .8575], [-.5843, 0, .8115],
+                         [-.7574, 0, .6529], [-.7076, .3892, .5897], [-.5151, .4722, .7154], [.4478, .4925, .7463],
+                         [0, .7071, .7071], [-.8138, -.3420, .4698], [.8138, -.3420, .4698]], np.float32)
+    depth, mask, albedo, normals, light, amb = [], [], [], [], [], []
+    for i in range(B):
+        rng = np.random.default_rng(seed0 + i)
+        ax, ay, nose = 85 + 10 * rng.random(), 105 + 10 * rng.random(), 30 + 10 * rng.random()
+        d = 80 * np.sqrt(np.maximum(1 - (x / ax) ** 2 - (y / ay) ** 2, 0)) \
+            + nose * np.exp(-(x ** 2 / 288 + (y - 12) ** 2 / 648)) + 3 * np.sin(c / 7) * np.cos(r / 9)
+        depth.append(d.astype(np.float32))
+        mask.append((((x / (ax - 8)) ** 2 + (y / (ay - 8)) ** 2) < 1).astype(np.uint8))
+        albedo.append((0.15 + 0.7 * rng.random((3, H, W))).astype(np.float32))
+        gy, gx = np.gradient(d)
+        n = np.stack([-gx, gy, np.ones_like(d)])
+        normals.append((n / np.linalg.norm(n, axis=0)).astype(np.float32))
+        light.append(lights11[(seed0 + i) % 11])
+        amb.append(np.float32(0.5))
+    return (np.stack(depth), np.stack(mask), np.stack(albedo), np.stack(normals), np.stack(light),
+            np.asarray(amb, np.float32))
+
+
+def cpu_baseline(sample_faces=3, seed0=0):
+    """Time the materialised-torch port (oracle/) on this host: forward, no_grad, like the reference's
+    inference path.  Checker code used here strictly as the reported CPU baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import materialised as M
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    depth, mask, albedo, normals, light, amb = synth_faces(sample_faces, seed0)
+    args = (torch.from_numpy(depth)[:, None], torch.from_numpy(albedo), torch.from_numpy(light),
+            torch.from_numpy(amb), torch.from_numpy(normals).double(), torch.from_numpy(mask))
+    with torch.no_grad():
+        M.render_block(args[0][:1], args[1][:1], args[2][:1], args[3][:1], args[4][:1], args[5][:1])  # warm-up
+        t = time.perf_counter()
+        M.render_block(*args)
+        dt = time.perf_counter() - t
+    return {"value": sample_faces * H * W * N_SAMPLES / dt, "unit": "ray-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d faces 256x256x160, forward no_grad, oracle/materialised.py (op-for-op port of "
+                      "T8:352-524), %.1f s" % (sample_faces, dt),
+            "faces_per_s": sample_faces / dt}
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per shadow_fwd launch from the committed rocprofv3 PMC pass, or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        return json.load(open(p)).get("shadow_fwd_hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--faces", type=int, default=FACES_PER_GPU, help="faces per GPU per step (configs[1]: 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d" % (a.gpus, a.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    from geomconsistentfr_amd import RenderParams
+    from geomconsistentfr_amd import block as R
+
+    prm = RenderParams()
+    B = a.faces
+    depth, mask, albedo, normals, light, amb = synth_faces(B, seed0=rank * 1_000_000)
+    d_depth = torch.from_numpy(depth).to(dev)
+    d_mask = torch.from_numpy(mask).to(dev)
+    d_albedo = torch.from_numpy(albedo).to(dev)
+    d_normals = torch.from_numpy(normals).to(dev)
+    d_light = torch.from_numpy(light).to(dev)
+    d_amb = torch.from_numpy(amb).to(dev)
+
+    ev_pairs = []
+
+    def step(timed):
+        _, pt = R.light_prep(d_light, prm)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()                                   # same stream the kernel is launched on
+        md, _ = R.shadow_min_distance(d_depth, d_mask, pt.reshape(B, 1, 3), prm, want_argmin=False)
+        if timed:
+            e1.record()
+            ev_pairs.append((e0, e1))
+        return R.shade(d_normals, d_depth, d_albedo, pt.reshape(B, 1, 3), d_amb.reshape(B, 1), md, prm)
+
+    for _ in range(a.warmup):
+        step(False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ray_steps_per_step = world * B * H * W * N_SAMPLES
+    value = ray_steps_per_step * a.steps / elapsed
+    shadow_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev_pairs]))
+    algo_bytes = B * H * W * N_SAMPLES * ALGO_BYTES_PER_RAY_STEP          # per launch (one rank)
+    achieved = algo_bytes / (shadow_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "ray_steps_per_sec", "value": value, "unit": "ray-steps/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch=%d synthetic 256x256 faces per GPU, 1 light each, "
+                                   "160 march steps, forward-only shadow+shade" % B,
+                       "faces_per_gpu": B, "H": H, "W": W, "n_samples": N_SAMPLES, "parallelism": "dp%d" % world},
+            "faces_per_sec": world * B * a.steps / elapsed,
+            "ray_steps_per_sec_per_gpu": value / world,
+            "roofline": {"bound": "hbm", "kernel": "shadow_fwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": shadow_ms,
+                         "kernel_ray_steps_per_sec": B * H * W * N_SAMPLES / (shadow_ms * 1e-3)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

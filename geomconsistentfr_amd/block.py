@@ -1,0 +1,178 @@
+"""Host-side entry points of the render block (inner boundary of SURVEY.md 8b).
+
+`render()` is what a RelightNet.forward calls at the T8:352 seam.  Everything numeric happens in the
+HIP kernels of libgcfr_hip.so; torch is used for device memory, streams and (later) autograd glue.
+All tensors must live on a ROCm device; there is no CPU path.
+"""
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class RenderParams:
+    """Constants of the block across the reference's five scripts.
+    Defaults are the training script's (T8:41-48)."""
+    n_samples: int = 160                  # T8:48   (SLT:22 -> 159)
+    t0: float = 0.025                     # T8:468  (SLT:451 -> 0.03)
+    dt: float = 0.005
+    light_distance: float = 4013.0        # T8:47
+    directional_intensity: float = 0.5    # T8:46   (SLT:20 -> 0.41)
+    clamp_light_z_min: Optional[float] = 0.0   # T8:358; None = target light given, no clamp (S1:332)
+    inside_bonus: float = 0.0             # S1:495-496 / SLT:503-504 -> 5.0
+    bonus_box: Optional[Tuple[float, float, float, float]] = None   # (x_lo, x_hi, y_lo, y_hi)
+
+    @staticmethod
+    def training() -> "RenderParams":
+        return RenderParams()
+
+    @staticmethod
+    def single_image(H: int = 256, W: int = 256) -> "RenderParams":
+        """test_relight_single_image.py / test_raytracing_relighting_..._8x.py form (S1:495)."""
+        return RenderParams(clamp_light_z_min=None, inside_bonus=5.0,
+                            bonus_box=(-(W / 2.0), W - W / 2.0 - 1, 1 - H / 2.0, H / 2.0))
+
+    @staticmethod
+    def lighting_transfer(H: int = 256, W: int = 256) -> "RenderParams":
+        """test_relight_single_image_lighting_transfer.py form (SLT:20-22, 451, 503)."""
+        return RenderParams(n_samples=159, t0=0.03, directional_intensity=0.41, clamp_light_z_min=None,
+                            inside_bonus=5.0, bonus_box=(-4.0 * W, 4.0 * W, 4.0 * (1 - H), 4.0 * H))
+
+
+_TABLE_CACHE = {}
+
+
+def _require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.GcfrError("geomconsistentfr_amd has no CPU path: tensors must be on a ROCm device")
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def sample_table(params: RenderParams, device) -> torch.Tensor:
+    """Device copy of the f64 sample-fraction table (np.arange value rule, T8:468)."""
+    key = (params.t0, params.dt, params.n_samples, str(device))
+    t = _TABLE_CACHE.get(key)
+    if t is None:
+        host = np.empty(params.n_samples, dtype=np.float64)
+        _lib.check(_lib.load().gcfr_sample_table(params.t0, params.dt, params.n_samples, host.ctypes.data),
+                   "gcfr_sample_table")
+        t = torch.from_numpy(host).to(device)
+        _TABLE_CACHE[key] = t
+    return t
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def light_prep(light: torch.Tensor, params: RenderParams = RenderParams()):
+    """(..., 3) raw / target light -> (unit direction, light point), same leading shape.  T8:357-363."""
+    _require_device(light)
+    L = _lib.load()
+    lr = _f32c(light).reshape(-1, 3)
+    unit = torch.empty_like(lr)
+    pt = torch.empty_like(lr)
+    clamp = params.clamp_light_z_min is not None
+    with torch.cuda.device(lr.device):
+        _lib.check(L.gcfr_light_prep(lr.data_ptr(), lr.shape[0], int(clamp),
+                                     float(params.clamp_light_z_min or 0.0), float(params.light_distance),
+                                     unit.data_ptr(), pt.data_ptr(), _stream_ptr(lr.device)), "gcfr_light_prep")
+    return unit.reshape(light.shape), pt.reshape(light.shape)
+
+
+def mask_to_u8(mask: torch.Tensor) -> torch.Tensor:
+    """The reference tests `mask == 0` on a float mask (T8:510); the kernels take u8 {0,1}."""
+    if mask.dtype == torch.uint8:
+        return mask.contiguous()
+    return (mask != 0).to(torch.uint8).contiguous()
+
+
+def shadow_min_distance(depth: torch.Tensor, mask: torch.Tensor, light_pt: torch.Tensor,
+                        params: RenderParams = RenderParams(), want_argmin: bool = True):
+    """depth (B,H,W) f32, mask (B|1,H,W), light_pt (B,L,3) -> min_dist (B,L,H,W) f32, argmin i32|None.
+    Replaces T8:371-515."""
+    _require_device(depth, mask, light_pt)
+    L_ = _lib.load()
+    depth = _f32c(depth)
+    B, H, W = depth.shape
+    mask_u8 = mask_to_u8(mask).reshape(-1, H, W)
+    light_pt = _f32c(light_pt).reshape(B, -1, 3)
+    L = light_pt.shape[1]
+    tt = sample_table(params, depth.device)
+    md = torch.empty((B, L, H, W), dtype=torch.float32, device=depth.device)
+    am = torch.empty((B, L, H, W), dtype=torch.int32, device=depth.device) if want_argmin else None
+    box = (ctypes_float4(params.bonus_box) if params.bonus_box is not None else None)
+    with torch.cuda.device(depth.device):
+        _lib.check(L_.gcfr_shadow_fwd(depth.data_ptr(), mask_u8.data_ptr(), mask_u8.shape[0], light_pt.data_ptr(),
+                                      B, L, H, W, params.n_samples, tt.data_ptr(), float(params.inside_bonus),
+                                      box, md.data_ptr(), am.data_ptr() if am is not None else None,
+                                      _stream_ptr(depth.device)), "gcfr_shadow_fwd")
+    return md, am
+
+
+def ctypes_float4(v):
+    import ctypes
+    arr = (ctypes.c_float * 4)(*[float(x) for x in v])
+    return ctypes.cast(arr, ctypes.c_void_p)
+
+
+def shade(normals, depth, albedo, light_pt, ambient, min_dist, params: RenderParams = RenderParams()):
+    """Replaces T8:364-369, 517-522.  Shapes as include/gcfr.h; returns dict of f32 tensors."""
+    _require_device(normals, depth, albedo, light_pt, ambient, min_dist)
+    L_ = _lib.load()
+    depth = _f32c(depth)
+    B, H, W = depth.shape
+    normals = _f32c(normals).reshape(B, 3, H, W)
+    albedo = _f32c(albedo).reshape(B, 3, H, W)
+    light_pt = _f32c(light_pt).reshape(B, -1, 3)
+    L = light_pt.shape[1]
+    ambient = _f32c(ambient).reshape(B, L)
+    min_dist = _f32c(min_dist).reshape(B, L, H, W)
+    dev = depth.device
+    w = torch.empty((B, L, H, W), dtype=torch.float32, device=dev)
+    full = torch.empty_like(w)
+    fin = torch.empty_like(w)
+    ren = torch.empty((B, L, 3, H, W), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L_.gcfr_shade_fwd(normals.data_ptr(), depth.data_ptr(), albedo.data_ptr(), light_pt.data_ptr(),
+                                     ambient.data_ptr(), min_dist.data_ptr(), B, L, H, W,
+                                     float(params.directional_intensity), w.data_ptr(), full.data_ptr(),
+                                     fin.data_ptr(), ren.data_ptr(), _stream_ptr(dev)), "gcfr_shade_fwd")
+    return dict(shadow_mask_weights=w, full_shading=full, final_shading=fin, rendered_images=ren)
+
+
+def render(depth, albedo, light, ambient, normals, mask, params: RenderParams = RenderParams()):
+    """Forward render block for a batch with one light per image (the reference's call shape).
+
+      depth (B,1,H,W) f32      c2_o_depth (x100 already applied, T8:350)
+      albedo (B,3,H,W) f32     c2_o_albedo
+      light (B,3)              SL_lin2[...,1:4] (T8:357) or target_lighting (S1:332)
+      ambient (B,)             SL_lin2[...,0] (T8:367) / target ambient
+      normals (B,3,H,W)        depth_to_normals(depth+offset, K), y negated (T8:353-354)
+      mask (B,H,W) or (1,H,W)  0 = outside the face (T8:510)
+
+    Returns the reference's tensors by name (T8:524 / S1:505), all f32."""
+    B, _, H, W = depth.shape
+    unit, pt = light_prep(light.reshape(B, 3), params)
+    md, am = shadow_min_distance(depth.reshape(B, H, W), mask.reshape(-1, H, W), pt.reshape(B, 1, 3), params)
+    out = shade(normals, depth.reshape(B, H, W), albedo, pt.reshape(B, 1, 3), ambient.reshape(B, 1), md, params)
+    amb = _f32c(ambient).reshape(B, 1, 1)
+    return dict(
+        shadow_mask_weights=out["shadow_mask_weights"][:, 0],
+        ambient_light=amb.expand(B, H, W),
+        full_shading=out["full_shading"][:, 0],
+        rendered_images=out["rendered_images"][:, 0],
+        unit_light_direction=unit.reshape(B, 3, 1, 1),
+        ambient_values=amb,
+        final_shading=out["final_shading"][:, 0],
+        minimum_distance=md[:, 0],
+        argmin=am[:, 0],
+    )

@@ -1,0 +1,103 @@
+// Device-side helpers shared by the gfx950 kernels of the GeomConsistentFR render block.
+//
+// Arithmetic contract: the reference is a chain of separately rounded torch
+// elementwise ops, so this translation unit is compiled with -ffp-contract=off and uses an explicit
+// fma only where the reference's own kernels do (torch.cross, vector 2-norm).  Decisions that pick
+// array cells (round / floor / ceil of f64 sample positions) must match the reference exactly;
+// values must match to <=1e-4 (shadow weight) and <=1e-3 (RGB).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gcfr {
+
+constexpr float kEps4 = 0.0001f;        // the reference's 0.0001 guards (T8:378, 395, 483, 509)
+constexpr float kMaskedDistance = 1000000.0f;  // T8:512
+
+// gfx9 raw buffer descriptor word 3 (DATA_FORMAT=32, no swizzle): out-of-range offsets read 0 and
+// drop writes, so a corrupted index can never fault the GPU.
+constexpr int kBufferRsrcWord3 = 0x00020000;
+
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void *p, int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, kBufferRsrcWord3);
+}
+__device__ inline float buf_load_f32(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ inline uint32_t buf_load_u8(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    return __builtin_amdgcn_raw_buffer_load_b8(r, byte_off, 0, 0);
+}
+
+// Image box in image-plane coordinates (T8:386-387, 416, 399).
+struct Box {
+    float x_lo, x_hi, y_lo, y_hi;
+};
+__device__ __host__ inline Box image_box(int H, int W)
+{
+    return Box{-(W / 2.0f), W - W / 2.0f - 1.0f, 1.0f - H / 2.0f, H / 2.0f};
+}
+
+// Which of the nine end-point branches a light selects (uniform per (image, light)).  T8:386-460.
+struct LightCase {
+    int xcase, ycase;  // 0: below lo, 1: inside [lo, hi], 2: above hi
+};
+__device__ inline LightCase classify_light(float Cx, float Cy, const Box &bx)
+{
+    LightCase lc;
+    lc.xcase = (Cx < bx.x_lo) ? 0 : (Cx <= bx.x_hi ? 1 : 2);
+    lc.ycase = (Cy < bx.y_lo) ? 0 : (Cy <= bx.y_hi ? 1 : 2);
+    return lc;
+}
+
+// End point of the 2-D segment pixel -> light, clipped to the image box.  T8:378-465.
+// All f32, each operation separately rounded, arithmetic (not boolean) selection at T8:398.
+__device__ inline void end_point(float x, float y, float Cx, float Cy, const Box &bx, LightCase lc,
+                                 float &Ex, float &Ey)
+{
+    const float m = (Cy - y) / ((Cx - x) + kEps4);  // slopes      T8:378
+    const float ic = Cy - m * Cx;                   // intercepts  T8:379
+    float ex, ey;
+    if (lc.xcase == 1) {
+        if (lc.ycase == 1) {  // light projects inside the image: its own xy (T8:422-425)
+            ex = Cx;
+            ey = Cy;
+        } else {  // T8:417-421 / 426-430
+            const float yb = (lc.ycase == 0) ? bx.y_lo : bx.y_hi;
+            ex = (yb - ic) / (m + kEps4);
+            ey = yb;
+        }
+    } else {
+        const float xb = (lc.xcase == 0) ? bx.x_lo : bx.x_hi;
+        const float Xy = m * xb + ic;  // T8:390
+        if (lc.ycase == 1) {           // T8:399-403 / 444-448
+            ex = xb;
+            ey = Xy;
+        } else {  // corner branches T8:387-398, 404-415, 432-443, 449-460
+            const float yb = (lc.ycase == 0) ? bx.y_lo : bx.y_hi;
+            const float Yx = (yb - ic) / (m + kEps4);
+            const float b = (Yx >= bx.x_lo && Yx <= bx.x_hi) ? 1.0f : 0.0f;
+            const float nb = 1.0f - b;
+            ex = Yx * b + xb * nb;  // a non-finite candidate poisons the result, as in the reference
+            ey = yb * b + Xy * nb;
+        }
+    }
+    // clamp T8:462-465 (NaN passes through, as a masked assignment would leave it)
+    ex = (ex < bx.x_lo) ? bx.x_lo : ex;
+    ex = (ex > bx.x_hi) ? bx.x_hi : ex;
+    ey = (ey < bx.y_lo) ? bx.y_lo : ey;
+    ey = (ey > bx.y_hi) ? bx.y_hi : ey;
+    Ex = ex;
+    Ey = ey;
+}
+
+// torch's vector 2-norm accumulates acc = fma(v, v, acc) (probed; see oracle/gcfr_oracle.c).
+__device__ inline float norm3_torch(float a, float b, float c)
+{
+    return __builtin_sqrtf(__builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a)));
+}
+
+}  // namespace gcfr

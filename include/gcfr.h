@@ -1,0 +1,99 @@
+/*
+ * gcfr.h -- C ABI of libgcfr_hip.so: the MI355X (gfx950) implementation of GeomConsistentFR's
+ * render block (ray-marched soft shadow + Lambertian shading + compositing).
+ *
+ * The reference (andrewhou1/GeomConsistentFR) has NO operator/plugin/FFI interface for this path:
+ * the block is ~170 inline lines of torch ops at the end of RelightNet.forward
+ * (train_raytracing_relighting_CelebAHQ_DSSIM_8x.py:352-524, "T8"; inference variants
+ * test_relight_single_image.py:326-505 "S1", test_relight_single_image_lighting_transfer.py:325-514
+ * "SLT").  The entry points below are therefore the seams a maintainer would cut at T8:352; each one
+ * cites the reference lines it replaces.  INTEGRATION.md shows the ctypes binding and the edit to
+ * RelightNet.forward.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (hipMalloc / torch tensor storage),
+ *     contiguous, planes in NCHW order; nothing is allocated, freed or synchronised inside;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue work;
+ *   - re-entrant, no global state; return value: GCFR_OK or a negative gcfr_status;
+ *   - shapes: B images, L lights per image, H rows, W columns, N samples per ray.
+ *     Pixel (r,c) has image-plane coordinates x = c - W/2, y = H/2 - r           (T8:51-55).
+ */
+#ifndef GCFR_H
+#define GCFR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gcfr_status {
+    GCFR_OK = 0,
+    GCFR_ERR_INVALID_ARGUMENT = -1, /* null pointer / non-positive or unsupported dimension */
+    GCFR_ERR_LAUNCH = -2            /* hipGetLastError() != hipSuccess after the launch       */
+} gcfr_status;
+
+/* Library / build identification: "gcfr-hip <version> gfx950". */
+const char *gcfr_version(void);
+
+/*
+ * Sample fractions t_k along the pixel->light segment, HOST side helper.
+ * Replaces np.arange(t0, ., dt) at T8:468 (S1:445, SLT:451) with numpy's value rule
+ * t_k = t0 + k*((t0+dt)-t0), all f64.  Writes n doubles to `out_host`; upload it and pass the
+ * device copy as `t_table`.
+ */
+int gcfr_sample_table(double t0, double dt, int32_t n, double *out_host);
+
+/*
+ * Light preparation.  Replaces T8:357-363 (clamp_z = 1, clamp_min = 0; SLT:332 uses 0.16) and
+ * S1:332-336 (clamp_z = 0).
+ *   light_raw     (n,3) f32   SL_lin2[...,1:4] or target_lighting
+ *   unit_out      (n,3) f32   unit_light_direction
+ *   light_pt_out  (n,3) f32   incident_light_points = light_distance * unit (T8:362)
+ */
+int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_z, float clamp_min,
+                    float light_distance, float *unit_out, float *light_pt_out, void *stream);
+
+/*
+ * Ray march: minimum point-to-line distance over the sample table.  Replaces T8:371-515
+ * (S1:349-496, SLT:355-504): slopes/intercepts, the nine-way end-point branch, clamp, the
+ * (N,2,H,W) f64 sample grids, five gathers, bilinear depth, cross product distance, mask, min.
+ *   depth       (B,H,W) f32      c2_o_depth, already x100 (T8:350)
+ *   mask_u8     (MB,H,W) u8      1 where the reference's mask != 0; MB = mask_batch = B (T8:510)
+ *                                or 1 (one mask shared by all images, S1:488)
+ *   light_pt    (B,L,3) f32      from gcfr_light_prep
+ *   t_table     (N) f64          from gcfr_sample_table (device copy)
+ *   bonus       added to the minimum when the light's (x,y) lies inside bonus_box
+ *               = {x_lo, x_hi, y_lo, y_hi} (S1:495-496: box = image, bonus = 5; SLT:503-504);
+ *               training form: bonus = 0 (bonus_box may be NULL).  bonus_box is a HOST pointer.
+ *   min_dist    (B,L,H,W) f32 out   minimum_distance (T8:515)
+ *   argmin      (B,L,H,W) i32 out   index of the minimising sample (saved for backward); may be NULL
+ * Supported: 2 <= H,W <= 4096, even; 1 <= N <= 4096.
+ */
+int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32_t mask_batch,
+                    const float *light_pt, int32_t B, int32_t L, int32_t H, int32_t W, int32_t N,
+                    const double *t_table, float bonus, const float *bonus_box, float *min_dist,
+                    int32_t *argmin, void *stream);
+
+/*
+ * Soft-shadow transfer + Lambert shading + composite.  Replaces T8:364-369 and T8:517-522.
+ *   normals     (B,3,H,W) f32    depth_to_normals(depth+offset, K) with y negated (T8:353-354);
+ *                                 re-normalised inside (T8:365)
+ *   depth       (B,H,W) f32;  albedo (B,3,H,W) f32;  light_pt (B,L,3) f32;  ambient (B,L) f32
+ *   min_dist    (B,L,H,W) f32    from gcfr_shadow_fwd
+ *   intensity   directional_intensity (T8:46: 0.5; SLT:20: 0.41)
+ * outputs (any may be NULL except rendered):
+ *   shadow_w    (B,L,H,W) f32    shadow_mask_weights = 1 - 4e^-d/(1+e^-d)^2        (T8:517)
+ *   full        (B,L,H,W) f32    full_shading = ambient + I*max(n.l, 0)            (T8:366-369)
+ *   final       (B,L,H,W) f32    final_shading = w*full + (1-w)*ambient            (T8:518)
+ *   rendered    (B,L,3,H,W) f32  rendered_images = albedo * final                  (T8:519-522)
+ */
+int gcfr_shade_fwd(const float *normals, const float *depth, const float *albedo,
+                   const float *light_pt, const float *ambient, const float *min_dist, int32_t B,
+                   int32_t L, int32_t H, int32_t W, float intensity, float *shadow_w, float *full,
+                   float *final_shading, float *rendered, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCFR_H */

@@ -1,0 +1,61 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gcfr.h declares (no compute calls)."""
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gcfr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gcfr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from geomconsistentfr_amd import _lib
+    L = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 5
+    for s in syms:
+        assert hasattr(L, s), "libgcfr_hip.so does not export %s" % s
+    assert set(_lib.exported_symbols()) == set(syms), "python binding and header disagree"
+    assert b"gfx950" in L.gcfr_version()
+
+
+def test_sample_table_host_helper_matches_numpy():
+    from geomconsistentfr_amd import _lib
+    L = _lib.load()
+    for t0, dt, n, stop in [(0.025, 0.005, 160, 0.825), (0.03, 0.005, 159, 0.825), (0.025, 0.0025, 320, 0.825)]:
+        out = np.empty(n)
+        assert L.gcfr_sample_table(t0, dt, n, out.ctypes.data) == 0
+        np.testing.assert_array_equal(out, np.arange(t0, stop, dt))
+    assert L.gcfr_sample_table(0.0, 0.1, 0, None) == -1
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    from geomconsistentfr_amd import _lib
+    L = _lib.load()
+    assert L.gcfr_shadow_fwd(None, None, 1, None, 1, 1, 256, 256, 160, None, 0.0, None, None, None, None) == -1
+    assert L.gcfr_light_prep(None, 1, 1, 0.0, 4013.0, None, None, None) == -1
+    assert L.gcfr_shade_fwd(None, None, None, None, None, None, 1, 1, 8, 8, 0.5, None, None, None, None, None) == -1
+
+
+def test_product_has_no_cpu_fallback():
+    import pytest
+    import torch
+    from geomconsistentfr_amd import RenderParams, shadow_min_distance
+    from geomconsistentfr_amd._lib import GcfrError
+    with pytest.raises(GcfrError):
+        shadow_min_distance(torch.zeros(1, 8, 8), torch.ones(1, 8, 8), torch.ones(1, 1, 3), RenderParams())
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "geomconsistentfr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+(oracle|c_oracle|materialised|ref_shim)\b", src, re.M), f
+                assert "/root/reference" not in src, f

@@ -1,0 +1,175 @@
+"""GPU parity: the HIP path (through the C ABI, geomconsistentfr_amd._lib) against
+  (1) the golden vectors generated from the reference (tests/golden/),
+  (2) the CPU oracle on seeded inputs at other sizes / sample counts,
+  (3) size-independent properties at BASELINE.json's full size (B=8, 256x256, N=160).
+Gates (BASELINE.json north_star): shadow mask <= 1e-4 max-abs, shaded RGB <= 1e-3 max-abs.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+from golden_cases import all_cases, H, W  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+W_GATE = 1e-4      # north_star: shadow mask
+RGB_GATE = 1e-3    # north_star: shaded RGB
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def to_dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def camera(f):
+    K = torch.zeros(1, 3, 3, dtype=torch.float64)
+    K[:, 0, 0] = K[:, 1, 1] = f
+    K[:, 2, 2] = 1.0
+    K[:, 0, 2] = W / 2.0
+    K[:, 1, 2] = H / 2.0
+    return K
+
+
+def params_from(prm):
+    from geomconsistentfr_amd import RenderParams
+    return RenderParams(n_samples=prm["n_samples"], t0=prm["t0"], dt=prm["dt"],
+                        light_distance=prm["light_distance"], directional_intensity=prm["intensity"],
+                        clamp_light_z_min=prm["clamp_light_z_min"], inside_bonus=prm["bonus"],
+                        bonus_box=prm["bonus_box"])
+
+
+CASES = list(all_cases())
+
+
+@pytest.mark.parametrize("name,case", CASES, ids=[c[0] for c in CASES])
+def test_render_matches_reference_golden(name, case):
+    from geomconsistentfr_amd import render
+    from normals_restatement import depth_to_normals
+    prm, exp = case["params"], case["expect"]
+    n = depth_to_normals(torch.from_numpy(case["depth"])[:, None] + prm["normal_z_offset"], camera(prm["focal"]))
+    n[:, 1] = -n[:, 1]
+    out = render(to_dev(case["depth"])[:, None], to_dev(case["albedo"]), to_dev(case["light"]),
+                 to_dev(case["ambient"]), n.float().to(dev()), to_dev(case["mask"]), params_from(prm))
+    w = out["shadow_mask_weights"].cpu().numpy()
+    e_w = np.abs(w - exp["shadow_mask_weights"]).max()
+    assert e_w <= W_GATE, e_w
+    assert e_w <= 2e-5, "inside the gate but worse than the expected fp32 noise: %g" % e_w
+    np.testing.assert_allclose(out["unit_light_direction"].cpu().numpy().reshape(-1, 3),
+                               exp["unit_light_direction"].reshape(-1, 3), atol=1e-7)
+    if "full_shading" in exp:
+        assert np.abs(out["full_shading"].cpu().numpy() - exp["full_shading"]).max() <= 1e-5
+    if "rendered_images" in exp:
+        e = np.abs(out["rendered_images"].cpu().numpy() - exp["rendered_images"]).max()
+        assert e <= RGB_GATE, e
+        assert e <= 2e-5, e
+
+
+@pytest.mark.parametrize("Hs,Ws,N,t0,dt", [(64, 64, 48, 0.025, 0.016), (48, 96, 37, 0.02, 0.02),
+                                            (130, 70, 160, 0.025, 0.005), (256, 256, 160, 0.025, 0.005),
+                                            (512, 512, 320, 0.025, 0.0025)])
+def test_shadow_matches_c_oracle(Hs, Ws, N, t0, dt):
+    """min distance + argmin against the C oracle, including non-tile-multiple sizes and config 5's size."""
+    import c_oracle
+    from geomconsistentfr_amd import RenderParams, shadow_min_distance, light_prep
+    rng = np.random.default_rng(Hs * 1000 + Ws)
+    r, c = np.mgrid[0:Hs, 0:Ws]
+    depth = (0.3 * Hs * np.exp(-(((c - 0.45 * Ws) / (0.2 * Ws)) ** 2 + ((r - 0.5 * Hs) / (0.25 * Hs)) ** 2))
+             + rng.random((Hs, Ws))).astype(np.float32)
+    mask = (rng.random((Hs, Ws)) > 0.15).astype(np.uint8)
+    lights = np.array([[0.3, 0.5, 0.8], [-0.9, 0.1, 0.2], [0.001, -0.002, 1.0], [0.7, -0.7, 0.05],
+                       [-0.6, 0.7, 0.1], [0.02, 0.9, 0.3], [0.5, -0.8, -0.3], [0.9, 0.05, 0.3]], np.float32)
+    B = len(lights)
+    prm = RenderParams(n_samples=N, t0=t0, dt=dt)
+    unit_o, pt_o = c_oracle.light_prep(lights, clamp_z_min=0.0)
+    unit, pt = light_prep(to_dev(lights), prm)
+    np.testing.assert_array_equal(pt.cpu().numpy(), pt_o)
+    depth_b = np.stack([np.roll(depth, 3 * b, axis=1) for b in range(B)])
+    md, am = shadow_min_distance(to_dev(depth_b), to_dev(mask[None]), pt.reshape(B, 1, 3), prm)
+    md_o, am_o = c_oracle.shadow_min_distance(depth_b, mask[None], pt_o[:, None, :], c_oracle.sample_table(t0, dt, N))
+    md, am = md.cpu().numpy(), am.cpu().numpy()
+    lit = md_o < 1e5
+    assert np.array_equal(lit, md < 1e5)
+    assert np.abs(md[lit] - md_o[lit]).max() <= 1e-5 * max(1.0, np.abs(md_o[lit]).max())
+    np.testing.assert_array_equal(md[~lit], md_o[~lit])
+    # argmin: -1 marks "minimum is a masked sample" (no gradient); elsewhere identical up to exact ties
+    assert np.all(am[~lit] == -1)
+    assert (am[lit] == am_o[lit]).mean() >= 0.9999
+
+
+def _full_size_inputs(B=8):
+    rng = np.random.default_rng(42)
+    r, c = np.mgrid[0:H, 0:W]
+    x, y = c - 128.0, r - 128.0
+    depths, masks = [], []
+    for b in range(B):
+        ax, ay = 85 + 10 * rng.random(), 105 + 10 * rng.random()
+        d = 80 * np.sqrt(np.maximum(1 - (x / ax) ** 2 - (y / ay) ** 2, 0)) \
+            + (30 + 10 * rng.random()) * np.exp(-(x ** 2 / 288 + (y - 12) ** 2 / 648)) + 3 * np.sin(c / 7) * np.cos(r / 9)
+        depths.append(d.astype(np.float32))
+        masks.append((((x / (ax - 8)) ** 2 + (y / (ay - 8)) ** 2) < 1).astype(np.uint8))
+    lights = np.array([[0, .7071, .7071], [.8138, -.342, .4698], [-.8138, -.342, .4698], [.7518, 0, .6594],
+                       [-.7076, .3892, .5897], [.4478, .4925, .7463], [-.5151, .4722, .7154], [.5145, 0, .8575]],
+                      np.float32)[:B]
+    return np.stack(depths), np.stack(masks), lights
+
+
+def test_full_size_properties():
+    """B=8 x 256x256 x 160 (BASELINE config 2): determinism, batch independence, mask semantics."""
+    from geomconsistentfr_amd import RenderParams, shadow_min_distance, light_prep
+    prm = RenderParams()
+    depth, mask, lights = _full_size_inputs()
+    _, pt = light_prep(to_dev(lights), prm)
+    md1, am1 = shadow_min_distance(to_dev(depth), to_dev(mask), pt.reshape(8, 1, 3), prm)
+    md2, am2 = shadow_min_distance(to_dev(depth), to_dev(mask), pt.reshape(8, 1, 3), prm)
+    assert torch.equal(md1, md2) and torch.equal(am1, am2)                       # deterministic
+    for b in (0, 5):                                                             # batch independence
+        mdb, _ = shadow_min_distance(to_dev(depth[b:b + 1]), to_dev(mask[b:b + 1]), pt[b].reshape(1, 1, 3), prm)
+        assert torch.equal(mdb[0], md1[b])
+    # multi-light layout (B=1, L=8) == batch layout with the same depth repeated
+    md_l, _ = shadow_min_distance(to_dev(depth[:1]), to_dev(mask[:1]), pt.reshape(1, 8, 3), prm)
+    md_b, _ = shadow_min_distance(to_dev(np.repeat(depth[:1], 8, 0)), to_dev(mask[:1]), pt.reshape(8, 1, 3), prm)
+    assert torch.equal(md_l[0], md_b[:, 0])
+    # all-zero mask: every sample is "outside the face" -> distance 1e6 everywhere (w = 1, fully lit)
+    md0, am0 = shadow_min_distance(to_dev(depth), to_dev(np.zeros_like(mask)), pt.reshape(8, 1, 3), prm)
+    assert torch.all(md0 == 1e6) and torch.all(am0 == -1)
+    # enlarging the mask can only lower the minimum distance
+    md_all, _ = shadow_min_distance(to_dev(depth), to_dev(np.ones_like(mask)), pt.reshape(8, 1, 3), prm)
+    assert torch.all(md_all <= md1)
+    assert torch.isfinite(md1).all() and (md1 >= 0).all()
+
+
+def test_shade_matches_c_oracle_random_normals():
+    import c_oracle
+    from geomconsistentfr_amd.block import shade
+    rng = np.random.default_rng(7)
+    B, L, Hs, Ws = 2, 3, 40, 56
+    normals = rng.standard_normal((B, 3, Hs, Ws)).astype(np.float32)
+    depth = (30 * rng.random((B, Hs, Ws))).astype(np.float32)
+    albedo = rng.random((B, 3, Hs, Ws), dtype=np.float32)
+    pt = (4013 * rng.standard_normal((B, L, 3)) / 1.7).astype(np.float32)
+    amb = rng.random((B, L), dtype=np.float32)
+    md = (rng.random((B, L, Hs, Ws)) * 6).astype(np.float32)
+    md[0, 0, :5] = 1e6
+    md[1, 2, 5:9] = 0.0
+    o = shade(to_dev(normals), to_dev(depth), to_dev(albedo), to_dev(pt), to_dev(amb), to_dev(md))
+    ref = c_oracle.shade(normals.astype(np.float64), depth, albedo, pt, amb, md)
+    assert np.abs(o["shadow_mask_weights"].cpu().numpy() - ref["shadow_w"]).max() <= 1e-6
+    assert np.abs(o["full_shading"].cpu().numpy() - ref["full_shading"]).max() <= 1e-6
+    assert np.abs(o["final_shading"].cpu().numpy() - ref["final_shading"]).max() <= 1e-6
+    assert np.abs(o["rendered_images"].cpu().numpy() - ref["rendered"]).max() <= 1e-6
+
+
+def test_no_cpu_path():
+    from geomconsistentfr_amd import RenderParams, shadow_min_distance
+    from geomconsistentfr_amd._lib import GcfrError
+    with pytest.raises(GcfrError):
+        shadow_min_distance(torch.zeros(1, 8, 8), torch.ones(1, 8, 8), torch.ones(1, 1, 3), RenderParams())
