@@ -149,8 +149,79 @@ def shade(normals, depth, albedo, light_pt, ambient, min_dist, params: RenderPar
     return dict(shadow_mask_weights=w, full_shading=full, final_shading=fin, rendered_images=ren)
 
 
+def _zeros(shape, dtype, device):
+    return torch.zeros(shape, dtype=dtype, device=device)
+
+
+def _opt_ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+class _RenderFunction(torch.autograd.Function):
+    """autograd glue around the HIP forward/backward kernels (one light per image).
+
+    Differentiable inputs: depth, albedo, light, ambient, normals -- the leaves autograd reaches in the
+    reference (T8:352-524).  The mask and the constants are not differentiable."""
+
+    @staticmethod
+    def forward(ctx, depth, albedo, light, ambient, normals, mask_u8, params):
+        B, _, H, W = depth.shape
+        depth3 = _f32c(depth).reshape(B, H, W)
+        light2 = _f32c(light).reshape(B, 3)
+        amb = _f32c(ambient).reshape(B, 1)
+        albedo_c = _f32c(albedo)
+        normals_c = _f32c(normals)
+        unit, pt = light_prep(light2, params)
+        need_grad = any(ctx.needs_input_grad[:5])
+        md, am = shadow_min_distance(depth3, mask_u8, pt.reshape(B, 1, 3), params, want_argmin=need_grad)
+        out = shade(normals_c, depth3, albedo_c, pt.reshape(B, 1, 3), amb, md, params)
+        ctx.params = params
+        if need_grad:
+            ctx.save_for_backward(depth3, albedo_c, light2, amb, normals_c, pt, md, am)
+        w, full, fin, ren = (out["shadow_mask_weights"][:, 0], out["full_shading"][:, 0],
+                             out["final_shading"][:, 0], out["rendered_images"][:, 0])
+        md0 = md[:, 0]
+        ctx.mark_non_differentiable(md0)
+        return w, full, fin, ren, unit, md0
+
+    @staticmethod
+    def backward(ctx, g_w, g_full, g_fin, g_ren, g_unit, _g_md):
+        depth3, albedo, light2, amb, normals, pt, md, am = ctx.saved_tensors
+        prm = ctx.params
+        L_ = _lib.load()
+        B, H, W = depth3.shape
+        dev = depth3.device
+        gw, gfull, gfin, gren = [None if g is None else _f32c(g) for g in (g_w, g_full, g_fin, g_ren)]
+        grad_normals = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+        grad_albedo = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+        grad_depth = _zeros((B, H, W), torch.float32, dev)
+        grad_pt = _zeros((B, 1, 3), torch.float64, dev)
+        grad_amb = _zeros((B, 1), torch.float64, dev)
+        grad_md = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        tt = sample_table(prm, dev)
+        with torch.cuda.device(dev):
+            st = _stream_ptr(dev)
+            _lib.check(L_.gcfr_shade_bwd(normals.data_ptr(), depth3.data_ptr(), albedo.data_ptr(), pt.data_ptr(),
+                                         amb.data_ptr(), md.data_ptr(), B, 1, H, W, float(prm.directional_intensity),
+                                         _opt_ptr(gw), _opt_ptr(gfull), _opt_ptr(gfin), _opt_ptr(gren),
+                                         grad_normals.data_ptr(), grad_albedo.data_ptr(), grad_depth.data_ptr(),
+                                         grad_pt.data_ptr(), grad_amb.data_ptr(), grad_md.data_ptr(), st),
+                       "gcfr_shade_bwd")
+            _lib.check(L_.gcfr_shadow_bwd(grad_md.data_ptr(), depth3.data_ptr(), pt.data_ptr(), am.data_ptr(),
+                                          B, 1, H, W, prm.n_samples, tt.data_ptr(), grad_depth.data_ptr(),
+                                          grad_pt.data_ptr(), st), "gcfr_shadow_bwd")
+            grad_light = torch.empty((B, 3), dtype=torch.float32, device=dev)
+            gu = None if g_unit is None else _f32c(g_unit).reshape(B, 3)
+            clamp = prm.clamp_light_z_min is not None
+            _lib.check(L_.gcfr_light_prep_bwd(light2.data_ptr(), B, int(clamp), float(prm.clamp_light_z_min or 0.0),
+                                              float(prm.light_distance), _opt_ptr(gu), grad_pt.data_ptr(),
+                                              grad_light.data_ptr(), st), "gcfr_light_prep_bwd")
+        return (grad_depth.reshape(B, 1, H, W), grad_albedo, grad_light, grad_amb.reshape(B).float(),
+                grad_normals, None, None)
+
+
 def render(depth, albedo, light, ambient, normals, mask, params: RenderParams = RenderParams()):
-    """Forward render block for a batch with one light per image (the reference's call shape).
+    """Render block for a batch with one light per image (the reference's call shape), differentiable.
 
       depth (B,1,H,W) f32      c2_o_depth (x100 already applied, T8:350)
       albedo (B,3,H,W) f32     c2_o_albedo
@@ -159,20 +230,22 @@ def render(depth, albedo, light, ambient, normals, mask, params: RenderParams = 
       normals (B,3,H,W)        depth_to_normals(depth+offset, K), y negated (T8:353-354)
       mask (B,H,W) or (1,H,W)  0 = outside the face (T8:510)
 
-    Returns the reference's tensors by name (T8:524 / S1:505), all f32."""
+    Returns the reference's tensors by name (T8:524 / S1:505), all f32.  Gradients flow to depth, albedo,
+    light, ambient and normals through the HIP backward kernels."""
+    _require_device(depth, albedo, light, ambient, normals, mask)
     B, _, H, W = depth.shape
-    unit, pt = light_prep(light.reshape(B, 3), params)
-    md, am = shadow_min_distance(depth.reshape(B, H, W), mask.reshape(-1, H, W), pt.reshape(B, 1, 3), params)
-    out = shade(normals, depth.reshape(B, H, W), albedo, pt.reshape(B, 1, 3), ambient.reshape(B, 1), md, params)
-    amb = _f32c(ambient).reshape(B, 1, 1)
+    mask_u8 = mask_to_u8(mask).reshape(-1, H, W)
+    light = light.reshape(B, 3)
+    ambient = ambient.reshape(B)
+    w, full, fin, ren, unit, md = _RenderFunction.apply(depth, albedo, light, ambient, normals, mask_u8, params)
+    amb = ambient.to(torch.float32).reshape(B, 1, 1)
     return dict(
-        shadow_mask_weights=out["shadow_mask_weights"][:, 0],
+        shadow_mask_weights=w,
         ambient_light=amb.expand(B, H, W),
-        full_shading=out["full_shading"][:, 0],
-        rendered_images=out["rendered_images"][:, 0],
+        full_shading=full,
+        rendered_images=ren,
         unit_light_direction=unit.reshape(B, 3, 1, 1),
         ambient_values=amb,
-        final_shading=out["final_shading"][:, 0],
-        minimum_distance=md[:, 0],
-        argmin=am[:, 0],
+        final_shading=fin,
+        minimum_distance=md,
     )

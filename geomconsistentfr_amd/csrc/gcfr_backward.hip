@@ -1,0 +1,411 @@
+// Backward of the render block, gfx950.
+//
+// The reference has no hand-written backward: torch autograd replays the ~90 tensor ops of
+// train_raytracing_relighting_CelebAHQ_DSSIM_8x.py:352-524 per image.  Only ONE sample per pixel
+// carries gradient (torch.min scatters to its argmin, T8:514), so the backward of the ray march is
+// a per-pixel, not a per-ray-step, computation: re-evaluate the argmin sample with the forward's
+// exact position pipeline, then apply the chain rule in f64:
+//     d  <- num/den,  num = sqrt(|BA x BC|^2 + 1e-4),  den = sqrt(|BC|^2 + 1e-4)
+//     BA <- A - B,  A = (u_x - W/2, H/2 - u_y, zA),  zA bilinear in 4 depth corners and in u
+//     u  <- start + t_k (E - start),  E <- (slope, intercept) by the selected end-point branch
+//     slope, intercept <- light point C;  BC <- C - B;  B_z = own depth
+// round / floor / ceil, the branch choice and the clamp are piecewise constant: zero gradient
+// (exactly what autograd gives the reference).  Gradients reach: the 4 bilinear corners and the
+// pixel's own depth (f32 atomics into grad_depth), and the light point (block reduction, then one
+// f64 atomic per block and component).
+#include "gcfr_device.hpp"
+
+#include "../../include/gcfr.h"
+
+namespace gcfr {
+
+__device__ inline double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Block-wide sum of up to NV doubles per thread -> one atomicAdd per value from thread 0.
+template <int NV>
+__device__ inline void block_reduce_atomic(double (&v)[NV], double *dst)
+{
+    __shared__ double part[4][NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double s = wave_sum(v[i]);
+        if (lane == 0)
+            part[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const double s = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (s != 0.0)
+            atomicAdd(dst + threadIdx.x, s);
+    }
+    __syncthreads();
+}
+
+// ----------------------------------------------------------------------------------------------
+// shadow backward
+// ----------------------------------------------------------------------------------------------
+struct ShadowBwdArgs {
+    const float *grad_min_dist;  // (B,L,H,W)
+    const float *depth;          // (B,H,W)
+    const float *light_pt;       // (B,L,3)
+    const int32_t *argmin;       // (B,L,H,W)
+    const double *t_table;       // (N)
+    float *grad_depth;           // (B,H,W)   +=
+    double *grad_light_pt;       // (B,L,3)   +=
+    int32_t L, H, W, N;
+};
+
+__global__ __launch_bounds__(256) void shadow_bwd_kernel(ShadowBwdArgs a)
+{
+    const int H = a.H, W = a.W;
+    const size_t P = (size_t)H * W;
+    const int bl = blockIdx.y;
+    const int b = bl / a.L;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double gC[3] = {0.0, 0.0, 0.0};
+
+    if (p < P) {
+        const int k = a.argmin[(size_t)bl * P + p];
+        const float g32 = a.grad_min_dist[(size_t)bl * P + p];
+        if (k >= 0 && k < a.N && g32 != 0.0f) {
+            const int r = (int)(p / W), c = (int)(p - (size_t)r * W);
+            const float *zimg = a.depth + (size_t)b * P;
+            float *gz = a.grad_depth + (size_t)b * P;
+            const float Cx = a.light_pt[3 * bl + 0], Cy = a.light_pt[3 * bl + 1], Cz = a.light_pt[3 * bl + 2];
+            const Box box = image_box(H, W);
+            const LightCase lc = classify_light(Cx, Cy, box);
+            const double halfW = W / 2.0, halfH = H / 2.0;
+            const float x = (float)c - W / 2.0f, y = H / 2.0f - (float)r;
+            const float zb = zimg[p];
+
+            // ---- forward recomputation at sample k (identical decisions to the forward kernel) ----
+            const float pden = (Cx - x) + kEps4;
+            const float m = (Cy - y) / pden;
+            const float ic = Cy - m * Cx;
+            float Ex, Ey;
+            end_point(x, y, Cx, Cy, box, lc, Ex, Ey);
+            // which candidate produced E, and whether the clamp cut it (zero gradient then)
+            //   kind 0: constant (light inside the image)   kind 1: X candidate (xb, m*xb+ic)
+            //   kind 2: Y candidate ((yb-ic)/(m+e), yb)
+            int kind;
+            float xb = 0.0f, yb = 0.0f;
+            if (lc.xcase == 1) {
+                kind = (lc.ycase == 1) ? 0 : 2;
+                yb = (lc.ycase == 0) ? box.y_lo : box.y_hi;
+            } else {
+                xb = (lc.xcase == 0) ? box.x_lo : box.x_hi;
+                if (lc.ycase == 1) {
+                    kind = 1;
+                } else {
+                    yb = (lc.ycase == 0) ? box.y_lo : box.y_hi;
+                    const float Yx = (yb - ic) / (m + kEps4);
+                    kind = (Yx >= box.x_lo && Yx <= box.x_hi) ? 2 : 1;
+                }
+            }
+            // unclamped candidate values, to detect the clamp (T8:462-465)
+            float ux_raw, uy_raw;
+            if (kind == 0) {
+                ux_raw = Cx;
+                uy_raw = Cy;
+            } else if (kind == 1) {
+                ux_raw = xb;
+                uy_raw = m * xb + ic;
+            } else {
+                ux_raw = (yb - ic) / (m + kEps4);
+                uy_raw = yb;
+            }
+            const bool live_x = !(ux_raw < box.x_lo) && !(ux_raw > box.x_hi);
+            const bool live_y = !(uy_raw < box.y_lo) && !(uy_raw > box.y_hi);
+
+            const float dxf = Ex - x, dyf = Ey - y;
+            const double t = a.t_table[k];
+            const double sx = (double)x + t * (double)dxf;
+            const double sy = (double)y + t * (double)dyf;
+            const double ux = (sx + halfW) - 0.0001, uy = (halfH - sy) - 0.0001;
+            const double fxd = floor(ux), gxd = ceil(ux), fyd = floor(uy), gyd = ceil(uy);
+            int fx = (int)fxd, gx = (int)gxd, fy = (int)fyd, gy = (int)gyd;
+            fx += (fx >> 31) & W;
+            fy += (fy >> 31) & H;
+            const double wx0 = gxd - ux, wx1 = ux - fxd, wy0 = gyd - uy, wy1 = uy - fyd;
+            const size_t iUL = (size_t)fy * W + fx, iUR = (size_t)fy * W + gx;
+            const size_t iLL = (size_t)gy * W + fx, iLR = (size_t)gy * W + gx;
+            const double zUL = zimg[iUL], zUR = zimg[iUR], zLL = zimg[iLL], zLR = zimg[iLR];
+            const double up = zUL * wx0 + zUR * wx1, low = zLL * wx0 + zLR * wx1;
+            const double zA = up * wy0 + low * wy1;
+            const float Axf = (float)(ux - halfW), Ayf = (float)(halfH - uy), Azf = (float)zA;
+            const double BAx = (double)(Axf - x), BAy = (double)(Ayf - y), BAz = (double)(Azf - zb);
+            const double BCx = (double)(Cx - x), BCy = (double)(Cy - y), BCz = (double)(Cz - zb);
+            const double Xx = BAy * BCz - BAz * BCy, Xy = BAz * BCx - BAx * BCz, Xz = BAx * BCy - BAy * BCx;
+            const double num = sqrt(Xx * Xx + Xy * Xy + Xz * Xz + 1e-4);
+            const double den = sqrt(BCx * BCx + BCy * BCy + BCz * BCz + 1e-4);
+
+            // ---- chain rule ----
+            const double g = (double)g32;
+            const double dnum = g / den, dden = -g * num / (den * den);
+            const double s1 = dnum / num;  // d(|X|^2+eps)^(1/2) = X/num
+            const double dXx = s1 * Xx, dXy = s1 * Xy, dXz = s1 * Xz;
+            const double s2 = dden / den;
+            double dBCx = s2 * BCx, dBCy = s2 * BCy, dBCz = s2 * BCz;
+            // X = BA x BC:  dBA = BC x dX ;  dBC += dX x BA
+            const double dBAx = BCy * dXz - BCz * dXy;
+            const double dBAy = BCz * dXx - BCx * dXz;
+            const double dBAz = BCx * dXy - BCy * dXx;
+            dBCx += dXy * BAz - dXz * BAy;
+            dBCy += dXz * BAx - dXx * BAz;
+            dBCz += dXx * BAy - dXy * BAx;
+            // B = (x, y, zb): only zb is differentiable
+            const double dzb = -dBAz - dBCz;
+            gC[0] = dBCx;
+            gC[1] = dBCy;
+            gC[2] = dBCz;
+            // A = (u_x - W/2, H/2 - u_y, zA)
+            const double dzA = dBAz;
+            const double dzA_dux = wy0 * (zUR - zUL) + wy1 * (zLR - zLL);
+            const double dzA_duy = low - up;
+            const double dux = dBAx + dzA * dzA_dux;
+            const double duy = -dBAy + dzA * dzA_duy;
+            // u_x = s_x + W/2 - e ;  u_y = H/2 - s_y - e ;  s = start + t*(E - start)
+            const double dEx = live_x ? t * dux : 0.0;
+            const double dEy = live_y ? -t * duy : 0.0;
+            double dm = 0.0, dic = 0.0;
+            if (kind == 1) {  // E = (xb, m*xb + ic)
+                dm = dEy * (double)xb;
+                dic = dEy;
+            } else if (kind == 2) {  // E = ((yb - ic)/(m + e), yb)
+                const double q = (double)(m + kEps4);
+                dic = -dEx / q;
+                dm = -dEx * (double)ux_raw / q;
+            }
+            // ic = Cy - m*Cx ;  m = (Cy - y)/(Cx - x + e)
+            gC[1] += dic;
+            dm += -dic * (double)Cx;
+            gC[0] += -dic * (double)m;
+            gC[1] += dm / (double)pden;
+            gC[0] += -dm * (double)m / (double)pden;
+
+            // depth: four bilinear corners + the pixel's own depth
+            atomicAdd(gz + iUL, (float)(dzA * wx0 * wy0));
+            atomicAdd(gz + iUR, (float)(dzA * wx1 * wy0));
+            atomicAdd(gz + iLL, (float)(dzA * wx0 * wy1));
+            atomicAdd(gz + iLR, (float)(dzA * wx1 * wy1));
+            atomicAdd(gz + p, (float)dzb);
+        }
+    }
+    block_reduce_atomic<3>(gC, a.grad_light_pt + 3 * (size_t)bl);
+}
+
+// ----------------------------------------------------------------------------------------------
+// shade backward: one thread per (image, pixel), loop over that image's lights
+// ----------------------------------------------------------------------------------------------
+struct ShadeBwdArgs {
+    const float *normals, *depth, *albedo, *light_pt, *ambient, *min_dist;
+    const float *g_w, *g_full, *g_final, *g_rendered;  // upstream grads, any may be null
+    float *grad_normals;   // (B,3,H,W)  =
+    float *grad_albedo;    // (B,3,H,W)  =
+    float *grad_depth;     // (B,H,W)    +=
+    double *grad_light_pt; // (B,L,3)    +=
+    double *grad_ambient;  // (B,L)      +=
+    float *grad_min_dist;  // (B,L,H,W)  =
+    int32_t L, H, W;
+    float intensity;
+};
+
+__global__ __launch_bounds__(256) void shade_bwd_kernel(ShadeBwdArgs a)
+{
+    const int H = a.H, W = a.W, L = a.L;
+    const size_t P = (size_t)H * W;
+    const int b = blockIdx.y;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = p < P;
+    const size_t pp = live ? p : 0;
+    const int r = (int)(pp / W), c = (int)(pp - (size_t)r * W);
+    const float x = (float)c - W / 2.0f, y = H / 2.0f - (float)r;
+    const float zb = a.depth[(size_t)b * P + pp];
+    const double nx = a.normals[((size_t)b * 3 + 0) * P + pp];
+    const double ny = a.normals[((size_t)b * 3 + 1) * P + pp];
+    const double nz = a.normals[((size_t)b * 3 + 2) * P + pp];
+    double nn = sqrt(nx * nx + ny * ny + nz * nz);
+    nn = nn > 1e-12 ? nn : 1e-12;
+    const double n0 = nx / nn, n1 = ny / nn, n2 = nz / nn;
+    const double al0 = a.albedo[((size_t)b * 3 + 0) * P + pp];
+    const double al1 = a.albedo[((size_t)b * 3 + 1) * P + pp];
+    const double al2 = a.albedo[((size_t)b * 3 + 2) * P + pp];
+
+    double gn0 = 0.0, gn1 = 0.0, gn2 = 0.0, ga0 = 0.0, ga1 = 0.0, ga2 = 0.0, gzb = 0.0;
+
+    for (int l = 0; l < L; ++l) {
+        const int bl = b * L + l;
+        const size_t o = (size_t)bl * P + pp;
+        const double Cx = a.light_pt[3 * bl + 0], Cy = a.light_pt[3 * bl + 1], Cz = a.light_pt[3 * bl + 2];
+        const double amb = a.ambient[bl];
+        double red[4] = {0.0, 0.0, 0.0, 0.0};  // dC.xyz, d ambient
+        if (live) {
+            // forward values
+            const double lx = Cx - x, ly = Cy - y, lz = Cz - zb;
+            double ln = sqrt(lx * lx + ly * ly + lz * lz);
+            ln = ln > 1e-12 ? ln : 1e-12;
+            const double u0 = lx / ln, u1 = ly / ln, u2 = lz / ln;
+            const double dot = n0 * u0 + n1 * u1 + n2 * u2;
+            const double full = amb + (double)a.intensity * (dot > 0.0 ? dot : 0.0);
+            const double d = a.min_dist[o];
+            const double e = exp(-d);
+            const double ope = 1.0 + e;
+            const double w = 1.0 - 4.0 * e / (ope * ope);
+            const double fin = w * full + (1.0 - w) * amb;
+            // upstream
+            const double gr0 = a.g_rendered ? (double)a.g_rendered[((size_t)bl * 3 + 0) * P + pp] : 0.0;
+            const double gr1 = a.g_rendered ? (double)a.g_rendered[((size_t)bl * 3 + 1) * P + pp] : 0.0;
+            const double gr2 = a.g_rendered ? (double)a.g_rendered[((size_t)bl * 3 + 2) * P + pp] : 0.0;
+            ga0 += gr0 * fin;  // rendered = albedo * final  (T8:520-522)
+            ga1 += gr1 * fin;
+            ga2 += gr2 * fin;
+            const double dfin = (gr0 * al0 + gr1 * al1 + gr2 * al2) + (a.g_final ? (double)a.g_final[o] : 0.0);
+            // final = w*full + (1-w)*amb  (T8:518)
+            const double dw = dfin * (full - amb) + (a.g_w ? (double)a.g_w[o] : 0.0);
+            const double dfull = dfin * w + (a.g_full ? (double)a.g_full[o] : 0.0);
+            red[3] = dfin * (1.0 - w) + dfull;  // ambient enters final directly and through full
+            // w = 1 - 4e/(1+e)^2, e = exp(-d):  dw/dd = 4e(1-e)/(1+e)^3  (T8:517)
+            a.grad_min_dist[o] = (float)(dw * (4.0 * e * (1.0 - e)) / (ope * ope * ope));
+            // full = amb + I*max(dot,0)  (T8:366)
+            const double ddot = (dot > 0.0) ? dfull * (double)a.intensity : 0.0;
+            const double dn0 = ddot * u0, dn1 = ddot * u1, dn2 = ddot * u2;  // d n_hat
+            const double du0 = ddot * n0, du1 = ddot * n1, du2 = ddot * n2;  // d l_hat
+            // n_hat = n/|n|
+            const double nd = n0 * dn0 + n1 * dn1 + n2 * dn2;
+            gn0 += (dn0 - n0 * nd) / nn;
+            gn1 += (dn1 - n1 * nd) / nn;
+            gn2 += (dn2 - n2 * nd) / nn;
+            // l_hat = l/|l|, l = C - P
+            const double ud = u0 * du0 + u1 * du1 + u2 * du2;
+            const double dl0 = (du0 - u0 * ud) / ln, dl1 = (du1 - u1 * ud) / ln, dl2 = (du2 - u2 * ud) / ln;
+            red[0] = dl0;
+            red[1] = dl1;
+            red[2] = dl2;
+            gzb -= dl2;
+        }
+        // per-(image, light) reductions: light point and ambient
+        double red3[3] = {red[0], red[1], red[2]};
+        block_reduce_atomic<3>(red3, a.grad_light_pt + 3 * (size_t)bl);
+        double red1[1] = {red[3]};
+        block_reduce_atomic<1>(red1, a.grad_ambient + bl);
+    }
+    if (live) {
+        a.grad_normals[((size_t)b * 3 + 0) * P + p] = (float)gn0;
+        a.grad_normals[((size_t)b * 3 + 1) * P + p] = (float)gn1;
+        a.grad_normals[((size_t)b * 3 + 2) * P + p] = (float)gn2;
+        a.grad_albedo[((size_t)b * 3 + 0) * P + p] = (float)ga0;
+        a.grad_albedo[((size_t)b * 3 + 1) * P + p] = (float)ga1;
+        a.grad_albedo[((size_t)b * 3 + 2) * P + p] = (float)ga2;
+        atomicAdd(a.grad_depth + (size_t)b * P + p, (float)gzb);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// light-prep backward (n tiny): unit = l'/max(|l'|,eps), l' = (a, b, max(c, clamp)), pt = dist*unit
+// ----------------------------------------------------------------------------------------------
+__global__ void light_prep_bwd_kernel(const float *__restrict__ light_raw, int n, int clamp_z,
+                                      float clamp_min, float light_distance,
+                                      const float *__restrict__ grad_unit,
+                                      const double *__restrict__ grad_light_pt,
+                                      float *__restrict__ grad_light_raw)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const double a = light_raw[3 * i + 0], b = light_raw[3 * i + 1];
+    double c = light_raw[3 * i + 2];
+    double zpass = 1.0;
+    if (clamp_z) {  // torch.maximum backward: 1 above, 0 below, 1/2 on a tie
+        zpass = (c > (double)clamp_min) ? 1.0 : (c == (double)clamp_min ? 0.5 : 0.0);
+        c = (c > (double)clamp_min) ? c : (double)clamp_min;
+    }
+    const double nrm = sqrt(a * a + b * b + c * c);
+    const double d = nrm > 1e-12 ? nrm : 1e-12;
+    const double u0 = a / d, u1 = b / d, u2 = c / d;
+    double g0 = grad_light_pt ? (double)light_distance * grad_light_pt[3 * i + 0] : 0.0;
+    double g1 = grad_light_pt ? (double)light_distance * grad_light_pt[3 * i + 1] : 0.0;
+    double g2 = grad_light_pt ? (double)light_distance * grad_light_pt[3 * i + 2] : 0.0;
+    if (grad_unit) {
+        g0 += grad_unit[3 * i + 0];
+        g1 += grad_unit[3 * i + 1];
+        g2 += grad_unit[3 * i + 2];
+    }
+    double r0, r1, r2;
+    if (nrm > 1e-12) {
+        const double ug = u0 * g0 + u1 * g1 + u2 * g2;
+        r0 = (g0 - u0 * ug) / d;
+        r1 = (g1 - u1 * ug) / d;
+        r2 = (g2 - u2 * ug) / d;
+    } else {  // clamp_min(eps) active: the denominator is a constant
+        r0 = g0 / d;
+        r1 = g1 / d;
+        r2 = g2 / d;
+    }
+    grad_light_raw[3 * i + 0] = (float)r0;
+    grad_light_raw[3 * i + 1] = (float)r1;
+    grad_light_raw[3 * i + 2] = (float)(r2 * zpass);
+}
+
+}  // namespace gcfr
+
+using namespace gcfr;
+
+static inline int launch_status() { return hipGetLastError() == hipSuccess ? GCFR_OK : GCFR_ERR_LAUNCH; }
+
+extern "C" int gcfr_shadow_bwd(const float *grad_min_dist, const float *depth, const float *light_pt,
+                               const int32_t *argmin, int32_t B, int32_t L, int32_t H, int32_t W,
+                               int32_t N, const double *t_table, float *grad_depth,
+                               double *grad_light_pt, void *stream)
+{
+    if (!grad_min_dist || !depth || !light_pt || !argmin || !t_table || !grad_depth || !grad_light_pt)
+        return GCFR_ERR_INVALID_ARGUMENT;
+    if (B <= 0 || L <= 0 || N <= 0 || H < 2 || W < 2 || H > 4096 || W > 4096 || (H & 1) || (W & 1) ||
+        (long long)B * L > 65535)
+        return GCFR_ERR_INVALID_ARGUMENT;
+    ShadowBwdArgs a{grad_min_dist, depth, light_pt, argmin, t_table, grad_depth, grad_light_pt, L, H, W, N};
+    const size_t P = (size_t)H * W;
+    hipLaunchKernelGGL(shadow_bwd_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)(B * L)), dim3(256),
+                       0, (hipStream_t)stream, a);
+    return launch_status();
+}
+
+extern "C" int gcfr_shade_bwd(const float *normals, const float *depth, const float *albedo,
+                              const float *light_pt, const float *ambient, const float *min_dist,
+                              int32_t B, int32_t L, int32_t H, int32_t W, float intensity,
+                              const float *g_shadow_w, const float *g_full, const float *g_final,
+                              const float *g_rendered, float *grad_normals, float *grad_albedo,
+                              float *grad_depth, double *grad_light_pt, double *grad_ambient,
+                              float *grad_min_dist, void *stream)
+{
+    if (!normals || !depth || !albedo || !light_pt || !ambient || !min_dist || !grad_normals ||
+        !grad_albedo || !grad_depth || !grad_light_pt || !grad_ambient || !grad_min_dist)
+        return GCFR_ERR_INVALID_ARGUMENT;
+    if (B <= 0 || L <= 0 || H <= 0 || W <= 0 || B > 65535)
+        return GCFR_ERR_INVALID_ARGUMENT;
+    ShadeBwdArgs a{normals, depth, albedo, light_pt, ambient, min_dist, g_shadow_w, g_full, g_final,
+                   g_rendered, grad_normals, grad_albedo, grad_depth, grad_light_pt, grad_ambient,
+                   grad_min_dist, L, H, W, intensity};
+    const size_t P = (size_t)H * W;
+    hipLaunchKernelGGL(shade_bwd_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    return launch_status();
+}
+
+extern "C" int gcfr_light_prep_bwd(const float *light_raw, int32_t n, int32_t clamp_z, float clamp_min,
+                                   float light_distance, const float *grad_unit,
+                                   const double *grad_light_pt, float *grad_light_raw, void *stream)
+{
+    if (!light_raw || !grad_light_raw || n <= 0 || (!grad_unit && !grad_light_pt))
+        return GCFR_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(light_prep_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       light_raw, n, clamp_z, clamp_min, light_distance, grad_unit, grad_light_pt,
+                       grad_light_raw);
+    return launch_status();
+}

@@ -93,6 +93,51 @@ int gcfr_shade_fwd(const float *normals, const float *depth, const float *albedo
                    int32_t L, int32_t H, int32_t W, float intensity, float *shadow_w, float *full,
                    float *final_shading, float *rendered, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backward.  The reference has no explicit backward: torch autograd replays T8:352-524
+ * (loss.backward() at T8:655).  These entry points compute the same vector-Jacobian products.
+ * Buffers marked "+=" are ACCUMULATED into (zero them first); "=" are overwritten.
+ * ------------------------------------------------------------------------------------------- */
+
+/*
+ * Backward of gcfr_shadow_fwd (T8:371-515 under autograd): only the argmin sample of each pixel
+ * carries gradient (torch.min, T8:514); round/floor/ceil, the end-point branch and the clamp are
+ * piecewise constant.
+ *   grad_min_dist (B,L,H,W) f32   dLoss/d minimum_distance
+ *   argmin        (B,L,H,W) i32   from gcfr_shadow_fwd (-1 = masked minimum: no gradient)
+ *   grad_depth    (B,H,W) f32 +=  to the four bilinear corners and the pixel's own depth (atomics)
+ *   grad_light_pt (B,L,3) f64 +=  to incident_light_points (reduced over pixels in f64)
+ */
+int gcfr_shadow_bwd(const float *grad_min_dist, const float *depth, const float *light_pt,
+                    const int32_t *argmin, int32_t B, int32_t L, int32_t H, int32_t W, int32_t N,
+                    const double *t_table, float *grad_depth, double *grad_light_pt, void *stream);
+
+/*
+ * Backward of gcfr_shade_fwd (T8:364-369, 517-522 under autograd).
+ *   g_shadow_w, g_full, g_final (B,L,H,W) f32, g_rendered (B,L,3,H,W) f32: upstream grads, any may be NULL
+ *   grad_normals (B,3,H,W) f32 =   (w.r.t. the un-normalised normals passed to the forward)
+ *   grad_albedo  (B,3,H,W) f32 =
+ *   grad_depth   (B,H,W) f32 +=    through the incident-light direction only
+ *   grad_light_pt (B,L,3) f64 +=,  grad_ambient (B,L) f64 +=
+ *   grad_min_dist (B,L,H,W) f32 =  feed to gcfr_shadow_bwd
+ */
+int gcfr_shade_bwd(const float *normals, const float *depth, const float *albedo,
+                   const float *light_pt, const float *ambient, const float *min_dist, int32_t B,
+                   int32_t L, int32_t H, int32_t W, float intensity, const float *g_shadow_w,
+                   const float *g_full, const float *g_final, const float *g_rendered,
+                   float *grad_normals, float *grad_albedo, float *grad_depth, double *grad_light_pt,
+                   double *grad_ambient, float *grad_min_dist, void *stream);
+
+/*
+ * Backward of gcfr_light_prep (T8:357-363 under autograd).
+ *   grad_unit (n,3) f32 or NULL: dLoss/d unit_light_direction (T8:636 uses it in the cosine loss)
+ *   grad_light_pt (n,3) f64 or NULL: accumulated by the two kernels above
+ *   grad_light_raw (n,3) f32 =
+ */
+int gcfr_light_prep_bwd(const float *light_raw, int32_t n, int32_t clamp_z, float clamp_min,
+                        float light_distance, const float *grad_unit, const double *grad_light_pt,
+                        float *grad_light_raw, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Profiling recipe (run on the GPU box through gpurun): kernel trace + separate PMC passes.
+# usage: tools/prof.sh <tag>      -> writes gpurun_out/prof_<tag>/...
+set -u
+TAG=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
+for pass in "FETCH_SIZE" "WRITE_SIZE" \
+            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" \
+            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
+            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" \
+            "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
+  name=$(echo $pass | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$name -o pmc -- $CMD > $OUT/pmc_$name.log 2>&1
+done
+ls -R $OUT | head -50
