@@ -1,0 +1,201 @@
+"""Training-step harness around the HIP render block (BASELINE configs 3-4).
+
+Mirrors the reference's step (train_raytracing_relighting_CelebAHQ_DSSIM_8x.py:582-656): PatchGAN
+discriminator step every GD_ratio iterations, then the generator step with seven losses -- masked L2
+reconstruction x20, masked L1 depth, ambient L1 x2.5, 1-cos light direction, grey-albedo L1 x5,
+GAN BCE x0.01, DSSIM x8/2.  Everything here is stock PyTorch-ROCm (consumer of the render block's
+outputs); the only hand-written device code on the step is the render block itself.
+
+Data parallelism: faces shard over ranks (whole faces per GPU, `shard_range`), the render block needs no
+collective, and the step adds one RCCL gradient all-reduce per optimiser step through
+DistributedDataParallel -- RelightNet 1,204,796 f32 = 4.8 MB every step, PatchGAN 2,766,529 f32 = 11 MB
+every GD_ratio-th step; both fit one flat bucket (bucket_cap_mb=32), which is what a latency-bound
+all-reduce on point-to-point xGMI wants.  BatchNorm statistics stay per GPU, as in the reference (B=3).
+
+Deviations that do not change any parameter update: the D step uses rendered.detach() (the reference
+back-propagates d_loss into the generator with retain_graph=True and then zeroes those grads, T8:624,631);
+PatchGAN's parameters are frozen during the G backward (the reference accumulates and later zeroes them).
+pytorch_msssim is un-vendored: `ssim` below restates its published algorithm (PARITY UNPINNED, off the hot path).
+"""
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .relightnet import PatchGAN, RelightNet
+
+
+# ------------------------------------------------------------------------------------------------
+# sharding
+# ------------------------------------------------------------------------------------------------
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous, balanced [lo, hi) of `n_items` faces for `rank` (first n%world ranks get one more)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank %d outside world %d" % (rank, world))
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# SSIM (restatement of pytorch_msssim.ssim as called at T8:643)
+# ------------------------------------------------------------------------------------------------
+def _gauss_window(size: int, sigma: float, device, dtype):
+    c = torch.arange(size, dtype=dtype, device=device) - size // 2
+    g = torch.exp(-(c ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def ssim(X: torch.Tensor, Y: torch.Tensor, data_range: float = 1.0, size_average: bool = True,
+         nonnegative_ssim: bool = True, win_size: int = 11, win_sigma: float = 1.5) -> torch.Tensor:
+    """Gaussian-window SSIM, separable 'valid' filtering, per-channel mean, K = (0.01, 0.03)."""
+    C = X.shape[1]
+    g = _gauss_window(win_size, win_sigma, X.device, X.dtype)
+    wh = g.view(1, 1, -1, 1).repeat(C, 1, 1, 1)
+    ww = g.view(1, 1, 1, -1).repeat(C, 1, 1, 1)
+
+    def blur(t):
+        return F.conv2d(F.conv2d(t, wh, groups=C), ww, groups=C)
+
+    C1, C2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    mu1, mu2 = blur(X), blur(Y)
+    s1 = blur(X * X) - mu1 * mu1
+    s2 = blur(Y * Y) - mu2 * mu2
+    s12 = blur(X * Y) - mu1 * mu2
+    cs = (2 * s12 + C2) / (s1 + s2 + C2)
+    ssim_map = ((2 * mu1 * mu2 + C1) / (mu1 * mu1 + mu2 * mu2 + C1)) * cs
+    per_channel = ssim_map.flatten(2).mean(-1)
+    if nonnegative_ssim:
+        per_channel = torch.relu(per_channel)
+    val = per_channel.mean(1)
+    return val.mean() if size_average else val
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic data (no dataset exists in the repository: SURVEY.md 8d)
+# ------------------------------------------------------------------------------------------------
+def synthetic_batch(B: int, seed0: int, H: int = 256, W: int = 256, device="cpu") -> Dict[str, torch.Tensor]:
+    """Deterministic stand-in for load_data() (T8:527-558): images, [ambient, light] targets, depth,
+    masks (skin, fill-nose-and-mouth), grey albedo; face i uses numpy default_rng(seed0 + i)."""
+    r, c = np.mgrid[0:H, 0:W]
+    x, y = c - W / 2.0, r - H / 2.0
+    sx, sy = W / 256.0, H / 256.0
+    imgs, lights, depths, masks, masks_fill, albedos = [], [], [], [], [], []
+    for i in range(B):
+        rng = np.random.default_rng(seed0 + i)
+        ax, ay = (85 + 10 * rng.random()) * sx, (105 + 10 * rng.random()) * sy
+        d = 80 * sx * np.sqrt(np.maximum(1 - (x / ax) ** 2 - (y / ay) ** 2, 0)) \
+            + (30 + 10 * rng.random()) * sx * np.exp(-((x / sx) ** 2 / 288 + ((y / sy) - 12) ** 2 / 648))
+        m = (((x / (ax - 8 * sx)) ** 2 + (y / (ay - 8 * sy)) ** 2) < 1).astype(np.float32)
+        l = rng.standard_normal(3)
+        l[2] = abs(l[2]) + 0.3
+        l /= np.linalg.norm(l)
+        base = 0.35 + 0.4 * rng.random()
+        alb = np.clip(base + 0.08 * np.sin(c / 11.0 + i) * np.cos(r / 13.0), 0.05, 0.95)
+        shade = 0.5 + 0.5 * np.clip(d / (80 * sx), 0, 1)
+        img = np.clip(alb[..., None] * shade[..., None] * (0.8 + 0.2 * rng.random(3)), 0, 1)
+        imgs.append(img.astype(np.float32))
+        lights.append(np.concatenate([[0.4 + 0.2 * rng.random()], l]).astype(np.float32))
+        depths.append(d.astype(np.float32)[..., None])
+        masks.append(m[..., None])
+        masks_fill.append(m[..., None])
+        albedos.append(alb.astype(np.float32)[..., None])
+    t = lambda a: torch.from_numpy(np.stack(a)).to(device)
+    return dict(images=t(imgs), lightings=t(lights), depths=t(depths), masks=t(masks),
+                masks_fill=t(masks_fill), albedo=t(albedos))
+
+
+# ------------------------------------------------------------------------------------------------
+# losses and the step
+# ------------------------------------------------------------------------------------------------
+def generator_losses(out, batch, logits_fake_for_g) -> Dict[str, torch.Tensor]:
+    """The seven generator-side terms of T8:633-645.  `out` is RelightNet.forward's 8-tuple."""
+    albedo, depth, _w, _amb_l, _full, rendered, unit_light, ambient_values = out
+    B = rendered.shape[0]
+    img = batch["images"].permute(0, 3, 1, 2)
+    m3 = batch["masks_fill"].permute(0, 3, 1, 2).repeat(1, 3, 1, 1)
+    L = {}
+    L["recon"] = 20.0 * F.mse_loss(rendered * m3, img * m3, reduction="sum") / m3.sum()                     # T8:633
+    L["depth"] = F.l1_loss(depth.permute(0, 2, 3, 1) * batch["masks"], batch["depths"] * batch["masks"],
+                           reduction="sum") / batch["masks"].sum()                                         # T8:634
+    L["ambient"] = 2.5 * F.l1_loss(ambient_values, batch["lightings"][:, 0].reshape(B, 1, 1))               # T8:635
+    L["lighting"] = torch.sum(1 - torch.sum(unit_light * batch["lightings"][:, 1:4].reshape(B, 3, 1, 1), dim=1)) / B
+    grey = albedo.mean(1).reshape(B, albedo.shape[2], albedo.shape[3], 1)
+    L["albedo"] = 5.0 * F.l1_loss(grey * batch["masks_fill"], batch["albedo"] * batch["masks_fill"],
+                                  reduction="sum") / batch["masks_fill"].sum()                              # T8:639
+    L["generator"] = 0.01 * F.binary_cross_entropy_with_logits(logits_fake_for_g, torch.ones_like(logits_fake_for_g))
+    composite = rendered * m3 + (1.0 - m3) * img
+    L["DSSIM"] = 8.0 * (1 - ssim(composite, img, data_range=1.0, size_average=True, nonnegative_ssim=True)) / 2.0
+    L["total"] = sum(L.values())
+    return L
+
+
+@dataclass
+class TrainConfig:
+    lr: float = 1e-4            # T8:44
+    gd_ratio: int = 5           # T8:49
+    focal: float = 1570.0       # T8:572
+    H: int = 256
+    W: int = 256
+    shortcut: str = "3x3"
+    bucket_cap_mb: int = 32     # one flat bucket per model (see module docstring)
+
+
+class Trainer:
+    """One process per GPU.  `step(batch, epoch, j)` = T8:617-656 for one batch of any size."""
+
+    def __init__(self, cfg: TrainConfig = TrainConfig(), device="cuda", distributed: bool = False,
+                 model: Optional[nn.Module] = None, patchgan: Optional[nn.Module] = None):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.model = (model or RelightNet(cfg.shortcut)).float().to(self.device)
+        self.patchgan = (patchgan or PatchGAN()).float().to(self.device)
+        self.net, self.disc = self.model, self.patchgan
+        if distributed:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            ids = [self.device.index] if self.device.type == "cuda" else None
+            self.net = DDP(self.model, device_ids=ids, bucket_cap_mb=cfg.bucket_cap_mb, gradient_as_bucket_view=True)
+            self.disc = DDP(self.patchgan, device_ids=ids, bucket_cap_mb=cfg.bucket_cap_mb, gradient_as_bucket_view=True)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=cfg.lr)                  # T8:589
+        self.opt_d = torch.optim.Adam(self.patchgan.parameters(), lr=cfg.lr)             # T8:590
+        K = torch.zeros(1, 3, 3, dtype=torch.float64)
+        K[:, 0, 0] = K[:, 1, 1] = cfg.focal
+        K[:, 2, 2] = 1.0
+        K[:, 0, 2], K[:, 1, 2] = cfg.W / 2.0, cfg.H / 2.0
+        self.K = K.to(self.device)
+
+    def step(self, batch: Dict[str, torch.Tensor], epoch: int, j: int, log: bool = True) -> Dict[str, float]:
+        """log=False skips the per-iteration .item() syncs the reference pays for its 11 prints (T8:657-669)."""
+        img = batch["images"].permute(0, 3, 1, 2)
+        m3 = batch["masks_fill"].permute(0, 3, 1, 2).repeat(1, 3, 1, 1)
+        out = self.net(batch["images"], epoch, self.K, batch["masks_fill"])              # T8:618
+        rendered = out[5]
+        composite = rendered * m3 + (1.0 - m3) * img
+        logs = {}
+        # ---- discriminator (T8:617-629) ----
+        if j % self.cfg.gd_ratio == 0:
+            self.opt_d.zero_grad(set_to_none=True)
+            lf = self.disc(composite.detach())
+            lr_ = self.disc(img)
+            d_fake = 0.01 * F.binary_cross_entropy_with_logits(lf, torch.zeros_like(lf))
+            d_real = 0.01 * F.binary_cross_entropy_with_logits(lr_, torch.ones_like(lr_))
+            (d_fake + d_real).backward()
+            self.opt_d.step()
+            if log:
+                logs.update(discriminator=float(d_fake + d_real))
+        # ---- generator (T8:631-656) ----
+        self.opt.zero_grad(set_to_none=True)
+        for p in self.patchgan.parameters():
+            p.requires_grad_(False)
+        try:
+            L = generator_losses(out, batch, self.patchgan(composite))
+            L["total"].backward()
+        finally:
+            for p in self.patchgan.parameters():
+                p.requires_grad_(True)
+        self.opt.step()
+        if log:
+            logs.update({k: float(v.detach()) for k, v in L.items()})
+        return logs

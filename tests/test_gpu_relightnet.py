@@ -110,3 +110,22 @@ def test_training_step_backward_reaches_every_parameter():
     missing = [n for n, p in net.named_parameters() if p.grad is None]
     assert not missing, missing
     assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_trainer_steps_run_and_update_parameters():
+    """Full training step (T8:617-656) around the HIP block on one GPU, batch 4, two iterations."""
+    from geomconsistentfr_amd.train import TrainConfig, Trainer, synthetic_batch
+    torch.manual_seed(0)
+    tr = Trainer(TrainConfig(), device=DEV)
+    before = torch.cat([p.detach().flatten().clone() for p in tr.model.parameters()])
+    d_before = torch.cat([p.detach().flatten().clone() for p in tr.patchgan.parameters()])
+    batch = synthetic_batch(4, 0, device=DEV)
+    logs0 = tr.step(batch, epoch=200, j=0)
+    logs1 = tr.step(batch, epoch=200, j=1)
+    assert "discriminator" in logs0 and "discriminator" not in logs1          # D step every GD_ratio (T8:624)
+    for k in ("recon", "depth", "ambient", "lighting", "albedo", "generator", "DSSIM", "total"):
+        assert np.isfinite(logs0[k]) and np.isfinite(logs1[k]), k
+    after = torch.cat([p.detach().flatten() for p in tr.model.parameters()])
+    d_after = torch.cat([p.detach().flatten() for p in tr.patchgan.parameters()])
+    assert not torch.equal(before, after) and not torch.equal(d_before, d_after)
+    assert torch.isfinite(after).all()

@@ -1,0 +1,134 @@
+"""CPU: host-side logic of the training harness -- sharding, SSIM restatement, and the N>1 path
+(world_size-2 gloo DistributedDataParallel gradient all-reduce on the network's CPU-runnable part)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_faces_exactly():
+    from geomconsistentfr_amd.train import shard_range
+    for n in (0, 1, 7, 8, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)
+
+
+def _ssim_naive(X, Y, L=1.0):
+    """Independent numpy SSIM: explicit 11x11 Gaussian window, valid region, K=(0.01,0.03)."""
+    g = np.exp(-((np.arange(11) - 5) ** 2) / (2 * 1.5 ** 2))
+    g /= g.sum()
+    w2 = np.outer(g, g)
+    C1, C2 = (0.01 * L) ** 2, (0.03 * L) ** 2
+    B, C, H, W = X.shape
+    out = np.zeros((B, C))
+    for b in range(B):
+        for c in range(C):
+            vals = []
+            for i in range(H - 10):
+                for j in range(W - 10):
+                    x, y = X[b, c, i:i + 11, j:j + 11], Y[b, c, i:i + 11, j:j + 11]
+                    mx, my = (w2 * x).sum(), (w2 * y).sum()
+                    sx, sy = (w2 * x * x).sum() - mx * mx, (w2 * y * y).sum() - my * my
+                    sxy = (w2 * x * y).sum() - mx * my
+                    vals.append(((2 * mx * my + C1) / (mx * mx + my * my + C1)) * ((2 * sxy + C2) / (sx + sy + C2)))
+            out[b, c] = max(np.mean(vals), 0.0)
+    return out.mean()
+
+
+def test_ssim_restatement():
+    from geomconsistentfr_amd.train import ssim
+    rng = np.random.default_rng(0)
+    X = rng.random((2, 3, 24, 20))
+    Y = np.clip(X + 0.1 * rng.standard_normal(X.shape), 0, 1)
+    Xt, Yt = torch.from_numpy(X), torch.from_numpy(Y)
+    assert abs(float(ssim(Xt, Xt)) - 1.0) < 1e-12
+    assert abs(float(ssim(Xt, Yt)) - float(ssim(Yt, Xt))) < 1e-12
+    assert abs(float(ssim(Xt, Yt)) - _ssim_naive(X, Y)) < 1e-10
+
+
+def test_synthetic_batch_is_deterministic_and_rank_disjoint():
+    from geomconsistentfr_amd.train import synthetic_batch
+    a = synthetic_batch(2, 5, 64, 64)
+    b = synthetic_batch(2, 5, 64, 64)
+    c = synthetic_batch(2, 1_000_005, 64, 64)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert not torch.equal(a["images"], c["images"])
+    assert a["images"].shape == (2, 64, 64, 3) and a["lightings"].shape == (2, 4)
+    assert a["masks"].shape == (2, 64, 64, 1) and a["depths"].shape == (2, 64, 64, 1)
+    np.testing.assert_allclose(a["lightings"][:, 1:].norm(dim=1).numpy(), 1.0, atol=1e-6)
+
+
+class _FeatureLoss(torch.nn.Module):
+    """RelightNet up to the T8:352 seam (CPU-runnable) with a scalar loss on its three heads."""
+
+    def __init__(self):
+        super().__init__()
+        from geomconsistentfr_amd.relightnet import RelightNet
+        torch.manual_seed(1234)
+        self.net = RelightNet()
+
+    def forward(self, img):
+        albedo, depth, SL = self.net.features(img, 200)
+        return albedo.mean() + 1e-3 * depth.abs().mean() + SL.pow(2).mean()
+
+
+def _ddp_worker(rank, world, port, q):
+    try:
+        _ddp_worker_body(rank, world, port, q)
+    except Exception as e:  # surface the failure instead of letting the parent wait for its timeout
+        q.put((rank, "error: %r" % (e,), 0.0, 0))
+        raise
+
+
+def _ddp_worker_body(rank, world, port, q):
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from geomconsistentfr_amd.train import shard_range, synthetic_batch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    m = _FeatureLoss()
+    ddp = DDP(m, bucket_cap_mb=32)
+    lo, hi = shard_range(4, rank, world)                     # 4 faces over 2 ranks, whole faces per rank
+    full = synthetic_batch(4, 0, 256, 256)["images"]         # the lighting head pools 16x16 at 1/16 scale (T8:85)
+    ddp(full[lo:hi]).backward()
+    g = torch.cat([p.grad.flatten() for p in m.parameters()])
+    # single-process reference: mean of the per-shard gradients (BatchNorm statistics stay per shard)
+    ref = []
+    for r in range(world):
+        m2 = _FeatureLoss()
+        a, b = shard_range(4, r, world)
+        m2(full[a:b]).backward()
+        ref.append(torch.cat([p.grad.flatten() for p in m2.parameters()]))
+    ref = torch.stack(ref).mean(0)
+    q.put((rank, float((g - ref).abs().max()), float(ref.abs().max()), g.numel()))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_gradient_allreduce_matches_mean_of_shards():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    assert all(not isinstance(r[1], str) for r in res), res
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, scale, n in res:
+        assert n == 1_204_796
+        assert err <= 1e-5 * max(scale, 1e-3), (rank, err, scale)
