@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--faces", type=int, default=FACES_PER_GPU, help="faces per GPU per step (configs[1]: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--direct", action="store_true", help="A/B: direct-gather kernel (no workspace prepass)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,7 +144,8 @@ def main():
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()                                   # same stream the kernel is launched on
-        md, _ = R.shadow_min_distance(d_depth, d_mask, pt.reshape(B, 1, 3), prm, want_argmin=False)
+        md, _ = R.shadow_min_distance(d_depth, d_mask, pt.reshape(B, 1, 3), prm, want_argmin=False,
+                                       use_workspace=not a.direct)
         if timed:
             e1.record()
             ev_pairs.append((e0, e1))

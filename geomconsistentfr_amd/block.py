@@ -96,9 +96,10 @@ def mask_to_u8(mask: torch.Tensor) -> torch.Tensor:
 
 
 def shadow_min_distance(depth: torch.Tensor, mask: torch.Tensor, light_pt: torch.Tensor,
-                        params: RenderParams = RenderParams(), want_argmin: bool = True):
+                        params: RenderParams = RenderParams(), want_argmin: bool = True,
+                        use_workspace: bool = True):
     """depth (B,H,W) f32, mask (B|1,H,W), light_pt (B,L,3) -> min_dist (B,L,H,W) f32, argmin i32|None.
-    Replaces T8:371-515."""
+    Replaces T8:371-515.  use_workspace=False selects the direct-gather kernel (same bits, slower)."""
     _require_device(depth, mask, light_pt)
     L_ = _lib.load()
     depth = _f32c(depth)
@@ -110,10 +111,13 @@ def shadow_min_distance(depth: torch.Tensor, mask: torch.Tensor, light_pt: torch
     md = torch.empty((B, L, H, W), dtype=torch.float32, device=depth.device)
     am = torch.empty((B, L, H, W), dtype=torch.int32, device=depth.device) if want_argmin else None
     box = (ctypes_float4(params.bonus_box) if params.bonus_box is not None else None)
+    ws_bytes = int(L_.gcfr_shadow_workspace_bytes(B, H, W)) if use_workspace else 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=depth.device) if ws_bytes else None
     with torch.cuda.device(depth.device):
         _lib.check(L_.gcfr_shadow_fwd(depth.data_ptr(), mask_u8.data_ptr(), mask_u8.shape[0], light_pt.data_ptr(),
                                       B, L, H, W, params.n_samples, tt.data_ptr(), float(params.inside_bonus),
                                       box, md.data_ptr(), am.data_ptr() if am is not None else None,
+                                      ws.data_ptr() if ws is not None else None, ws_bytes,
                                       _stream_ptr(depth.device)), "gcfr_shadow_fwd")
     return md, am
 

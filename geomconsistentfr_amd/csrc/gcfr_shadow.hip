@@ -184,6 +184,201 @@ __global__ __launch_bounds__(256) void shadow_fwd_kernel(ShadowArgs a)
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// shadow march, "quad texel" variant (used when the caller provides a workspace)
+//
+// A prepass rewrites each depth map as a (H+1) x (W+1) grid of 2x2 neighbourhoods
+//     Q[r][c] = { z[r][c], z[r][c+1], z[r+1][c], z[r+1][c+1] },   r in [-1, H-1], c in [-1, W-1],
+// with row/column -1 holding the reference's wrap-around neighbours (index -1 == last, T8:488-491).
+// The march then needs ONE 16-byte gather and one address per ray-step instead of four 4-byte
+// gathers, four addresses and the wrap arithmetic; values are the same bits, so results are
+// bit-identical to the direct kernel above (tests/test_gpu_parity.py asserts it).
+// When floor(u) == ceil(u) (u integral) the reference reads z[f] twice with weights 0 and 0; here the
+// second operand is z[f+1], still multiplied by 0 -- identical for finite depth.
+//
+// Other exact instruction trims in this variant:
+//   * rint(s) via the 2^52+2^51 magic add (round-half-even of the f64 adder == torch.round), the
+//     integer falls out of the low dword with no v_rndne / v_cvt; when W/2 and H/2 are even the
+//     +W/2 and H/2- offsets ride in the magic constant (parity-safe), otherwise they are int adds;
+//   * argmin tracking compiled out when the caller does not ask for it (inference).
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict__ depth,
+                                                         float4 *__restrict__ quad, int H, int W)
+{
+    const int Wp = W + 1, Hp = H + 1;
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Hp * Wp)
+        return;
+    const int rp = i / Wp, cp = i - rp * Wp;
+    const int r = rp - 1, c = cp - 1;
+    const int r0 = r < 0 ? H - 1 : r, c0 = c < 0 ? W - 1 : c;
+    const int r1 = (r + 1 >= H) ? 0 : r + 1, c1 = (c + 1 >= W) ? 0 : c + 1;
+    const float *z = depth + (size_t)b * H * W;
+    quad[(size_t)b * Hp * Wp + i] =
+        make_float4(z[(size_t)r0 * W + c0], z[(size_t)r0 * W + c1], z[(size_t)r1 * W + c0], z[(size_t)r1 * W + c1]);
+}
+
+struct ShadowQuadArgs {
+    const float *depth;     // (B,H,W)      own-pixel depth
+    const float4 *quad;     // (B,H+1,W+1)  prepass output
+    const uint8_t *mask;    // (MB,H,W)
+    const float *light_pt;  // (B,L,3)
+    const double *t_table;  // (N)
+    float *min_dist;        // (B,L,H,W)
+    int32_t *argmin;        // (B,L,H,W) or null
+    int32_t mask_batch, B, L, H, W, N;
+    int32_t quads_x, quads_per_image;  // 4-tile block columns / blocks per (image, light)
+    float bonus, bx_lo, bx_hi, by_lo, by_hi;
+};
+
+constexpr double kRintMagic = 6755399441055744.0;  // 2^52 + 2^51
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline int lo32(double v)
+{
+    return (int)(unsigned)(__builtin_bit_cast(unsigned long long, v) & 0xffffffffull);
+}
+
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, bool XCD_AFFINE>
+__global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
+{
+    constexpr int TILE_H = 64 / TILE_W;
+    constexpr int WAVES = 4;
+    const int H = a.H, W = a.W, N = a.N, L = a.L;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+
+    // blockIdx -> (image, light, tile quad).  Blocks are dealt round-robin to the 8 XCDs (observed:
+    // block i runs on XCD i % 8); XCD_AFFINE keeps every block of an image -- all its lights and
+    // tiles -- on one XCD so the image's depth/mask stay in that XCD's private L2.  Placement only
+    // affects speed, never results.
+    const int per_image = a.quads_per_image * L;
+    int b, rem;
+    if (XCD_AFFINE) {
+        const int B8 = a.B & ~7;
+        const int i = blockIdx.x;
+        if (i < B8 * per_image) {
+            const int xcd = i & 7, j = i >> 3;
+            b = (j / per_image) * 8 + xcd;
+            rem = j % per_image;
+        } else {
+            b = i / per_image;
+            rem = i - b * per_image;
+        }
+    } else {
+        b = blockIdx.x / per_image;
+        rem = blockIdx.x - b * per_image;
+    }
+    const int l = rem / a.quads_per_image;
+    const int q = rem - l * a.quads_per_image;
+    const int bl = b * L + l;
+    const int qy = q / a.quads_x, qx = q - qy * a.quads_x;
+
+    int r = qy * TILE_H + lane / TILE_W;
+    int c = (qx * WAVES + wave) * TILE_W + (lane % TILE_W);
+    const bool valid = (r < H) && (c < W);
+    r = valid ? r : H - 1;
+    c = valid ? c : W - 1;
+
+    const size_t P = (size_t)H * W;
+    const int Wp = W + 1;
+    const size_t Pq = (size_t)(H + 1) * Wp;
+    const __amdgpu_buffer_rsrc_t qr = make_rsrc(a.quad + (size_t)b * Pq, (int)(Pq * 16));
+    const __amdgpu_buffer_rsrc_t mr =
+        make_rsrc(a.mask + (size_t)(a.mask_batch == 1 ? 0 : b) * P, (int)P);
+
+    const float Cx = a.light_pt[3 * bl + 0], Cy = a.light_pt[3 * bl + 1], Cz = a.light_pt[3 * bl + 2];
+    const Box box = image_box(H, W);
+    const LightCase lc = classify_light(Cx, Cy, box);
+    const float halfWf = W / 2.0f, halfHf = H / 2.0f;
+    const double halfW = W / 2.0, halfH = H / 2.0;
+    const int halfWi = W / 2, halfHi = H / 2;
+
+    const float x = (float)c - halfWf, y = halfHf - (float)r;
+    const float zb = a.depth[(size_t)b * P + (size_t)r * W + c];
+    float Ex, Ey;
+    end_point(x, y, Cx, Cy, box, lc, Ex, Ey);
+    const float dxf = Ex - x, dyf = Ey - y;
+    const float BCx = Cx - x, BCy = Cy - y, BCz = Cz - zb;
+    const bool finite_ray = (dxf - dxf == 0.0f) && (dyf - dyf == 0.0f);
+    const double x64 = x, y64 = y;
+    const double dx64 = finite_ray ? (double)dxf : 0.0, dy64 = finite_ray ? (double)dyf : 0.0;
+    // magic constants (see header comment); the y one is used as (My - sy)
+    const double Mx = EVEN_HALF ? kRintMagic + halfW : kRintMagic;
+    const double My = EVEN_HALF ? kRintMagic + halfH : kRintMagic;
+    const int quad_origin = (Wp + 1) << 4;  // byte offset of texel (r=0, c=0)
+
+    float bestS = __builtin_inff();
+    int besti = -1;
+    bool any_masked = false;
+
+#pragma unroll 2
+    for (int k = 0; k < N; ++k) {
+        const double t = a.t_table[k];
+        const double sx = x64 + t * dx64;  // T8:472 / 480
+        const double sy = y64 + t * dy64;
+        // mask cell (T8:472-477, 510)
+        int col_r, row_r;
+        if (EVEN_HALF) {
+            col_r = lo32(sx + Mx);   // rint(sx) + W/2
+            row_r = lo32(My - sy);   // H/2 - rint(sy)
+        } else {
+            col_r = lo32(sx + Mx) + halfWi;
+            row_r = halfHi - lo32(sy + My);
+        }
+        const uint32_t mk = buf_load_u8(mr, __mul24(row_r, W) + col_r);
+        // unrounded position (T8:480-487)
+        const double ux = (sx + halfW) - 0.0001;
+        const double uy = (halfH - sy) - 0.0001;
+        const double fxd = __builtin_floor(ux), gxd = __builtin_ceil(ux);
+        const double fyd = __builtin_floor(uy), gyd = __builtin_ceil(uy);
+        const int fx = (int)fxd, fy = (int)fyd;  // may be -1: the quad grid has that row / column
+        const int texel = __mul24(fy, Wp) + fx;
+        // NB: bit-cast the whole vector.  Indexing the builtin's result element-wise makes this
+        // hipcc narrow the load to ONE dword (all four corners alias) -- caught in the ISA.
+        const f32x4 qv = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(qr, (texel << 4) + quad_origin, 0, 0));
+        const double wx0 = gxd - ux, wx1 = ux - fxd;
+        const double wy0 = gyd - uy, wy1 = uy - fyd;
+        const double zUL = qv.x, zUR = qv.y, zLL = qv.z, zLR = qv.w;
+        const double up = zUL * wx0 + zUR * wx1;
+        const double low = zLL * wx0 + zLR * wx1;
+        const double zA = up * wy0 + low * wy1;
+        const float Ax = (float)(ux - halfW), Ay = (float)(halfH - uy), Az = (float)zA;
+        const float BAx = Ax - x, BAy = Ay - y, BAz = Az - zb;
+        const float Xx = __builtin_fmaf(BAy, BCz, -(BAz * BCy));
+        const float Xy = __builtin_fmaf(BAz, BCx, -(BAx * BCz));
+        const float Xz = __builtin_fmaf(BAx, BCy, -(BAy * BCx));
+        const float S = ((Xx * Xx + Xy * Xy) + Xz * Xz) + kEps4;
+        const bool masked = (mk == 0);
+        any_masked |= masked;
+        const bool take = !masked && (S < bestS);
+        bestS = take ? S : bestS;
+        if (WANT_ARGMIN)
+            besti = take ? k : besti;
+    }
+
+    const float den = __builtin_sqrtf(((BCx * BCx + BCy * BCy) + BCz * BCz) + kEps4);
+    float d = __builtin_sqrtf(bestS) / den;
+    if (any_masked && !(d < kMaskedDistance)) {
+        d = kMaskedDistance;
+        besti = -1;
+    }
+    if (!finite_ray)
+        d = __builtin_nanf("");
+    const bool inside = (Cx >= a.bx_lo) && (Cx <= a.bx_hi) && (Cy >= a.by_lo) && (Cy <= a.by_hi);
+    if (inside)
+        d = d + a.bonus;
+    if (valid) {
+        const size_t o = (size_t)bl * P + (size_t)r * W + c;
+        a.min_dist[o] = d;
+        if (WANT_ARGMIN)
+            a.argmin[o] = besti;
+    }
+}
+
 }  // namespace gcfr
 
 // ----------------------------------------------------------------------------------------------
@@ -220,11 +415,38 @@ extern "C" int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_
     return launch_status();
 }
 
+extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
+{
+    if (B <= 0 || H <= 0 || W <= 0)
+        return 0;
+    return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4);
+}
+
+template <int TILE_W>
+static void launch_quad(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
+                        hipStream_t st)
+{
+#define GCFR_LAUNCH(E, A) \
+    hipLaunchKernelGGL((shadow_fwd_quad_kernel<TILE_W, E, A, true>), dim3(blocks), dim3(256), 0, st, a)
+    if (even_half) {
+        if (want_argmin)
+            GCFR_LAUNCH(true, true);
+        else
+            GCFR_LAUNCH(true, false);
+    } else {
+        if (want_argmin)
+            GCFR_LAUNCH(false, true);
+        else
+            GCFR_LAUNCH(false, false);
+    }
+#undef GCFR_LAUNCH
+}
+
 extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32_t mask_batch,
                                const float *light_pt, int32_t B, int32_t L, int32_t H, int32_t W,
                                int32_t N, const double *t_table, float bonus,
                                const float *bonus_box, float *min_dist, int32_t *argmin,
-                               void *stream)
+                               void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!depth || !mask_u8 || !light_pt || !t_table || !min_dist)
         return GCFR_ERR_INVALID_ARGUMENT;
@@ -233,8 +455,53 @@ extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32
         return GCFR_ERR_INVALID_ARGUMENT;
     if (bonus != 0.0f && !bonus_box)
         return GCFR_ERR_INVALID_ARGUMENT;
+    if (workspace && workspace_bytes < gcfr_shadow_workspace_bytes(B, H, W))
+        return GCFR_ERR_INVALID_ARGUMENT;
 
     constexpr int TILE_W = 16, TILE_H = 64 / TILE_W, WAVES = 4;
+    const int tiles_x = (W + TILE_W - 1) / TILE_W;
+    const int quads_x = (tiles_x + WAVES - 1) / WAVES;
+    const int quads_per_image = quads_x * ((H + TILE_H - 1) / TILE_H);
+    const long long blocks = (long long)B * L * quads_per_image;
+    if (blocks > 0x7fffffffLL)
+        return GCFR_ERR_INVALID_ARGUMENT;
+    float bx[4] = {0.0f, -1.0f, 0.0f, -1.0f};
+    if (bonus_box)
+        for (int i = 0; i < 4; ++i)
+            bx[i] = bonus_box[i];
+    hipStream_t st = (hipStream_t)stream;
+
+    if (workspace) {
+        // prepass: 2x2 neighbourhood grid (see shadow_fwd_quad_kernel), then the march
+        const int texels = (H + 1) * (W + 1);
+        hipLaunchKernelGGL(build_quad_kernel, dim3((texels + 255) / 256, B), dim3(256), 0, st, depth,
+                           (float4 *)workspace, H, W);
+        ShadowQuadArgs a;
+        a.depth = depth;
+        a.quad = (const float4 *)workspace;
+        a.mask = mask_u8;
+        a.light_pt = light_pt;
+        a.t_table = t_table;
+        a.min_dist = min_dist;
+        a.argmin = argmin;
+        a.mask_batch = mask_batch;
+        a.B = B;
+        a.L = L;
+        a.H = H;
+        a.W = W;
+        a.N = N;
+        a.quads_x = quads_x;
+        a.quads_per_image = quads_per_image;
+        a.bonus = bonus;
+        a.bx_lo = bx[0];
+        a.bx_hi = bx[1];
+        a.by_lo = bx[2];
+        a.by_hi = bx[3];
+        const bool even_half = (((W / 2) & 1) == 0) && (((H / 2) & 1) == 0);
+        launch_quad<TILE_W>(a, even_half, argmin != nullptr, (unsigned)blocks, st);
+        return launch_status();
+    }
+
     ShadowArgs a;
     a.depth = depth;
     a.mask = mask_u8;
@@ -247,24 +514,13 @@ extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32
     a.H = H;
     a.W = W;
     a.N = N;
-    a.tiles_x = (W + TILE_W - 1) / TILE_W;
-    const int quads_x = (a.tiles_x + WAVES - 1) / WAVES;
-    const int quads_per_image = quads_x * ((H + TILE_H - 1) / TILE_H);
+    a.tiles_x = tiles_x;
     a.tiles_per_image = quads_per_image;
     a.bonus = bonus;
-    if (bonus_box) {
-        a.bx_lo = bonus_box[0];
-        a.bx_hi = bonus_box[1];
-        a.by_lo = bonus_box[2];
-        a.by_hi = bonus_box[3];
-    } else {
-        a.bx_lo = a.by_lo = 0.0f;
-        a.bx_hi = a.by_hi = -1.0f;
-    }
-    const long long blocks = (long long)B * L * quads_per_image;
-    if (blocks > 0x7fffffffLL)
-        return GCFR_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(shadow_fwd_kernel<TILE_W>, dim3((unsigned)blocks), dim3(256), 0,
-                       (hipStream_t)stream, a);
+    a.bx_lo = bx[0];
+    a.bx_hi = bx[1];
+    a.by_lo = bx[2];
+    a.by_hi = bx[3];
+    hipLaunchKernelGGL(shadow_fwd_kernel<TILE_W>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     return launch_status();
 }

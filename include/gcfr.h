@@ -21,6 +21,7 @@
 #ifndef GCFR_H
 #define GCFR_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -68,12 +69,17 @@ int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_z, float cl
  *               training form: bonus = 0 (bonus_box may be NULL).  bonus_box is a HOST pointer.
  *   min_dist    (B,L,H,W) f32 out   minimum_distance (T8:515)
  *   argmin      (B,L,H,W) i32 out   index of the minimising sample (saved for backward); may be NULL
+ *   workspace   device scratch of >= gcfr_shadow_workspace_bytes(B,H,W) bytes, or NULL.
+ *               With a workspace the depth maps are first repacked into 2x2-neighbourhood texels
+ *               (one 16-byte gather per ray-step instead of four 4-byte gathers); results are
+ *               bit-identical to the NULL-workspace path, only faster.  Contents are scratch.
  * Supported: 2 <= H,W <= 4096, even; 1 <= N <= 4096.
  */
+size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W);
 int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32_t mask_batch,
                     const float *light_pt, int32_t B, int32_t L, int32_t H, int32_t W, int32_t N,
                     const double *t_table, float bonus, const float *bonus_box, float *min_dist,
-                    int32_t *argmin, void *stream);
+                    int32_t *argmin, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Soft-shadow transfer + Lambert shading + composite.  Replaces T8:364-369 and T8:517-522.

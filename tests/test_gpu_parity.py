@@ -173,3 +173,26 @@ def test_no_cpu_path():
     from geomconsistentfr_amd._lib import GcfrError
     with pytest.raises(GcfrError):
         shadow_min_distance(torch.zeros(1, 8, 8), torch.ones(1, 8, 8), torch.ones(1, 1, 3), RenderParams())
+
+
+@pytest.mark.parametrize("Hs,Ws,N", [(64, 64, 48), (130, 70, 160), (48, 96, 37), (256, 256, 160), (258, 254, 33),
+                                     (512, 512, 320)])
+def test_workspace_kernel_is_bit_identical_to_direct_kernel(Hs, Ws, N):
+    """The quad-texel / magic-rint / XCD-affine kernel must reproduce the direct-gather kernel bit for bit
+    (values AND argmin), including odd half sizes (EVEN_HALF=false path) and B not a multiple of 8."""
+    from geomconsistentfr_amd import RenderParams, shadow_min_distance, light_prep
+    rng = np.random.default_rng(Hs + 7 * Ws)
+    B, L = 11, 2
+    depth = (40 * rng.random((B, Hs, Ws))).astype(np.float32)
+    mask = (rng.random((B, Hs, Ws)) > 0.3).astype(np.uint8)
+    lights = rng.standard_normal((B, L, 3)).astype(np.float32)
+    lights[0, 0] = (0.001, 0.002, 1.0)          # light projects inside the image
+    lights[1, 1] = (0.0, 0.9, 0.1)              # purely vertical: column 0 exercises the -1 wrap
+    prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
+    _, pt = light_prep(to_dev(lights), prm)
+    a_md, a_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True)
+    b_md, b_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=False)
+    assert torch.equal(a_md, b_md)
+    assert torch.equal(a_am, b_am)
+    c_md, c_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, want_argmin=False, use_workspace=True)
+    assert c_am is None and torch.equal(c_md, a_md)
