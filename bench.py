@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--faces", type=int, default=FACES_PER_GPU, help="faces per GPU per step (configs[1]: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--direct", action="store_true", help="A/B: direct-gather kernel (no workspace prepass)")
+    ap.add_argument("--tune", type=str, default="", help="A/B: comma list key=value for gcfr_tune, e.g. 0=32,2=1")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,6 +128,11 @@ def main():
     from geomconsistentfr_amd import RenderParams
     from geomconsistentfr_amd import block as R
 
+    if a.tune:
+        from geomconsistentfr_amd import _lib
+        for kv in a.tune.split(","):
+            k, v = kv.split("=")
+            _lib.check(_lib.load().gcfr_tune(int(k), int(v)), "gcfr_tune")
     prm = RenderParams()
     B = a.faces
     depth, mask, albedo, normals, light, amb = synth_faces(B, seed0=rank * 1_000_000)

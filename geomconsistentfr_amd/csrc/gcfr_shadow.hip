@@ -216,8 +216,10 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
     const int r0 = r < 0 ? H - 1 : r, c0 = c < 0 ? W - 1 : c;
     const int r1 = (r + 1 >= H) ? 0 : r + 1, c1 = (c + 1 >= W) ? 0 : c + 1;
     const float *z = depth + (size_t)b * H * W;
-    quad[(size_t)b * Hp * Wp + i] =
-        make_float4(z[(size_t)r0 * W + c0], z[(size_t)r0 * W + c1], z[(size_t)r1 * W + c0], z[(size_t)r1 * W + c1]);
+    const float zUL = z[(size_t)r0 * W + c0], zUR = z[(size_t)r0 * W + c1];
+    const float zLL = z[(size_t)r1 * W + c0], zLR = z[(size_t)r1 * W + c1];
+    const size_t o = (size_t)b * Hp * Wp + i;
+    quad[o] = make_float4(zUL, zUR, zLL, zLR);
 }
 
 struct ShadowQuadArgs {
@@ -314,21 +316,44 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
     int besti = -1;
     bool any_masked = false;
 
-#pragma unroll 2
-    for (int k = 0; k < N; ++k) {
-        const double t = a.t_table[k];
-        const double sx = x64 + t * dx64;  // T8:472 / 480
-        const double sy = y64 + t * dy64;
-        // mask cell (T8:472-477, 510)
+    // Two-stage software pipeline.  Stage A (sample k+1): position, rounded cell, issue the mask byte
+    // gather.  Stage B (sample k): if NO lane of the wave has an unmasked sample, the whole bilinear /
+    // distance body is skipped -- masked samples only contribute "1e6" (T8:512), which `any_masked`
+    // records.  The skip is wave-uniform (ballot -> scalar branch) and exact; on face-shaped masks more
+    // than half of all wave-steps take it (rays that have left the face, background tiles).
+    auto sample_pos = [&](int k, double &sx, double &sy) {
+        const double t = a.t_table[k];  // wave-uniform -> s_load
+        sx = x64 + t * dx64;            // T8:472 / 480 (f64, mul and add rounded separately)
+        sy = y64 + t * dy64;
+    };
+    auto mask_offset = [&](double sx, double sy) -> int {  // T8:472-477, 510
         int col_r, row_r;
         if (EVEN_HALF) {
-            col_r = lo32(sx + Mx);   // rint(sx) + W/2
-            row_r = lo32(My - sy);   // H/2 - rint(sy)
+            col_r = lo32(sx + Mx);  // rint(sx) + W/2
+            row_r = lo32(My - sy);  // H/2 - rint(sy)
         } else {
             col_r = lo32(sx + Mx) + halfWi;
             row_r = halfHi - lo32(sy + My);
         }
-        const uint32_t mk = buf_load_u8(mr, __mul24(row_r, W) + col_r);
+        return __mul24(row_r, W) + col_r;
+    };
+
+    double nsx, nsy;
+    sample_pos(0, nsx, nsy);
+    uint32_t mk_next = buf_load_u8(mr, mask_offset(nsx, nsy));
+
+    for (int k = 0; k < N; ++k) {
+        const double sx = nsx, sy = nsy;
+        const uint32_t mk = mk_next;
+        {  // stage A for the next sample (the last iteration harmlessly re-reads sample N-1)
+            const int kn = (k + 1 < N) ? k + 1 : N - 1;
+            sample_pos(kn, nsx, nsy);
+            mk_next = buf_load_u8(mr, mask_offset(nsx, nsy));
+        }
+        const bool masked = (mk == 0);
+        any_masked |= masked;
+        if (__builtin_amdgcn_ballot_w64(!masked) == 0ull)
+            continue;
         // unrounded position (T8:480-487)
         const double ux = (sx + halfW) - 0.0001;
         const double uy = (halfH - sy) - 0.0001;
@@ -352,8 +377,6 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
         const float Xy = __builtin_fmaf(BAz, BCx, -(BAx * BCz));
         const float Xz = __builtin_fmaf(BAx, BCy, -(BAy * BCx));
         const float S = ((Xx * Xx + Xy * Xy) + Xz * Xz) + kEps4;
-        const bool masked = (mk == 0);
-        any_masked |= masked;
         const bool take = !masked && (S < bestS);
         bestS = take ? S : bestS;
         if (WANT_ARGMIN)
@@ -415,6 +438,30 @@ extern "C" int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_
     return launch_status();
 }
 
+// Process-wide tuning knobs (experiments / A-B runs only; defaults are the shipped configuration).
+// Measured on MI355X, B=8 x 256^2 x 160 (gpurun_out/ab_r01.txt -> DESIGN.md section 4.1):
+//   tile 2x32 > 4x16 > 8x8 > 1x64;  XCD-affine mapping is 12 % SLOWER at B=8 (one image per XCD: the
+//   slowest image sets the kernel time; L1 already serves 99.7 % of the gathers, so L2 affinity buys
+//   nothing);  f64 texels (32 B gathers) are 25 % slower (vector-memory bound).
+static int g_tile_w = 32;     // pixels per tile row: 8, 16, 32 or 64 (tile = 64/tile_w rows)
+static int g_xcd_affine = 0;  // keep all blocks of an image on one XCD
+
+extern "C" int gcfr_tune(int32_t key, int32_t value)
+{
+    switch (key) {
+    case 0:
+        if (value != 8 && value != 16 && value != 32 && value != 64)
+            return GCFR_ERR_INVALID_ARGUMENT;
+        g_tile_w = value;
+        return GCFR_OK;
+    case 1:
+        g_xcd_affine = value != 0;
+        return GCFR_OK;
+    default:
+        return GCFR_ERR_INVALID_ARGUMENT;
+    }
+}
+
 extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
 {
     if (B <= 0 || H <= 0 || W <= 0)
@@ -422,12 +469,12 @@ extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
     return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4);
 }
 
-template <int TILE_W>
-static void launch_quad(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
-                        hipStream_t st)
+template <int TILE_W, bool XCD>
+static void launch_quad3(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
+                         hipStream_t st)
 {
 #define GCFR_LAUNCH(E, A) \
-    hipLaunchKernelGGL((shadow_fwd_quad_kernel<TILE_W, E, A, true>), dim3(blocks), dim3(256), 0, st, a)
+    hipLaunchKernelGGL((shadow_fwd_quad_kernel<TILE_W, E, A, XCD>), dim3(blocks), dim3(256), 0, st, a)
     if (even_half) {
         if (want_argmin)
             GCFR_LAUNCH(true, true);
@@ -440,6 +487,16 @@ static void launch_quad(const ShadowQuadArgs &a, bool even_half, bool want_argmi
             GCFR_LAUNCH(false, false);
     }
 #undef GCFR_LAUNCH
+}
+
+template <int TILE_W>
+static void launch_quad(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
+                        hipStream_t st)
+{
+    if (g_xcd_affine)
+        launch_quad3<TILE_W, true>(a, even_half, want_argmin, blocks, st);
+    else
+        launch_quad3<TILE_W, false>(a, even_half, want_argmin, blocks, st);
 }
 
 extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32_t mask_batch,
@@ -458,7 +515,7 @@ extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32
     if (workspace && workspace_bytes < gcfr_shadow_workspace_bytes(B, H, W))
         return GCFR_ERR_INVALID_ARGUMENT;
 
-    constexpr int TILE_W = 16, TILE_H = 64 / TILE_W, WAVES = 4;
+    const int TILE_W = workspace ? g_tile_w : 16, TILE_H = 64 / TILE_W, WAVES = 4;
     const int tiles_x = (W + TILE_W - 1) / TILE_W;
     const int quads_x = (tiles_x + WAVES - 1) / WAVES;
     const int quads_per_image = quads_x * ((H + TILE_H - 1) / TILE_H);
@@ -498,7 +555,21 @@ extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32
         a.by_lo = bx[2];
         a.by_hi = bx[3];
         const bool even_half = (((W / 2) & 1) == 0) && (((H / 2) & 1) == 0);
-        launch_quad<TILE_W>(a, even_half, argmin != nullptr, (unsigned)blocks, st);
+        const bool want = argmin != nullptr;
+        switch (TILE_W) {
+        case 8:
+            launch_quad<8>(a, even_half, want, (unsigned)blocks, st);
+            break;
+        case 32:
+            launch_quad<32>(a, even_half, want, (unsigned)blocks, st);
+            break;
+        case 64:
+            launch_quad<64>(a, even_half, want, (unsigned)blocks, st);
+            break;
+        default:
+            launch_quad<16>(a, even_half, want, (unsigned)blocks, st);
+            break;
+        }
         return launch_status();
     }
 
@@ -521,6 +592,6 @@ extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32
     a.bx_hi = bx[1];
     a.by_lo = bx[2];
     a.by_hi = bx[3];
-    hipLaunchKernelGGL(shadow_fwd_kernel<TILE_W>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(shadow_fwd_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     return launch_status();
 }

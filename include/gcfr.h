@@ -76,6 +76,10 @@ int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_z, float cl
  * Supported: 2 <= H,W <= 4096, even; 1 <= N <= 4096.
  */
 size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W);
+
+/* Tuning / A-B knob for experiments (process-wide; not needed in normal use; results never change):
+ * key 0 = tile width {8,16,32,64} (default 32), key 1 = XCD-affine block map {0,1} (default 0). */
+int gcfr_tune(int32_t key, int32_t value);
 int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32_t mask_batch,
                     const float *light_pt, int32_t B, int32_t L, int32_t H, int32_t W, int32_t N,
                     const double *t_table, float bonus, const float *bonus_box, float *min_dist,
