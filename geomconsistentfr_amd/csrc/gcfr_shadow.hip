@@ -243,7 +243,7 @@ __device__ inline int lo32(double v)
     return (int)(unsigned)(__builtin_bit_cast(unsigned long long, v) & 0xffffffffull);
 }
 
-template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, bool XCD_AFFINE>
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH>
 __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
 {
     constexpr int TILE_H = 64 / TILE_W;
@@ -252,27 +252,12 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
 
-    // blockIdx -> (image, light, tile quad).  Blocks are dealt round-robin to the 8 XCDs (observed:
-    // block i runs on XCD i % 8); XCD_AFFINE keeps every block of an image -- all its lights and
-    // tiles -- on one XCD so the image's depth/mask stay in that XCD's private L2.  Placement only
-    // affects speed, never results.
+    // blockIdx -> (image, light, tile quad), image-major.  An XCD-affine remap (all blocks of an image
+    // on one XCD) was measured 12 % SLOWER at B=8 -- one image per XCD makes the slowest image set the
+    // kernel time, and the CU L1 already serves 99.7 % of the gathers -- so blocks stay round-robin.
     const int per_image = a.quads_per_image * L;
-    int b, rem;
-    if (XCD_AFFINE) {
-        const int B8 = a.B & ~7;
-        const int i = blockIdx.x;
-        if (i < B8 * per_image) {
-            const int xcd = i & 7, j = i >> 3;
-            b = (j / per_image) * 8 + xcd;
-            rem = j % per_image;
-        } else {
-            b = i / per_image;
-            rem = i - b * per_image;
-        }
-    } else {
-        b = blockIdx.x / per_image;
-        rem = blockIdx.x - b * per_image;
-    }
+    const int b = blockIdx.x / per_image;
+    const int rem = blockIdx.x - b * per_image;
     const int l = rem / a.quads_per_image;
     const int q = rem - l * a.quads_per_image;
     const int bl = b * L + l;
@@ -338,49 +323,75 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
         return __mul24(row_r, W) + col_r;
     };
 
-    double nsx, nsy;
-    sample_pos(0, nsx, nsy);
-    uint32_t mk_next = buf_load_u8(mr, mask_offset(nsx, nsy));
+    // Samples are processed in groups of DEPTH.  The group's mask bytes were gathered one group ahead;
+    // if no lane has an unmasked sample anywhere in the group the whole group is skipped, otherwise the
+    // DEPTH bodies run as straight-line code so their texel gathers are in flight together.  Indices
+    // past N-1 are clamped to N-1: re-evaluating the last sample changes neither the minimum nor the
+    // (first) argmin, so the tail needs no branch.
+    auto clampk = [&](int k) { return k < N ? k : N - 1; };
+    uint32_t ring[DEPTH];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) {
+        double px, py;
+        sample_pos(clampk(j), px, py);
+        ring[j] = buf_load_u8(mr, mask_offset(px, py));
+    }
 
-    for (int k = 0; k < N; ++k) {
-        const double sx = nsx, sy = nsy;
-        const uint32_t mk = mk_next;
-        {  // stage A for the next sample (the last iteration harmlessly re-reads sample N-1)
-            const int kn = (k + 1 < N) ? k + 1 : N - 1;
-            sample_pos(kn, nsx, nsy);
-            mk_next = buf_load_u8(mr, mask_offset(nsx, nsy));
+    for (int k0 = 0; k0 < N; k0 += DEPTH) {
+        uint32_t mk[DEPTH];
+        bool none = true;
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            mk[j] = ring[j];
+            double px, py;  // gather the next group's mask bytes
+            sample_pos(clampk(k0 + DEPTH + j), px, py);
+            ring[j] = buf_load_u8(mr, mask_offset(px, py));
+            none = none && (mk[j] == 0);
+            any_masked |= (mk[j] == 0);
         }
-        const bool masked = (mk == 0);
-        any_masked |= masked;
-        if (__builtin_amdgcn_ballot_w64(!masked) == 0ull)
+        if (__builtin_amdgcn_ballot_w64(!none) == 0ull)
             continue;
-        // unrounded position (T8:480-487)
-        const double ux = (sx + halfW) - 0.0001;
-        const double uy = (halfH - sy) - 0.0001;
-        const double fxd = __builtin_floor(ux), gxd = __builtin_ceil(ux);
-        const double fyd = __builtin_floor(uy), gyd = __builtin_ceil(uy);
-        const int fx = (int)fxd, fy = (int)fyd;  // may be -1: the quad grid has that row / column
-        const int texel = __mul24(fy, Wp) + fx;
-        // NB: bit-cast the whole vector.  Indexing the builtin's result element-wise makes this
-        // hipcc narrow the load to ONE dword (all four corners alias) -- caught in the ISA.
-        const f32x4 qv = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(qr, (texel << 4) + quad_origin, 0, 0));
-        const double wx0 = gxd - ux, wx1 = ux - fxd;
-        const double wy0 = gyd - uy, wy1 = uy - fyd;
-        const double zUL = qv.x, zUR = qv.y, zLL = qv.z, zLR = qv.w;
-        const double up = zUL * wx0 + zUR * wx1;
-        const double low = zLL * wx0 + zLR * wx1;
-        const double zA = up * wy0 + low * wy1;
-        const float Ax = (float)(ux - halfW), Ay = (float)(halfH - uy), Az = (float)zA;
-        const float BAx = Ax - x, BAy = Ay - y, BAz = Az - zb;
-        const float Xx = __builtin_fmaf(BAy, BCz, -(BAz * BCy));
-        const float Xy = __builtin_fmaf(BAz, BCx, -(BAx * BCz));
-        const float Xz = __builtin_fmaf(BAx, BCy, -(BAy * BCx));
-        const float S = ((Xx * Xx + Xy * Xy) + Xz * Xz) + kEps4;
-        const bool take = !masked && (S < bestS);
-        bestS = take ? S : bestS;
-        if (WANT_ARGMIN)
-            besti = take ? k : besti;
+        // phase 1: positions and texel gathers for the whole group (all in flight together)
+        double ux[DEPTH], uy[DEPTH], fxd[DEPTH], fyd[DEPTH];
+        f32x4 qv[DEPTH];
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            double sx, sy;
+            sample_pos(clampk(k0 + j), sx, sy);
+            ux[j] = (sx + halfW) - 0.0001;  // unrounded position (T8:480-487)
+            uy[j] = (halfH - sy) - 0.0001;
+            fxd[j] = __builtin_floor(ux[j]);
+            fyd[j] = __builtin_floor(uy[j]);
+            const int fx = (int)fxd[j], fy = (int)fyd[j];  // may be -1: the quad grid has that row / column
+            const int texel = __mul24(fy, Wp) + fx;
+            // NB: bit-cast the whole vector.  Indexing the builtin's result element-wise makes this
+            // hipcc narrow the load to ONE dword (all four corners alias) -- caught in the ISA.
+            qv[j] = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(qr, (texel << 4) + quad_origin, 0, 0));
+        }
+        // phase 2: bilinear depth, point A, squared distance numerator, running minimum
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            const int k = clampk(k0 + j);
+            const bool masked = (mk[j] == 0);
+            const double gxd = __builtin_ceil(ux[j]), gyd = __builtin_ceil(uy[j]);
+            const double wx0 = gxd - ux[j], wx1 = ux[j] - fxd[j];
+            const double wy0 = gyd - uy[j], wy1 = uy[j] - fyd[j];
+            const double zUL = qv[j].x, zUR = qv[j].y, zLL = qv[j].z, zLR = qv[j].w;
+            const double up = zUL * wx0 + zUR * wx1;
+            const double low = zLL * wx0 + zLR * wx1;
+            const double zA = up * wy0 + low * wy1;
+            const float Ax = (float)(ux[j] - halfW), Ay = (float)(halfH - uy[j]), Az = (float)zA;
+            const float BAx = Ax - x, BAy = Ay - y, BAz = Az - zb;
+            const float Xx = __builtin_fmaf(BAy, BCz, -(BAz * BCy));
+            const float Xy = __builtin_fmaf(BAz, BCx, -(BAx * BCz));
+            const float Xz = __builtin_fmaf(BAx, BCy, -(BAy * BCx));
+            const float S = ((Xx * Xx + Xy * Xy) + Xz * Xz) + kEps4;
+            const bool take = !masked && (S < bestS);
+            bestS = take ? S : bestS;
+            if (WANT_ARGMIN)
+                besti = take ? k : besti;
+        }
     }
 
     const float den = __builtin_sqrtf(((BCx * BCx + BCy * BCy) + BCz * BCz) + kEps4);
@@ -440,11 +451,10 @@ extern "C" int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_
 
 // Process-wide tuning knobs (experiments / A-B runs only; defaults are the shipped configuration).
 // Measured on MI355X, B=8 x 256^2 x 160 (gpurun_out/ab_r01.txt -> DESIGN.md section 4.1):
-//   tile 2x32 > 4x16 > 8x8 > 1x64;  XCD-affine mapping is 12 % SLOWER at B=8 (one image per XCD: the
-//   slowest image sets the kernel time; L1 already serves 99.7 % of the gathers, so L2 affinity buys
-//   nothing);  f64 texels (32 B gathers) are 25 % slower (vector-memory bound).
-static int g_tile_w = 32;     // pixels per tile row: 8, 16, 32 or 64 (tile = 64/tile_w rows)
-static int g_xcd_affine = 0;  // keep all blocks of an image on one XCD
+//   tile 2x32 > 4x16 > 8x8 > 1x64;  an XCD-affine block map is 12 % slower;  f64 texels (32-B gathers)
+//   are 25 % slower (vector-memory bound).
+static int g_tile_w = 32;  // pixels per tile row: 8, 16, 32 or 64 (tile = 64/tile_w rows)
+static int g_depth = 4;    // samples per group (skip granularity / gathers in flight): 1, 2 or 4
 
 extern "C" int gcfr_tune(int32_t key, int32_t value)
 {
@@ -455,7 +465,9 @@ extern "C" int gcfr_tune(int32_t key, int32_t value)
         g_tile_w = value;
         return GCFR_OK;
     case 1:
-        g_xcd_affine = value != 0;
+        if (value != 1 && value != 2 && value != 4)
+            return GCFR_ERR_INVALID_ARGUMENT;
+        g_depth = value;
         return GCFR_OK;
     default:
         return GCFR_ERR_INVALID_ARGUMENT;
@@ -469,12 +481,12 @@ extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
     return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4);
 }
 
-template <int TILE_W, bool XCD>
+template <int TILE_W, int DEPTH>
 static void launch_quad3(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
                          hipStream_t st)
 {
 #define GCFR_LAUNCH(E, A) \
-    hipLaunchKernelGGL((shadow_fwd_quad_kernel<TILE_W, E, A, XCD>), dim3(blocks), dim3(256), 0, st, a)
+    hipLaunchKernelGGL((shadow_fwd_quad_kernel<TILE_W, E, A, DEPTH>), dim3(blocks), dim3(256), 0, st, a)
     if (even_half) {
         if (want_argmin)
             GCFR_LAUNCH(true, true);
@@ -493,10 +505,12 @@ template <int TILE_W>
 static void launch_quad(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
                         hipStream_t st)
 {
-    if (g_xcd_affine)
-        launch_quad3<TILE_W, true>(a, even_half, want_argmin, blocks, st);
+    if (g_depth == 1)
+        launch_quad3<TILE_W, 1>(a, even_half, want_argmin, blocks, st);
+    else if (g_depth == 2)
+        launch_quad3<TILE_W, 2>(a, even_half, want_argmin, blocks, st);
     else
-        launch_quad3<TILE_W, false>(a, even_half, want_argmin, blocks, st);
+        launch_quad3<TILE_W, 4>(a, even_half, want_argmin, blocks, st);
 }
 
 extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32_t mask_batch,
