@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--faces", type=int, default=FACES_PER_GPU, help="faces per GPU per step (configs[1]: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--direct", action="store_true", help="A/B: direct-gather kernel (no workspace prepass)")
+    ap.add_argument("--unfused", action="store_true", help="A/B: three separate entry points instead of gcfr_render_fwd")
     ap.add_argument("--tune", type=str, default="", help="A/B: comma list key=value for gcfr_tune, e.g. 0=32,2=1")
     a = ap.parse_args()
 
@@ -143,19 +144,35 @@ def main():
     d_light = torch.from_numpy(light).to(dev)
     d_amb = torch.from_numpy(amb).to(dev)
 
+    # HIP events around the dominant (march) kernel alone, recorded on the launch stream by the library
+    # itself (gcfr_profile_events); created through the same HIP runtime torch loaded.
+    import ctypes
+    from geomconsistentfr_amd import _lib
+    L_ = _lib.load()
+    hip = ctypes.CDLL("libamdhip64.so")
     ev_pairs = []
 
+    def new_event():
+        e = ctypes.c_void_p()
+        assert hip.hipEventCreate(ctypes.byref(e)) == 0
+        return e
+
     def step(timed):
-        _, pt = R.light_prep(d_light, prm)
         if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()                                   # same stream the kernel is launched on
-        md, _ = R.shadow_min_distance(d_depth, d_mask, pt.reshape(B, 1, 3), prm, want_argmin=False,
-                                       use_workspace=not a.direct)
-        if timed:
-            e1.record()
+            e0, e1 = new_event(), new_event()
+            _lib.check(L_.gcfr_profile_events(e0, e1), "gcfr_profile_events")
             ev_pairs.append((e0, e1))
-        return R.shade(d_normals, d_depth, d_albedo, pt.reshape(B, 1, 3), d_amb.reshape(B, 1), md, prm)
+        if a.direct or a.unfused:
+            _, pt = R.light_prep(d_light, prm)
+            md, _ = R.shadow_min_distance(d_depth, d_mask, pt.reshape(B, 1, 3), prm, want_argmin=False,
+                                          use_workspace=not a.direct)
+            out = R.shade(d_normals, d_depth, d_albedo, pt.reshape(B, 1, 3), d_amb.reshape(B, 1), md, prm)
+        else:
+            out = R.render_fwd(d_depth, d_mask, d_light.reshape(B, 1, 3), d_amb.reshape(B, 1), d_normals, d_albedo,
+                               prm, want_argmin=False)
+        if timed:
+            _lib.check(L_.gcfr_profile_events(None, None), "gcfr_profile_events")
+        return out
 
     for _ in range(a.warmup):
         step(False)
@@ -179,7 +196,15 @@ def main():
 
     ray_steps_per_step = world * B * H * W * N_SAMPLES
     value = ray_steps_per_step * a.steps / elapsed
-    shadow_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev_pairs]))
+    def elapsed_ms(e0, e1):
+        ms = ctypes.c_float()
+        assert hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1) == 0
+        return ms.value
+
+    if a.direct:      # the direct kernel has no event hook: fall back to the whole-step time
+        shadow_ms = 1e3 * elapsed / a.steps
+    else:
+        shadow_ms = float(np.mean([elapsed_ms(e0, e1) for e0, e1 in ev_pairs]))
     algo_bytes = B * H * W * N_SAMPLES * ALGO_BYTES_PER_RAY_STEP          # per launch (one rank)
     achieved = algo_bytes / (shadow_ms * 1e-3) / 1e9
 
@@ -194,7 +219,7 @@ def main():
                        "faces_per_gpu": B, "H": H, "W": W, "n_samples": N_SAMPLES, "parallelism": "dp%d" % world},
             "faces_per_sec": world * B * a.steps / elapsed,
             "ray_steps_per_sec_per_gpu": value / world,
-            "roofline": {"bound": "hbm", "kernel": "shadow_fwd_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "shadow_fwd_quad_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": shadow_ms,
                          "kernel_ray_steps_per_sec": B * H * W * N_SAMPLES / (shadow_ms * 1e-3)},

@@ -153,6 +153,48 @@ def shade(normals, depth, albedo, light_pt, ambient, min_dist, params: RenderPar
     return dict(shadow_mask_weights=w, full_shading=full, final_shading=fin, rendered_images=ren)
 
 
+def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParams = RenderParams(),
+               want_argmin: bool = True):
+    """One enqueue for the whole forward block (gcfr_render_fwd): light prep, depth repack, ray march with
+    the shading fused into its epilogue.  depth (B,H,W), mask (B|1,H,W), light (B,L,3) raw/target,
+    ambient (B,L), normals/albedo (B,3,H,W).  Returns a dict of f32 tensors (B,L,...)."""
+    _require_device(depth, mask, light, ambient, normals, albedo)
+    L_ = _lib.load()
+    depth = _f32c(depth)
+    B, H, W = depth.shape
+    dev = depth.device
+    mask_u8 = mask_to_u8(mask).reshape(-1, H, W)
+    light = _f32c(light).reshape(B, -1, 3)
+    L = light.shape[1]
+    ambient = _f32c(ambient).reshape(B, L)
+    normals = _f32c(normals).reshape(B, 3, H, W)
+    albedo = _f32c(albedo).reshape(B, 3, H, W)
+    tt = sample_table(params, dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    unit = torch.empty((B, L, 3), **f32)
+    pt = torch.empty((B, L, 3), **f32)
+    md = torch.empty((B, L, H, W), **f32)
+    am = torch.empty((B, L, H, W), dtype=torch.int32, device=dev) if want_argmin else None
+    w = torch.empty((B, L, H, W), **f32)
+    full = torch.empty((B, L, H, W), **f32)
+    fin = torch.empty((B, L, H, W), **f32)
+    ren = torch.empty((B, L, 3, H, W), **f32)
+    ws_bytes = int(L_.gcfr_shadow_workspace_bytes(B, H, W))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    box = ctypes_float4(params.bonus_box) if params.bonus_box is not None else None
+    clamp = params.clamp_light_z_min is not None
+    with torch.cuda.device(dev):
+        _lib.check(L_.gcfr_render_fwd(
+            light.data_ptr(), int(clamp), float(params.clamp_light_z_min or 0.0), float(params.light_distance),
+            depth.data_ptr(), mask_u8.data_ptr(), mask_u8.shape[0], normals.data_ptr(), albedo.data_ptr(),
+            ambient.data_ptr(), B, L, H, W, params.n_samples, tt.data_ptr(), float(params.inside_bonus), box,
+            float(params.directional_intensity), unit.data_ptr(), pt.data_ptr(), md.data_ptr(), _opt_ptr(am),
+            w.data_ptr(), full.data_ptr(), fin.data_ptr(), ren.data_ptr(), ws.data_ptr(), ws_bytes,
+            _stream_ptr(dev)), "gcfr_render_fwd")
+    return dict(unit_light_direction=unit, light_pt=pt, minimum_distance=md, argmin=am, shadow_mask_weights=w,
+                full_shading=full, final_shading=fin, rendered_images=ren)
+
+
 def _zeros(shape, dtype, device):
     return torch.zeros(shape, dtype=dtype, device=device)
 
@@ -175,10 +217,11 @@ class _RenderFunction(torch.autograd.Function):
         amb = _f32c(ambient).reshape(B, 1)
         albedo_c = _f32c(albedo)
         normals_c = _f32c(normals)
-        unit, pt = light_prep(light2, params)
         need_grad = any(ctx.needs_input_grad[:5])
-        md, am = shadow_min_distance(depth3, mask_u8, pt.reshape(B, 1, 3), params, want_argmin=need_grad)
-        out = shade(normals_c, depth3, albedo_c, pt.reshape(B, 1, 3), amb, md, params)
+        out = render_fwd(depth3, mask_u8, light2.reshape(B, 1, 3), amb, normals_c, albedo_c, params,
+                         want_argmin=need_grad)
+        unit, pt, md, am = (out["unit_light_direction"].reshape(B, 3), out["light_pt"].reshape(B, 3),
+                            out["minimum_distance"], out["argmin"])
         ctx.params = params
         if need_grad:
             ctx.save_for_backward(depth3, albedo_c, light2, amb, normals_c, pt, md, am)

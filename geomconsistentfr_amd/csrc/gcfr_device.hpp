@@ -100,4 +100,37 @@ __device__ inline float norm3_torch(float a, float b, float c)
     return __builtin_sqrtf(__builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a)));
 }
 
+// T8:517: w = 1 - 4 e^-d / (1 + e^-d)^2   (== tanh^2(d/2)); evaluated as written, in f32.
+__device__ inline float shadow_transfer(float d)
+{
+    const float e = expf(-d);  // precise expf (the fast __expf is deliberately not used)
+    const float onepe = 1.0f + e;
+    return (-4.0f * e) / (onepe * onepe) + 1.0f;
+}
+
+// Shading of one pixel for one light, T8:364-369 and 517-518 (shared by the stand-alone shade kernel
+// and the fused epilogue of the march kernel so that both produce the same bits).
+struct Shaded {
+    float w, full, fin;
+};
+__device__ inline Shaded shade_pixel(float x, float y, float zb, float nx, float ny, float nz, float Cx,
+                                     float Cy, float Cz, float amb, float intensity, float min_dist)
+{
+    // incident light direction, T8:364
+    const float lx = Cx - x, ly = Cy - y, lz = Cz - zb;
+    float ln = norm3_torch(lx, ly, lz);
+    ln = ln > 1e-12f ? ln : 1e-12f;
+    const float ux = lx / ln, uy = ly / ln, uz = lz / ln;
+    // surface normal, re-normalised (T8:365)
+    float nn = norm3_torch(nx, ny, nz);
+    nn = nn > 1e-12f ? nn : 1e-12f;
+    const float n0 = nx / nn, n1 = ny / nn, n2 = nz / nn;
+    const float dot = (n0 * ux + n1 * uy) + n2 * uz;  // T8:366
+    Shaded o;
+    o.full = amb + intensity * (dot > 0.0f ? dot : 0.0f);  // T8:366-369
+    o.w = shadow_transfer(min_dist);                        // T8:517
+    o.fin = o.w * o.full + (1.0f - o.w) * amb;              // T8:518
+    return o;
+}
+
 }  // namespace gcfr

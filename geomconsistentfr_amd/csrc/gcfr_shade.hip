@@ -27,14 +27,6 @@ struct ShadeArgs {
     float intensity;
 };
 
-// T8:517: w = 1 - 4 e^-d / (1 + e^-d)^2   (== tanh^2(d/2)); evaluated as written, in f32.
-__device__ inline float shadow_transfer(float d)
-{
-    const float e = expf(-d);  // precise expf (the fast __expf is deliberately not used)
-    const float onepe = 1.0f + e;
-    return (-4.0f * e) / (onepe * onepe) + 1.0f;
-}
-
 __global__ __launch_bounds__(256) void shade_fwd_kernel(ShadeArgs a)
 {
     const int W = a.W, H = a.H;
@@ -50,22 +42,11 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(ShadeArgs a)
         const int r = (int)(p / W), c = (int)(p - (size_t)r * W);
         const float x = (float)c - halfWf, y = halfHf - (float)r;
         const float zb = a.depth[(size_t)b * P + p];
-        // incident light direction, T8:364
-        const float lx = Cx - x, ly = Cy - y, lz = Cz - zb;
-        float ln = norm3_torch(lx, ly, lz);
-        ln = ln > 1e-12f ? ln : 1e-12f;
-        const float ux = lx / ln, uy = ly / ln, uz = lz / ln;
-        // surface normal, re-normalised (T8:365)
-        const float nx = a.normals[((size_t)b * 3 + 0) * P + p];
-        const float ny = a.normals[((size_t)b * 3 + 1) * P + p];
-        const float nz = a.normals[((size_t)b * 3 + 2) * P + p];
-        float nn = norm3_torch(nx, ny, nz);
-        nn = nn > 1e-12f ? nn : 1e-12f;
-        const float n0 = nx / nn, n1 = ny / nn, n2 = nz / nn;
-        const float dot = (n0 * ux + n1 * uy) + n2 * uz;           // T8:366
-        const float full = amb + a.intensity * (dot > 0.0f ? dot : 0.0f);  // T8:366-369
-        const float w = shadow_transfer(a.min_dist[(size_t)bl * P + p]);     // T8:517
-        const float fin = w * full + (1.0f - w) * amb;              // T8:518
+        const Shaded sh = shade_pixel(x, y, zb, a.normals[((size_t)b * 3 + 0) * P + p],
+                                      a.normals[((size_t)b * 3 + 1) * P + p],
+                                      a.normals[((size_t)b * 3 + 2) * P + p], Cx, Cy, Cz, amb, a.intensity,
+                                      a.min_dist[(size_t)bl * P + p]);
+        const float w = sh.w, full = sh.full, fin = sh.fin;
         const size_t o = (size_t)bl * P + p;
         if (a.shadow_w)
             a.shadow_w[o] = w;

@@ -21,13 +21,10 @@ namespace gcfr {
 // ----------------------------------------------------------------------------------------------
 // light preparation, T8:357-363 / S1:332-336
 // ----------------------------------------------------------------------------------------------
-__global__ void light_prep_kernel(const float *__restrict__ light_raw, int n, int clamp_z,
-                                  float clamp_min, float light_distance, float *__restrict__ unit_out,
-                                  float *__restrict__ light_pt_out)
+__device__ inline void light_prep_one(const float *__restrict__ light_raw, int i, int clamp_z,
+                                      float clamp_min, float light_distance,
+                                      float *__restrict__ unit_out, float *__restrict__ light_pt_out)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
     const float a = light_raw[3 * i + 0], b = light_raw[3 * i + 1];
     float c = light_raw[3 * i + 2];
     if (clamp_z)
@@ -41,6 +38,15 @@ __global__ void light_prep_kernel(const float *__restrict__ light_raw, int n, in
     light_pt_out[3 * i + 0] = light_distance * ux;  // T8:362
     light_pt_out[3 * i + 1] = light_distance * uy;
     light_pt_out[3 * i + 2] = light_distance * uz;
+}
+
+__global__ void light_prep_kernel(const float *__restrict__ light_raw, int n, int clamp_z,
+                                  float clamp_min, float light_distance, float *__restrict__ unit_out,
+                                  float *__restrict__ light_pt_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        light_prep_one(light_raw, i, clamp_z, clamp_min, light_distance, unit_out, light_pt_out);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -203,12 +209,25 @@ __global__ __launch_bounds__(256) void shadow_fwd_kernel(ShadowArgs a)
 //     +W/2 and H/2- offsets ride in the magic constant (parity-safe), otherwise they are int adds;
 //   * argmin tracking compiled out when the caller does not ask for it (inference).
 // ----------------------------------------------------------------------------------------------
+struct PrepassLights {  // optional: fold gcfr_light_prep into the prepass launch (gcfr_render_fwd)
+    const float *light_raw = nullptr;
+    float *unit_out = nullptr, *light_pt_out = nullptr;
+    int L = 0, clamp_z = 0;
+    float clamp_min = 0.0f, light_distance = 0.0f;
+};
+
 __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict__ depth,
-                                                         float4 *__restrict__ quad, int H, int W)
+                                                         float4 *__restrict__ quad, int H, int W,
+                                                         PrepassLights pl)
 {
     const int Wp = W + 1, Hp = H + 1;
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pl.light_raw && blockIdx.x == 0) {
+        for (int l = threadIdx.x; l < pl.L; l += blockDim.x)
+            light_prep_one(pl.light_raw, b * pl.L + l, pl.clamp_z, pl.clamp_min, pl.light_distance,
+                           pl.unit_out, pl.light_pt_out);
+    }
     if (i >= Hp * Wp)
         return;
     const int rp = i / Wp, cp = i - rp * Wp;
@@ -233,6 +252,12 @@ struct ShadowQuadArgs {
     int32_t mask_batch, B, L, H, W, N;
     int32_t quads_x, quads_per_image;  // 4-tile block columns / blocks per (image, light)
     float bonus, bx_lo, bx_hi, by_lo, by_hi;
+    // fused shading epilogue (FUSE_SHADE): T8:364-369, 517-522 on the pixel the lane just marched
+    const float *normals;   // (B,3,H,W)
+    const float *albedo;    // (B,3,H,W)
+    const float *ambient;   // (B,L)
+    float *shadow_w, *full, *final_shading, *rendered;
+    float intensity;
 };
 
 constexpr double kRintMagic = 6755399441055744.0;  // 2^52 + 2^51
@@ -243,7 +268,7 @@ __device__ inline int lo32(double v)
     return (int)(unsigned)(__builtin_bit_cast(unsigned long long, v) & 0xffffffffull);
 }
 
-template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH>
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE>
 __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
 {
     constexpr int TILE_H = 64 / TILE_W;
@@ -406,10 +431,27 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
     if (inside)
         d = d + a.bonus;
     if (valid) {
-        const size_t o = (size_t)bl * P + (size_t)r * W + c;
+        const size_t pix = (size_t)r * W + c;
+        const size_t o = (size_t)bl * P + pix;
         a.min_dist[o] = d;
         if (WANT_ARGMIN)
             a.argmin[o] = besti;
+        if (FUSE_SHADE) {
+            const float *nrm = a.normals + (size_t)b * 3 * P + pix;
+            const Shaded sh = shade_pixel(x, y, zb, nrm[0], nrm[P], nrm[2 * P], Cx, Cy, Cz, a.ambient[bl],
+                                          a.intensity, d);
+            if (a.shadow_w)
+                a.shadow_w[o] = sh.w;
+            if (a.full)
+                a.full[o] = sh.full;
+            if (a.final_shading)
+                a.final_shading[o] = sh.fin;
+            const float *alb = a.albedo + (size_t)b * 3 * P + pix;
+            float *ren = a.rendered + (size_t)bl * 3 * P + pix;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)  // T8:519-522
+                ren[ch * P] = alb[ch * P] * sh.fin;
+        }
     }
 }
 
@@ -481,12 +523,22 @@ extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
     return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4);
 }
 
-template <int TILE_W, int DEPTH>
-static void launch_quad3(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
+// Optional profiling hook: events recorded around the dominant (march) kernel of the next launches.
+static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
+extern "C" int gcfr_profile_events(void *start, void *stop)
+{
+    g_ev_start = (hipEvent_t)start;
+    g_ev_stop = (hipEvent_t)stop;
+    return GCFR_OK;
+}
+
+template <int TILE_W, int DEPTH, bool FUSE>
+static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
                          hipStream_t st)
 {
 #define GCFR_LAUNCH(E, A) \
-    hipLaunchKernelGGL((shadow_fwd_quad_kernel<TILE_W, E, A, DEPTH>), dim3(blocks), dim3(256), 0, st, a)
+    hipLaunchKernelGGL((shadow_fwd_quad_kernel<TILE_W, E, A, DEPTH, FUSE>), dim3(blocks), dim3(256), 0, st, a)
     if (even_half) {
         if (want_argmin)
             GCFR_LAUNCH(true, true);
@@ -501,23 +553,44 @@ static void launch_quad3(const ShadowQuadArgs &a, bool even_half, bool want_argm
 #undef GCFR_LAUNCH
 }
 
+template <int TILE_W, int DEPTH>
+static void launch_quad3(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
+                         hipStream_t st)
+{
+    if (a.rendered)
+        launch_quad4<TILE_W, DEPTH, true>(a, even_half, want_argmin, blocks, st);
+    else
+        launch_quad4<TILE_W, DEPTH, false>(a, even_half, want_argmin, blocks, st);
+}
+
 template <int TILE_W>
 static void launch_quad(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
                         hipStream_t st)
 {
+    if (g_ev_start)
+        (void)hipEventRecord(g_ev_start, st);
     if (g_depth == 1)
         launch_quad3<TILE_W, 1>(a, even_half, want_argmin, blocks, st);
     else if (g_depth == 2)
         launch_quad3<TILE_W, 2>(a, even_half, want_argmin, blocks, st);
     else
         launch_quad3<TILE_W, 4>(a, even_half, want_argmin, blocks, st);
+    if (g_ev_stop)
+        (void)hipEventRecord(g_ev_stop, st);
 }
 
-extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32_t mask_batch,
-                               const float *light_pt, int32_t B, int32_t L, int32_t H, int32_t W,
-                               int32_t N, const double *t_table, float bonus,
-                               const float *bonus_box, float *min_dist, int32_t *argmin,
-                               void *workspace, size_t workspace_bytes, void *stream)
+struct FusedShade {  // operands of the fused shading epilogue; rendered == nullptr: march only
+    const float *normals = nullptr, *albedo = nullptr, *ambient = nullptr;
+    float *shadow_w = nullptr, *full = nullptr, *final_shading = nullptr, *rendered = nullptr;
+    float intensity = 0.0f;
+    PrepassLights lights;  // light_raw != nullptr: the prepass also writes unit / light_pt
+};
+
+static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t mask_batch,
+                           const float *light_pt, int32_t B, int32_t L, int32_t H, int32_t W, int32_t N,
+                           const double *t_table, float bonus, const float *bonus_box, float *min_dist,
+                           int32_t *argmin, void *workspace, size_t workspace_bytes, void *stream,
+                           const FusedShade &fs)
 {
     if (!depth || !mask_u8 || !light_pt || !t_table || !min_dist)
         return GCFR_ERR_INVALID_ARGUMENT;
@@ -546,7 +619,7 @@ extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32
         // prepass: 2x2 neighbourhood grid (see shadow_fwd_quad_kernel), then the march
         const int texels = (H + 1) * (W + 1);
         hipLaunchKernelGGL(build_quad_kernel, dim3((texels + 255) / 256, B), dim3(256), 0, st, depth,
-                           (float4 *)workspace, H, W);
+                           (float4 *)workspace, H, W, fs.lights);
         ShadowQuadArgs a;
         a.depth = depth;
         a.quad = (const float4 *)workspace;
@@ -568,6 +641,14 @@ extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32
         a.bx_hi = bx[1];
         a.by_lo = bx[2];
         a.by_hi = bx[3];
+        a.normals = fs.normals;
+        a.albedo = fs.albedo;
+        a.ambient = fs.ambient;
+        a.shadow_w = fs.shadow_w;
+        a.full = fs.full;
+        a.final_shading = fs.final_shading;
+        a.rendered = fs.rendered;
+        a.intensity = fs.intensity;
         const bool even_half = (((W / 2) & 1) == 0) && (((H / 2) & 1) == 0);
         const bool want = argmin != nullptr;
         switch (TILE_W) {
@@ -587,6 +668,8 @@ extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32
         return launch_status();
     }
 
+    if (fs.rendered)
+        return GCFR_ERR_INVALID_ARGUMENT;  // the fused epilogue lives in the workspace kernel only
     ShadowArgs a;
     a.depth = depth;
     a.mask = mask_u8;
@@ -608,4 +691,48 @@ extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32
     a.by_hi = bx[3];
     hipLaunchKernelGGL(shadow_fwd_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, a);
     return launch_status();
+}
+
+extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32_t mask_batch,
+                               const float *light_pt, int32_t B, int32_t L, int32_t H, int32_t W,
+                               int32_t N, const double *t_table, float bonus,
+                               const float *bonus_box, float *min_dist, int32_t *argmin,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    return shadow_fwd_impl(depth, mask_u8, mask_batch, light_pt, B, L, H, W, N, t_table, bonus, bonus_box,
+                           min_dist, argmin, workspace, workspace_bytes, stream, FusedShade{});
+}
+
+extern "C" int gcfr_render_fwd(const float *light_raw, int32_t clamp_z, float clamp_min,
+                               float light_distance, const float *depth, const uint8_t *mask_u8,
+                               int32_t mask_batch, const float *normals, const float *albedo,
+                               const float *ambient, int32_t B, int32_t L, int32_t H, int32_t W,
+                               int32_t N, const double *t_table, float bonus, const float *bonus_box,
+                               float intensity, float *unit_out, float *light_pt_out, float *min_dist,
+                               int32_t *argmin, float *shadow_w, float *full, float *final_shading,
+                               float *rendered, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!light_raw || !normals || !albedo || !ambient || !unit_out || !light_pt_out || !rendered ||
+        !workspace)
+        return GCFR_ERR_INVALID_ARGUMENT;
+    if (B <= 0 || L <= 0)
+        return GCFR_ERR_INVALID_ARGUMENT;
+    FusedShade fs;
+    fs.lights.light_raw = light_raw;  // light prep rides in the prepass launch
+    fs.lights.unit_out = unit_out;
+    fs.lights.light_pt_out = light_pt_out;
+    fs.lights.L = L;
+    fs.lights.clamp_z = clamp_z;
+    fs.lights.clamp_min = clamp_min;
+    fs.lights.light_distance = light_distance;
+    fs.normals = normals;
+    fs.albedo = albedo;
+    fs.ambient = ambient;
+    fs.shadow_w = shadow_w;
+    fs.full = full;
+    fs.final_shading = final_shading;
+    fs.rendered = rendered;
+    fs.intensity = intensity;
+    return shadow_fwd_impl(depth, mask_u8, mask_batch, light_pt_out, B, L, H, W, N, t_table, bonus,
+                           bonus_box, min_dist, argmin, workspace, workspace_bytes, stream, fs);
 }

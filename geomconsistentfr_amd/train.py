@@ -184,7 +184,7 @@ class Trainer:
             (d_fake + d_real).backward()
             self.opt_d.step()
             if log:
-                logs.update(discriminator=float(d_fake + d_real))
+                logs.update(discriminator=float((d_fake + d_real).detach()))
         # ---- generator (T8:631-656) ----
         self.opt.zero_grad(set_to_none=True)
         for p in self.patchgan.parameters():

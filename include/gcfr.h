@@ -103,6 +103,27 @@ int gcfr_shade_fwd(const float *normals, const float *depth, const float *albedo
                    int32_t L, int32_t H, int32_t W, float intensity, float *shadow_w, float *full,
                    float *final_shading, float *rendered, void *stream);
 
+/*
+ * One-call forward for a batch: gcfr_light_prep + depth repack + ray march with the shading fused
+ * into the march kernel's epilogue (each lane shades the pixel it just marched; min_dist never
+ * makes a round trip through HBM).  Replaces T8:356-522 in one enqueue.  Arguments as in the three
+ * entry points above; workspace is mandatory; argmin / shadow_w / full / final_shading may be NULL.
+ * Results are bit-identical to calling gcfr_light_prep, gcfr_shadow_fwd and gcfr_shade_fwd in turn.
+ */
+int gcfr_render_fwd(const float *light_raw, int32_t clamp_z, float clamp_min, float light_distance,
+                    const float *depth, const uint8_t *mask_u8, int32_t mask_batch,
+                    const float *normals, const float *albedo, const float *ambient, int32_t B,
+                    int32_t L, int32_t H, int32_t W, int32_t N, const double *t_table, float bonus,
+                    const float *bonus_box, float intensity, float *unit_out, float *light_pt_out,
+                    float *min_dist, int32_t *argmin, float *shadow_w, float *full,
+                    float *final_shading, float *rendered, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
+/* Profiling hook: two hipEvent_t handles (or NULL, NULL to clear) that subsequent gcfr_shadow_fwd /
+ * gcfr_render_fwd calls record immediately before and after the march kernel, on the launch stream.
+ * Process-wide; used by bench.py to time the dominant kernel alone. */
+int gcfr_profile_events(void *start_event, void *stop_event);
+
 /* ---------------------------------------------------------------------------------------------
  * Backward.  The reference has no explicit backward: torch autograd replays T8:352-524
  * (loss.backward() at T8:655).  These entry points compute the same vector-Jacobian products.
