@@ -9,11 +9,15 @@ kornia 0.4.1's published algorithm --
     n = normalize(cross(dP/du, dP/dv))                                   F.normalize, eps 1e-12
 -- and everything downstream of it (shading given normals) is pinned by reference code.
 
-Plain torch ops (device-agnostic, differentiable); SURVEY.md 8(f)-1 lists fusing this stencil into the
-HIP shading kernel as the next widening step.
+Two implementations of the same statement:
+  * tensors on a ROCm device -> the HIP kernels gcfr_normals_fwd / gcfr_normals_bwd (csrc/gcfr_normals.hip)
+    behind a torch.autograd.Function (no fallback: a missing library raises);
+  * host tensors -> plain torch ops (`depth_to_normals_torch`), used by the CPU tests and as the readable spec.
 """
 import torch
 import torch.nn.functional as F
+
+from . import _lib
 
 
 def _sobel(p):
@@ -27,9 +31,51 @@ def _sobel(p):
     return du, dv
 
 
-def depth_to_normals(depth: torch.Tensor, camera_matrix: torch.Tensor, negate_y: bool = True) -> torch.Tensor:
-    """depth (B,1,H,W), camera_matrix (1|B,3,3) -> unit normals (B,3,H,W) in depth's dtype, y negated
-    as the reference does right after the call (T8:354)."""
+class _NormalsFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, fx, fy, cx, cy, z_offset, negate_y):
+        B, _, H, W = depth.shape
+        d = depth.detach().to(torch.float32).contiguous()
+        out = torch.empty((B, 3, H, W), dtype=torch.float32, device=d.device)
+        with torch.cuda.device(d.device):
+            _lib.check(_lib.load().gcfr_normals_fwd(d.data_ptr(), B, H, W, fx, fy, cx, cy, float(z_offset),
+                                                    int(negate_y), out.data_ptr(),
+                                                    torch.cuda.current_stream(d.device).cuda_stream), "gcfr_normals_fwd")
+        ctx.save_for_backward(d)
+        ctx.k = (fx, fy, cx, cy, float(z_offset), int(negate_y))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        B, _, H, W = d.shape
+        fx, fy, cx, cy, z_offset, negate_y = ctx.k
+        g = g.detach().to(torch.float32).contiguous()
+        gd = torch.zeros((B, 1, H, W), dtype=torch.float32, device=d.device)
+        with torch.cuda.device(d.device):
+            _lib.check(_lib.load().gcfr_normals_bwd(g.data_ptr(), d.data_ptr(), B, H, W, fx, fy, cx, cy, z_offset,
+                                                    negate_y, gd.data_ptr(),
+                                                    torch.cuda.current_stream(d.device).cuda_stream), "gcfr_normals_bwd")
+        return gd, None, None, None, None, None, None
+
+
+def depth_to_normals(depth: torch.Tensor, camera_matrix: torch.Tensor, negate_y: bool = True,
+                     z_offset: float = 0.0) -> torch.Tensor:
+    """depth (B,1,H,W), camera_matrix (1|B,3,3) -> unit normals (B,3,H,W), y negated as the reference does
+    right after the call (T8:354).  `z_offset` is added to the depth in f32 first (T8:353: +1610).
+    Device tensors run the HIP kernels; host tensors the torch restatement."""
+    if not depth.is_cuda:
+        return depth_to_normals_torch(depth + z_offset if z_offset else depth, camera_matrix, negate_y)
+    K = camera_matrix.detach().to("cpu", torch.float64)          # tiny; the reference builds it on the host (T8:571)
+    if K.shape[0] != 1 and not bool((K == K[:1]).all()):
+        return torch.cat([depth_to_normals(depth[i:i + 1], camera_matrix[i:i + 1], negate_y, z_offset)
+                          for i in range(depth.shape[0])])
+    fx, fy, cx, cy = (float(K[0, 0, 0]), float(K[0, 1, 1]), float(K[0, 0, 2]), float(K[0, 1, 2]))
+    return _NormalsFunction.apply(depth, fx, fy, cx, cy, z_offset, negate_y)
+
+
+def depth_to_normals_torch(depth: torch.Tensor, camera_matrix: torch.Tensor, negate_y: bool = True) -> torch.Tensor:
+    """Torch-op statement of the same algorithm (any device, differentiable by autograd)."""
     B, _, H, W = depth.shape
     K = camera_matrix.to(device=depth.device)
     ct = torch.promote_types(depth.dtype, K.dtype)            # the reference's K is f64 -> f64 maths

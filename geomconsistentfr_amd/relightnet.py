@@ -133,7 +133,7 @@ class RelightNet(_Hourglass):
     def forward(self, img, epoch, intrinsic_matrix, masks):
         albedo, depth, SL = self.features(img, epoch)
         B = depth.shape[0]
-        normals = depth_to_normals(depth + self.normal_z_offset, intrinsic_matrix)      # T8:353-354 (y negated)
+        normals = depth_to_normals(depth, intrinsic_matrix, z_offset=self.normal_z_offset)   # T8:353-354 (y negated)
         r = render(depth, albedo, SL[:, 0, 0, 1:4], SL[:, 0, 0, 0], normals,
                    masks.reshape(B, masks.shape[1], masks.shape[2]), self.render_params)
         return (albedo, depth, r["shadow_mask_weights"], r["ambient_light"], r["full_shading"],
@@ -154,7 +154,7 @@ class RelightNetSingleImage(_Hourglass):
     def forward(self, img, epoch, intrinsic_matrix, mask, target_lighting, target_ambient_values, batch_mask=None):
         albedo, depth, SL = self.features(img, epoch)
         B, _, H, W = depth.shape
-        normals = depth_to_normals(depth + self.normal_z_offset, intrinsic_matrix)
+        normals = depth_to_normals(depth, intrinsic_matrix, z_offset=self.normal_z_offset)
         ambient = SL[:, 0, 0, 0] + self.ambient_offset                                  # S1:342
         r = render(depth, albedo, target_lighting.reshape(B, 3), ambient, normals, mask.reshape(1, H, W),
                    self.render_params)
@@ -176,7 +176,7 @@ class RelightNetLightingTransfer(_Hourglass):
     def forward(self, img, epoch, intrinsic_matrix, mask, target_lighting, target_ambient_values):
         albedo, depth, SL = self.features(img, epoch)
         B, _, H, W = depth.shape
-        normals = depth_to_normals(depth + self.normal_z_offset, intrinsic_matrix)
+        normals = depth_to_normals(depth, intrinsic_matrix, z_offset=self.normal_z_offset)
         est = SL[:, 0, 0, 1:4]
         est = torch.stack([est[:, 0], est[:, 1], torch.clamp_min(est[:, 2], self.estimate_z_min)], 1)
         est_unit = F.normalize(est, p=2, dim=1).reshape(B, 3, 1, 1)                     # SLT:329-335

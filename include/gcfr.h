@@ -104,6 +104,20 @@ int gcfr_shade_fwd(const float *normals, const float *depth, const float *albedo
                    float *final_shading, float *rendered, void *stream);
 
 /*
+ * Surface normals from depth.  Replaces the kornia call + sign flip at T8:353-354 (SLT:325: offset 1410,
+ * focal 700).  kornia 0.4.1 is un-vendored: this restates its published algorithm (unproject with the
+ * camera matrix, normalised 3x3 Sobel with replicate padding, cross, normalise) -- parity UNPINNED.
+ *   depth (B,H,W) f32;  fx, fy, cx, cy from intrinsic_matrix (T8:571-577);  z_offset added in f32
+ *   negate_y: 1 = apply T8:354;  normals (B,3,H,W) f32 out, unit length
+ */
+int gcfr_normals_fwd(const float *depth, int32_t B, int32_t H, int32_t W, double fx, double fy, double cx,
+                     double cy, float z_offset, int32_t negate_y, float *normals, void *stream);
+/* Backward of gcfr_normals_fwd: grad_normals (B,3,H,W) f32 -> grad_depth (B,H,W) f32 += (atomics). */
+int gcfr_normals_bwd(const float *grad_normals, const float *depth, int32_t B, int32_t H, int32_t W,
+                     double fx, double fy, double cx, double cy, float z_offset, int32_t negate_y,
+                     float *grad_depth, void *stream);
+
+/*
  * One-call forward for a batch: gcfr_light_prep + depth repack + ray march with the shading fused
  * into the march kernel's epilogue (each lane shades the pixel it just marched; min_dist never
  * makes a round trip through HBM).  Replaces T8:356-522 in one enqueue.  Arguments as in the three

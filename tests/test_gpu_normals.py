@@ -1,0 +1,56 @@
+"""GPU: gcfr_normals_fwd / gcfr_normals_bwd against the oracle's kornia restatement (torch CPU, f64) and
+its autograd.  NB: this stage is parity-UNPINNED with respect to kornia itself (un-vendored dependency)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def camera(f, H, W):
+    K = torch.zeros(1, 3, 3, dtype=torch.float64)
+    K[:, 0, 0] = K[:, 1, 1] = f
+    K[:, 2, 2] = 1.0
+    K[:, 0, 2], K[:, 1, 2] = W / 2.0, H / 2.0
+    return K
+
+
+@pytest.mark.parametrize("H,W,f,off", [(64, 80, 1570.0, 1610.0), (256, 256, 700.0, 1410.0), (31, 17, 300.0, 50.0)])
+def test_normals_forward_and_backward_match_the_restatement(H, W, f, off):
+    from geomconsistentfr_amd.normals import depth_to_normals
+    from normals_restatement import depth_to_normals as oracle_normals
+    rng = np.random.default_rng(H * W)
+    depth = (25 * rng.random((3, 1, H, W))).astype(np.float32)
+    G = rng.standard_normal((3, 3, H, W)).astype(np.float32)
+    K = camera(f, H, W)
+    d_ref = torch.from_numpy(depth).clone().requires_grad_()
+    n_ref = oracle_normals(d_ref + off, K)
+    n_ref = torch.cat([n_ref[:, 0:1], -n_ref[:, 1:2], n_ref[:, 2:3]], 1)
+    (n_ref * torch.from_numpy(G)).sum().backward()
+
+    d = torch.from_numpy(depth).to(DEV).requires_grad_()
+    n = depth_to_normals(d, K.to(DEV), z_offset=off)
+    assert n.dtype == torch.float32 and n.shape == (3, 3, H, W)
+    assert float((n.detach().cpu().double() - n_ref.detach()).abs().max()) <= 2e-6
+    (n * torch.from_numpy(G).to(DEV)).sum().backward()
+    g, g_ref = d.grad.cpu().numpy(), d_ref.grad.numpy()
+    assert np.abs(g - g_ref).max() <= 2e-5 * max(np.abs(g_ref).max(), 1e-6)
+
+
+def test_normals_per_image_camera_matrices():
+    from geomconsistentfr_amd.normals import depth_to_normals
+    rng = np.random.default_rng(1)
+    depth = torch.from_numpy((25 * rng.random((2, 1, 32, 32))).astype(np.float32)).to(DEV)
+    K = torch.cat([camera(1570.0, 32, 32), camera(700.0, 32, 32)]).to(DEV)
+    n = depth_to_normals(depth, K, z_offset=100.0)
+    n0 = depth_to_normals(depth[:1], K[:1], z_offset=100.0)
+    n1 = depth_to_normals(depth[1:], K[1:], z_offset=100.0)
+    assert torch.equal(n, torch.cat([n0, n1]))
+    np.testing.assert_allclose(n.norm(dim=1).cpu().numpy(), 1.0, atol=1e-6)
