@@ -38,6 +38,36 @@ ALGO_BYTES_PER_RAY_STEP = 17.4      # 4 f32 depth corners + 1 u8 m
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+LIGHTS18 = np.array([[.7518, 0, .6594], [.6893, .3991, .6047], [.5145, 0, .8575], [-.5843, 0, .8115],
+                     [-.7574, 0, .6529], [-.7076, .3892, .5897], [-.5151, .4722, .7154], [.4478, .4925, .7463],
+                     [0, .7071, .7071], [-.8138, -.3420, .4698], [.8138, -.3420, .4698],      # 11 from S1:519-562
+                     [.3, .3, .9], [-.3, .3, .9], [.2, -.5, .84], [-.2, -.5, .84], [.9, .1, .42], [-.9, .1, .42],
+                     [0, .2, .98]], np.float32)                                                # 7 synthetic
+
+
+def synth_faces_sized(B, seed0, size, n_lights, mask_kind="ellipse"):
+    """Config-5 style inputs: `size` x `size` faces (surface scaled), `n_lights` lights per face."""
+    r, c = np.mgrid[0:size, 0:size]
+    s = size / 256.0
+    x, y = (c - size / 2.0) / s, (r - size / 2.0) / s
+    depth, mask, albedo, normals = [], [], [], []
+    for i in range(B):
+        rng = np.random.default_rng(seed0 + i)
+        ax, ay, nose = 85 + 10 * rng.random(), 105 + 10 * rng.random(), 30 + 10 * rng.random()
+        d = s * (80 * np.sqrt(np.maximum(1 - (x / ax) ** 2 - (y / ay) ** 2, 0))
+                 + nose * np.exp(-(x ** 2 / 288 + (y - 12) ** 2 / 648)) + 3 * np.sin(x / 7) * np.cos(y / 9))
+        depth.append(d.astype(np.float32))
+        m = (((x / (ax - 8)) ** 2 + (y / (ay - 8)) ** 2) < 1) if mask_kind == "ellipse" else np.ones_like(x, bool)
+        mask.append(m.astype(np.uint8))
+        albedo.append((0.15 + 0.7 * rng.random((3, size, size))).astype(np.float32))
+        gy, gx = np.gradient(d)
+        n = np.stack([-gx, gy, np.ones_like(d)])
+        normals.append((n / np.linalg.norm(n, axis=0)).astype(np.float32))
+    light = np.stack([np.roll(LIGHTS18, seed0 + i, axis=0)[:n_lights] for i in range(B)])
+    amb = np.full((B, n_lights), 0.5, np.float32)
+    return np.stack(depth), np.stack(mask), np.stack(albedo), np.stack(normals), light, amb
+
+
 def synth_faces(B, seed0):
     """Deterministic synthetic faces: jittered ellipsoid + nose + ripple."""
     r, c = np.mgrid[0:H, 0:W]
@@ -107,6 +137,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--direct", action="store_true", help="A/B: direct-gather kernel (no workspace prepass)")
     ap.add_argument("--unfused", action="store_true", help="A/B: three separate entry points instead of gcfr_render_fwd")
+    ap.add_argument("--size", type=int, default=256, help="other workloads: image side (config 5: 512)")
+    ap.add_argument("--lights", type=int, default=1, help="lights per face (config 5: 18)")
+    ap.add_argument("--samples", type=int, default=160, help="march steps (config 5: 320)")
+    ap.add_argument("--mask", choices=["ellipse", "ones"], default="ellipse",
+                    help="'ones' = worst case: no fully masked wave-step exists, nothing is skipped")
     ap.add_argument("--tune", type=str, default="", help="A/B: comma list key=value for gcfr_tune, e.g. 0=32,2=1")
     a = ap.parse_args()
 
@@ -134,9 +169,16 @@ def main():
         for kv in a.tune.split(","):
             k, v = kv.split("=")
             _lib.check(_lib.load().gcfr_tune(int(k), int(v)), "gcfr_tune")
-    prm = RenderParams()
     B = a.faces
-    depth, mask, albedo, normals, light, amb = synth_faces(B, seed0=rank * 1_000_000)
+    headline = (a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse")
+    if headline:
+        prm = RenderParams()
+        depth, mask, albedo, normals, light, amb = synth_faces(B, seed0=rank * 1_000_000)
+    else:
+        prm = RenderParams(n_samples=a.samples, dt=0.8 / a.samples)
+        depth, mask, albedo, normals, light, amb = synth_faces_sized(B, rank * 1_000_000, a.size, a.lights, a.mask)
+    Hh = Ww = a.size
+    Ll, Nn = a.lights, a.samples
     d_depth = torch.from_numpy(depth).to(dev)
     d_mask = torch.from_numpy(mask).to(dev)
     d_albedo = torch.from_numpy(albedo).to(dev)
@@ -164,11 +206,11 @@ def main():
             ev_pairs.append((e0, e1))
         if a.direct or a.unfused:
             _, pt = R.light_prep(d_light, prm)
-            md, _ = R.shadow_min_distance(d_depth, d_mask, pt.reshape(B, 1, 3), prm, want_argmin=False,
+            md, _ = R.shadow_min_distance(d_depth, d_mask, pt.reshape(B, Ll, 3), prm, want_argmin=False,
                                           use_workspace=not a.direct)
-            out = R.shade(d_normals, d_depth, d_albedo, pt.reshape(B, 1, 3), d_amb.reshape(B, 1), md, prm)
+            out = R.shade(d_normals, d_depth, d_albedo, pt.reshape(B, Ll, 3), d_amb.reshape(B, Ll), md, prm)
         else:
-            out = R.render_fwd(d_depth, d_mask, d_light.reshape(B, 1, 3), d_amb.reshape(B, 1), d_normals, d_albedo,
+            out = R.render_fwd(d_depth, d_mask, d_light.reshape(B, Ll, 3), d_amb.reshape(B, Ll), d_normals, d_albedo,
                                prm, want_argmin=False)
         if timed:
             _lib.check(L_.gcfr_profile_events(None, None), "gcfr_profile_events")
@@ -194,7 +236,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    ray_steps_per_step = world * B * H * W * N_SAMPLES
+    ray_steps_per_step = world * B * Ll * Hh * Ww * Nn
     value = ray_steps_per_step * a.steps / elapsed
     def elapsed_ms(e0, e1):
         ms = ctypes.c_float()
@@ -205,7 +247,7 @@ def main():
         shadow_ms = 1e3 * elapsed / a.steps
     else:
         shadow_ms = float(np.mean([elapsed_ms(e0, e1) for e0, e1 in ev_pairs]))
-    algo_bytes = B * H * W * N_SAMPLES * ALGO_BYTES_PER_RAY_STEP          # per launch (one rank)
+    algo_bytes = B * Ll * Hh * Ww * Nn * ALGO_BYTES_PER_RAY_STEP          # per launch (one rank)
     achieved = algo_bytes / (shadow_ms * 1e-3) / 1e9
 
     if rank == 0:
@@ -214,17 +256,20 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: batch=%d synthetic 256x256 faces per GPU, 1 light each, "
-                                   "160 march steps, forward-only shadow+shade" % B,
-                       "faces_per_gpu": B, "H": H, "W": W, "n_samples": N_SAMPLES, "parallelism": "dp%d" % world},
-            "faces_per_sec": world * B * a.steps / elapsed,
+            "config": {"workload": ("BASELINE configs[1]: batch=%d synthetic 256x256 faces per GPU, 1 light each, "
+                                    "160 march steps, forward-only shadow+shade" % B) if headline else
+                                   ("non-headline: batch=%d synthetic %dx%d faces per GPU, %d light(s) each, %d march "
+                                    "steps, mask=%s, forward-only shadow+shade" % (B, Hh, Ww, Ll, Nn, a.mask)),
+                       "faces_per_gpu": B, "H": Hh, "W": Ww, "lights_per_face": Ll, "n_samples": Nn,
+                       "parallelism": "dp%d" % world},
+            "faces_per_sec": world * B * Ll * a.steps / elapsed,
             "ray_steps_per_sec_per_gpu": value / world,
             "roofline": {"bound": "hbm", "kernel": "shadow_fwd_quad_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": shadow_ms,
-                         "kernel_ray_steps_per_sec": B * H * W * N_SAMPLES / (shadow_ms * 1e-3)},
+                         "kernel_ray_steps_per_sec": B * Ll * Hh * Ww * Nn / (shadow_ms * 1e-3)},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:
