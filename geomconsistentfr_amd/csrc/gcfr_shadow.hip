@@ -258,6 +258,7 @@ struct ShadowQuadArgs {
     const float *ambient;   // (B,L)
     float *shadow_w, *full, *final_shading, *rendered;
     float intensity;
+    int32_t ksplit;  // host-side choice, see shadow_fwd_quad_kernel
 };
 
 constexpr double kRintMagic = 6755399441055744.0;  // 2^52 + 2^51
@@ -268,14 +269,23 @@ __device__ inline int lo32(double v)
     return (int)(unsigned)(__builtin_bit_cast(unsigned long long, v) & 0xffffffffull);
 }
 
-template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE>
+// KSPLIT = false: the 4 waves of a workgroup march 4 horizontally adjacent tiles, all N samples each.
+// KSPLIT = true : the 4 waves march the SAME tile, a contiguous quarter of the sample range each, and
+//                 combine their partial minima through LDS (earliest index wins ties, as torch.min).
+//                 Same total work in 4x finer, more uniform pieces: used for small batches, where a few
+//                 heavy (fully unmasked) tiles otherwise leave the SIMDs idle at the tail of the launch.
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool KSPLIT>
 __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
 {
     constexpr int TILE_H = 64 / TILE_W;
-    constexpr int WAVES = 4;
-    const int H = a.H, W = a.W, N = a.N, L = a.L;
+    constexpr int WAVES = KSPLIT ? 1 : 4;  // tiles per workgroup along x
+    const int H = a.H, W = a.W, L = a.L;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // sample range of this wave
+    const int chunk = KSPLIT ? (a.N + 3) >> 2 : a.N;
+    const int k_lo = KSPLIT ? wave * chunk : 0;
+    const int N = KSPLIT ? min(a.N, k_lo + chunk) : a.N;  // exclusive upper bound ("N" below)
 
     // blockIdx -> (image, light, tile quad), image-major.  An XCD-affine remap (all blocks of an image
     // on one XCD) was measured 12 % SLOWER at B=8 -- one image per XCD makes the slowest image set the
@@ -289,7 +299,7 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
     const int qy = q / a.quads_x, qx = q - qy * a.quads_x;
 
     int r = qy * TILE_H + lane / TILE_W;
-    int c = (qx * WAVES + wave) * TILE_W + (lane % TILE_W);
+    int c = (qx * WAVES + (KSPLIT ? 0 : wave)) * TILE_W + (lane % TILE_W);
     const bool valid = (r < H) && (c < W);
     r = valid ? r : H - 1;
     c = valid ? c : W - 1;
@@ -355,14 +365,16 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
     // (first) argmin, so the tail needs no branch.
     auto clampk = [&](int k) { return k < N ? k : N - 1; };
     uint32_t ring[DEPTH];
+    if (k_lo < N) {
 #pragma unroll
-    for (int j = 0; j < DEPTH; ++j) {
-        double px, py;
-        sample_pos(clampk(j), px, py);
-        ring[j] = buf_load_u8(mr, mask_offset(px, py));
+        for (int j = 0; j < DEPTH; ++j) {
+            double px, py;
+            sample_pos(clampk(k_lo + j), px, py);
+            ring[j] = buf_load_u8(mr, mask_offset(px, py));
+        }
     }
 
-    for (int k0 = 0; k0 < N; k0 += DEPTH) {
+    for (int k0 = k_lo; k0 < N; k0 += DEPTH) {
         uint32_t mk[DEPTH];
         bool none = true;
 #pragma unroll
@@ -416,6 +428,26 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
             bestS = take ? S : bestS;
             if (WANT_ARGMIN)
                 besti = take ? k : besti;
+        }
+    }
+
+    if (KSPLIT) {  // combine the four sample-range quarters of this tile
+        __shared__ float sS[4][64];
+        __shared__ int sK[4][64];
+        __shared__ uint8_t sM[4][64];
+        sS[wave][lane] = bestS;
+        sK[wave][lane] = besti;
+        sM[wave][lane] = any_masked ? 1 : 0;
+        __syncthreads();
+        if (wave != 0)
+            return;
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float Sq = sS[q][lane];
+            const bool take = Sq < bestS;  // strict: the earlier quarter keeps ties (first minimum, T8:514)
+            bestS = take ? Sq : bestS;
+            besti = take ? sK[q][lane] : besti;
+            any_masked |= (sM[q][lane] != 0);
         }
     }
 
@@ -497,6 +529,7 @@ extern "C" int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_
 //   are 25 % slower (vector-memory bound).
 static int g_tile_w = 32;  // pixels per tile row: 8, 16, 32 or 64 (tile = 64/tile_w rows)
 static int g_depth = 4;    // samples per group (skip granularity / gathers in flight): 1, 2 or 4
+static int g_ksplit = -1;  // sample-range split over the 4 waves of a workgroup: 0 off, 1 on, -1 auto
 
 extern "C" int gcfr_tune(int32_t key, int32_t value)
 {
@@ -510,6 +543,11 @@ extern "C" int gcfr_tune(int32_t key, int32_t value)
         if (value != 1 && value != 2 && value != 4)
             return GCFR_ERR_INVALID_ARGUMENT;
         g_depth = value;
+        return GCFR_OK;
+    case 2:
+        if (value < -1 || value > 1)
+            return GCFR_ERR_INVALID_ARGUMENT;
+        g_ksplit = value;
         return GCFR_OK;
     default:
         return GCFR_ERR_INVALID_ARGUMENT;
@@ -533,12 +571,13 @@ extern "C" int gcfr_profile_events(void *start, void *stop)
     return GCFR_OK;
 }
 
-template <int TILE_W, int DEPTH, bool FUSE>
-static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
+template <int TILE_W, int DEPTH, bool FUSE, bool KSPLIT>
+static void launch_quad5(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
                          hipStream_t st)
 {
 #define GCFR_LAUNCH(E, A) \
-    hipLaunchKernelGGL((shadow_fwd_quad_kernel<TILE_W, E, A, DEPTH, FUSE>), dim3(blocks), dim3(256), 0, st, a)
+    hipLaunchKernelGGL((shadow_fwd_quad_kernel<TILE_W, E, A, DEPTH, FUSE, KSPLIT>), dim3(blocks), dim3(256), 0, \
+                       st, a)
     if (even_half) {
         if (want_argmin)
             GCFR_LAUNCH(true, true);
@@ -551,6 +590,16 @@ static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argm
             GCFR_LAUNCH(false, false);
     }
 #undef GCFR_LAUNCH
+}
+
+template <int TILE_W, int DEPTH, bool FUSE>
+static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
+                         hipStream_t st)
+{
+    if (a.ksplit)
+        launch_quad5<TILE_W, DEPTH, FUSE, true>(a, even_half, want_argmin, blocks, st);
+    else
+        launch_quad5<TILE_W, DEPTH, FUSE, false>(a, even_half, want_argmin, blocks, st);
 }
 
 template <int TILE_W, int DEPTH>
@@ -634,8 +683,16 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         a.H = H;
         a.W = W;
         a.N = N;
-        a.quads_x = quads_x;
-        a.quads_per_image = quads_per_image;
+        // small launches: split every tile's sample range over the 4 waves of its workgroup (finer, more
+        // uniform work items); large launches keep one tile per wave (less per-pixel prologue work).
+        const long long tiles_total = (long long)B * L * tiles_x * ((H + TILE_H - 1) / TILE_H);
+        const bool ksplit = (g_ksplit < 0) ? (tiles_total <= 4096 && N >= 16) : (g_ksplit == 1);  // measured: helps B<=4 at 256^2
+        a.ksplit = ksplit ? 1 : 0;
+        a.quads_x = ksplit ? tiles_x : quads_x;
+        a.quads_per_image = a.quads_x * ((H + TILE_H - 1) / TILE_H);
+        const long long qblocks = (long long)B * L * a.quads_per_image;
+        if (qblocks > 0x7fffffffLL)
+            return GCFR_ERR_INVALID_ARGUMENT;
         a.bonus = bonus;
         a.bx_lo = bx[0];
         a.bx_hi = bx[1];
@@ -653,16 +710,16 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         const bool want = argmin != nullptr;
         switch (TILE_W) {
         case 8:
-            launch_quad<8>(a, even_half, want, (unsigned)blocks, st);
+            launch_quad<8>(a, even_half, want, (unsigned)qblocks, st);
             break;
         case 32:
-            launch_quad<32>(a, even_half, want, (unsigned)blocks, st);
+            launch_quad<32>(a, even_half, want, (unsigned)qblocks, st);
             break;
         case 64:
-            launch_quad<64>(a, even_half, want, (unsigned)blocks, st);
+            launch_quad<64>(a, even_half, want, (unsigned)qblocks, st);
             break;
         default:
-            launch_quad<16>(a, even_half, want, (unsigned)blocks, st);
+            launch_quad<16>(a, even_half, want, (unsigned)qblocks, st);
             break;
         }
         return launch_status();

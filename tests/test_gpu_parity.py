@@ -196,3 +196,28 @@ def test_workspace_kernel_is_bit_identical_to_direct_kernel(Hs, Ws, N):
     assert torch.equal(a_am, b_am)
     c_md, c_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, want_argmin=False, use_workspace=True)
     assert c_am is None and torch.equal(c_md, a_md)
+
+
+@pytest.mark.parametrize("N", [160, 37, 5, 2])
+def test_sample_range_split_is_bit_identical(N):
+    """The k-split variant (4 waves share a tile, a quarter of the samples each, LDS combine) against the
+    one-tile-per-wave variant and the direct kernel: same bits, same argmin (ties -> earliest index)."""
+    from geomconsistentfr_amd import RenderParams, shadow_min_distance, light_prep, _lib
+    L_ = _lib.load()
+    rng = np.random.default_rng(N)
+    B, Hs, Ws = 3, 66, 130
+    depth = (40 * rng.random((B, Hs, Ws))).astype(np.float32)
+    depth[1] = 7.0                                      # flat depth -> many exact ties between samples
+    mask = (rng.random((B, Hs, Ws)) > 0.3).astype(np.uint8)
+    lights = rng.standard_normal((B, 2, 3)).astype(np.float32)
+    prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
+    _, pt = light_prep(to_dev(lights), prm)
+    ref_md, ref_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=False)
+    try:
+        for ks in (0, 1):
+            assert L_.gcfr_tune(2, ks) == 0
+            md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True)
+            assert torch.equal(md, ref_md), ks
+            assert torch.equal(am, ref_am), ks
+    finally:
+        L_.gcfr_tune(2, -1)
