@@ -191,7 +191,8 @@ def main():
     import ctypes
     from geomconsistentfr_amd import _lib
     L_ = _lib.load()
-    hip = ctypes.CDLL("libamdhip64.so")
+    # the exact file torch loaded (same inode -> the same runtime instance, never a second HIP runtime)
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
     ev_pairs = []
 
     def new_event():

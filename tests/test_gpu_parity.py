@@ -221,3 +221,53 @@ def test_sample_range_split_is_bit_identical(N):
             assert torch.equal(am, ref_am), ks
     finally:
         L_.gcfr_tune(2, -1)
+
+
+def _compact_masks(Hs, Ws):
+    r, c = np.mgrid[0:Hs, 0:Ws]
+    masks = {
+        "ellipse": ((((c - 0.55 * Ws) / (0.3 * Ws)) ** 2 + ((r - 0.45 * Hs) / (0.35 * Hs)) ** 2) < 1),
+        "small_rect": (r >= 10) & (r < 14) & (c >= Ws - 9) & (c < Ws - 3),
+        "single_pixel": (r == Hs // 3) & (c == Ws // 4),
+        "empty": np.zeros((Hs, Ws), bool),
+        "border_rows": (r < 2) | (r >= Hs - 1),
+        "left_column": (c == 0),
+        "two_blobs": ((((c - 12) ** 2 + (r - 12) ** 2) < 30) | (((c - Ws + 10) ** 2 + (r - Hs + 14) ** 2) < 40)),
+    }
+    return {k: v.astype(np.uint8) for k, v in masks.items()}
+
+
+@pytest.mark.parametrize("Hs,Ws,N", [(96, 128, 160), (130, 70, 37), (256, 256, 160)])
+def test_mask_bounding_box_pruning_is_exact(Hs, Ws, N):
+    """Compact / degenerate masks: the workspace kernel bounds each wave's sample loop by the mask's bounding
+    box; values and argmin must stay bit-identical to the direct kernel, with and without k-split."""
+    from geomconsistentfr_amd import RenderParams, shadow_min_distance, light_prep, _lib
+    L_ = _lib.load()
+    rng = np.random.default_rng(Hs + Ws + N)
+    masks = _compact_masks(Hs, Ws)
+    B = len(masks)
+    mask = np.stack(list(masks.values()))
+    r, c = np.mgrid[0:Hs, 0:Ws]
+    depth = np.stack([(0.3 * Hs * np.exp(-(((c - 0.5 * Ws) / (0.25 * Ws)) ** 2 + ((r - 0.5 * Hs) / (0.3 * Hs)) ** 2))
+                       + rng.random((Hs, Ws))).astype(np.float32) for _ in range(B)])
+    lights = np.array([[0.3, 0.5, 0.8], [-0.9, 0.1, 0.2], [0.001, -0.002, 1.0], [0.7, -0.7, 0.05], [0.0, 0.9, 0.1],
+                       [0.9, 0.0, 0.1]], np.float32)
+    lights = np.stack([np.roll(lights, b, axis=0)[:3] for b in range(B)])                  # (B,3,3)
+    prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
+    _, pt = light_prep(to_dev(lights), prm)
+    ref_md, ref_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=False)
+    try:
+        for ks in (0, 1):
+            assert L_.gcfr_tune(2, ks) == 0
+            md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True)
+            bad = (md != ref_md).nonzero()
+            assert torch.equal(md, ref_md), (ks, bad[:5].tolist())
+            assert torch.equal(am, ref_am), ks
+    finally:
+        L_.gcfr_tune(2, -1)
+    empty = list(masks).index("empty")
+    assert torch.all(ref_md[empty] == 1e6)
+    # one mask shared by the whole batch (S1 form): bounding box of mask 0 applies to every image
+    md1, am1 = shadow_min_distance(to_dev(depth), to_dev(mask[:1]), pt, prm, use_workspace=True)
+    md1r, am1r = shadow_min_distance(to_dev(depth), to_dev(mask[:1]), pt, prm, use_workspace=False)
+    assert torch.equal(md1, md1r) and torch.equal(am1, am1r)
