@@ -271,3 +271,46 @@ def test_mask_bounding_box_pruning_is_exact(Hs, Ws, N):
     md1, am1 = shadow_min_distance(to_dev(depth), to_dev(mask[:1]), pt, prm, use_workspace=True)
     md1r, am1r = shadow_min_distance(to_dev(depth), to_dev(mask[:1]), pt, prm, use_workspace=False)
     assert torch.equal(md1, md1r) and torch.equal(am1, am1r)
+
+
+def test_non_finite_inputs_do_not_fault_and_stay_local():
+    """NaN / inf depth and degenerate lights: no GPU fault (raw buffer range checks), finite pixels elsewhere
+    unaffected where the reference's data flow says so, NaN light -> NaN outputs (visible, not silent)."""
+    from geomconsistentfr_amd import RenderParams, shadow_min_distance, light_prep
+    prm = RenderParams()
+    rng = np.random.default_rng(3)
+    Hs = Ws = 128
+    depth = (20 * rng.random((3, Hs, Ws))).astype(np.float32)
+    mask = np.ones((3, Hs, Ws), np.uint8)
+    clean = depth.copy()
+    depth[0, 40, 50] = np.nan
+    depth[1, 10:12, 100] = np.inf
+    lights = np.array([[0.3, 0.5, 0.8], [0.0, 0.0, 0.0], [np.nan, 0.2, 0.5]], np.float32)
+    unit, pt = light_prep(to_dev(lights), prm)
+    assert torch.all(unit[1] == 0) and torch.all(pt[1] == 0)             # normalize(0) = 0 (SLT pass 1, SLT:543)
+    md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt.reshape(3, 1, 3), prm)
+    torch.cuda.synchronize()
+    md_clean, _ = shadow_min_distance(to_dev(clean), to_dev(mask), pt.reshape(3, 1, 3), prm)
+    md, md_clean = md.cpu().numpy(), md_clean.cpu().numpy()
+    # image 0: only rays that sample the NaN texel (or start on it) can differ; far-away pixels are untouched
+    same = (md[0, 0] == md_clean[0, 0])
+    assert same.mean() > 0.9 and np.isnan(md[0, 0]).sum() <= (~same).sum()
+    assert np.isfinite(md[1, 0]).mean() > 0.9
+    assert np.isnan(md[2, 0]).all()                                       # NaN light poisons its own image only
+    assert np.isfinite(md_clean[:2]).all()
+
+
+def test_python_boundary_rejects_bad_shapes():
+    from geomconsistentfr_amd import RenderParams, render, shadow_min_distance
+    from geomconsistentfr_amd._lib import GcfrError
+    d = torch.zeros(2, 1, 64, 64, device="cuda:0")
+    with pytest.raises((GcfrError, RuntimeError, ValueError)):
+        render(d, torch.zeros(2, 3, 64, 64, device="cuda:0"), torch.zeros(3, 3, device="cuda:0"),
+               torch.zeros(2, device="cuda:0"), torch.zeros(2, 3, 64, 64, device="cuda:0"),
+               torch.ones(2, 64, 64, device="cuda:0"))
+    with pytest.raises(GcfrError):                                        # odd width is outside the supported set
+        shadow_min_distance(torch.zeros(1, 64, 63, device="cuda:0"), torch.ones(1, 64, 63, device="cuda:0"),
+                            torch.ones(1, 1, 3, device="cuda:0"), RenderParams())
+    with pytest.raises(GcfrError):                                        # mask batch must be 1 or B
+        shadow_min_distance(torch.zeros(3, 64, 64, device="cuda:0"), torch.ones(2, 64, 64, device="cuda:0"),
+                            torch.ones(3, 1, 3, device="cuda:0"), RenderParams())

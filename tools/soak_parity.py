@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Randomised parity soak (GPU box): many random (depth, mask, light) cases, HIP workspace kernel vs the C
+oracle.  Reports the worst min-distance error over unmasked pixels and the argmin agreement.  Evidence for
+the 'decision parity' claims (magic-number rint, quad texels, skip, bounding-box pruning, k-split)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import c_oracle  # noqa: E402
+from geomconsistentfr_amd import RenderParams, light_prep, shadow_min_distance  # noqa: E402
+
+
+def random_case(rng, H, W):
+    r, c = np.mgrid[0:H, 0:W]
+    kind = rng.integers(0, 4)
+    depth = (0.3 * H * np.exp(-(((c - rng.uniform(0.3, 0.7) * W) / (0.25 * W)) ** 2
+                                + ((r - rng.uniform(0.3, 0.7) * H) / (0.3 * H)) ** 2))).astype(np.float32)
+    if kind == 0:
+        depth += rng.random((H, W), dtype=np.float32)
+    elif kind == 1:
+        depth += (3 * np.sin(c / rng.uniform(3, 9)) * np.cos(r / rng.uniform(3, 9))).astype(np.float32)
+    elif kind == 2:
+        depth = np.round(depth)                       # plateaus -> exact ties between samples
+    mk = rng.integers(0, 4)
+    if mk == 0:
+        mask = rng.random((H, W)) > rng.uniform(0.05, 0.6)
+    elif mk == 1:
+        mask = (((c - rng.uniform(0.3, 0.7) * W) / (rng.uniform(0.1, 0.45) * W)) ** 2
+                + ((r - rng.uniform(0.3, 0.7) * H) / (rng.uniform(0.1, 0.45) * H)) ** 2) < 1
+    elif mk == 2:
+        r0, c0 = rng.integers(0, H - 4), rng.integers(0, W - 4)
+        mask = (r >= r0) & (r < r0 + rng.integers(1, H - r0)) & (c >= c0) & (c < c0 + rng.integers(1, W - c0))
+    else:
+        mask = np.ones((H, W), bool)
+    l = rng.standard_normal(3)
+    if rng.random() < 0.25:
+        l[:2] *= 0.01                                 # light nearly on the optical axis (mid/mid branch)
+    if rng.random() < 0.15:
+        l[rng.integers(0, 2)] = 0.0                   # axis-aligned rays: the -1 wrap column / row
+    return depth, mask.astype(np.uint8), l.astype(np.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=240)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    dev = torch.device("cuda:0")
+    sizes = [(64, 64, 48), (96, 128, 80), (130, 70, 37), (128, 128, 160), (256, 256, 160)]
+    worst = {"abs": 0.0, "rel": 0.0}
+    n_pix = n_arg_diff = n_lit_mismatch = 0
+    t0 = time.time()
+    B = 8
+    for it in range(a.cases // B):
+        H, W, N = sizes[it % len(sizes)]
+        cases = [random_case(rng, H, W) for _ in range(B)]
+        depth = np.stack([c[0] for c in cases])
+        mask = np.stack([c[1] for c in cases])
+        lights = np.stack([c[2] for c in cases])
+        prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
+        _, pt = light_prep(torch.from_numpy(lights).to(dev), prm)
+        md, am = shadow_min_distance(torch.from_numpy(depth).to(dev), torch.from_numpy(mask).to(dev),
+                                     pt.reshape(B, 1, 3), prm)
+        _, pt_o = c_oracle.light_prep(lights, clamp_z_min=0.0)
+        md_o, am_o = c_oracle.shadow_min_distance(depth, mask, pt_o[:, None, :], c_oracle.sample_table(0.025, 0.8 / N, N))
+        md, am = md.cpu().numpy(), am.cpu().numpy()
+        lit_o, lit = md_o < 1e5, md < 1e5
+        n_lit_mismatch += int((lit_o != lit).sum())
+        both = lit & lit_o
+        err = np.abs(md[both] - md_o[both])
+        if err.size:
+            worst["abs"] = max(worst["abs"], float(err.max()))
+            worst["rel"] = max(worst["rel"], float((err / np.maximum(np.abs(md_o[both]), 1.0)).max()))
+        n_pix += int(both.sum())
+        n_arg_diff += int((am[both] != am_o[both]).sum())
+    out = {"cases": (a.cases // B) * B, "pixels_compared": n_pix, "lit_mask_mismatches": n_lit_mismatch,
+           "max_abs_err_min_dist": worst["abs"], "max_rel_err_min_dist": worst["rel"],
+           "argmin_differences": n_arg_diff, "argmin_difference_rate": n_arg_diff / max(n_pix, 1),
+           "seconds": time.time() - t0}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
