@@ -1,0 +1,96 @@
+"""Callers of the render block on the inference side, as functions.
+
+The reference's three test scripts are `main()` bodies with hard-coded paths; what they DO with the model is:
+
+  relight_single_image    test_relight_single_image.py:569-620 (S1) -- one image, one target light, composite
+  relight_batch           test_raytracing_relighting_CelebAHQ_DSSIM_8x.py:552-608 (S8) -- many (image, light) pairs
+  lighting_transfer       test_relight_single_image_lighting_transfer.py:527-579 (SLT) -- two passes: estimate the
+                          reference image's light, relight the input with it
+
+The reference runs one image per forward (batch_size = 1 hard-coded); here a whole batch goes through one forward.
+Light directions the reference ships in source (S1:519-562) are exposed as LIGHT_DIRECTIONS.
+"""
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import postprocess as pp
+from .relightnet import RelightNetLightingTransfer, RelightNetSingleImage
+
+# name -> (x, y, z), test_relight_single_image.py:519-562
+LIGHT_DIRECTIONS: Dict[str, tuple] = {
+    "multipie_04": (0.7518, 0.0, 0.6594),
+    "multipie_14": (0.6893, 0.3991, 0.6047),
+    "multipie_05": (0.5145, 0.0, 0.8575),
+    "multipie_09": (-0.5843, 0.0, 0.8115),
+    "multipie_10": (-0.7574, 0.0, 0.6529),
+    "multipie_18": (-0.7076, 0.3892, 0.5897),
+    "multipie_17": (-0.5151, 0.4722, 0.7154),
+    "multipie_15": (0.4478, 0.4925, 0.7463),
+    "top_A00E45": (0.0, 0.7071, 0.7071),
+    "bottom_left_A60E-20": (-0.8138, -0.3420, 0.4698),
+    "bottom_right_A-60E-20": (0.8138, -0.3420, 0.4698),
+}
+
+
+def camera_matrix(focal: float, H: int = 256, W: int = 256, device="cpu") -> torch.Tensor:
+    """(1,3,3) float64 intrinsics as built at S1:566-572 (focal 1570) / SLT:528-534 (focal 700)."""
+    K = torch.zeros(1, 3, 3, dtype=torch.float64)
+    K[:, 0, 0] = K[:, 1, 1] = focal
+    K[:, 2, 2] = 1.0
+    K[:, 0, 2], K[:, 1, 2] = W / 2.0, H / 2.0
+    return K.to(device)
+
+
+def _as_batch(images) -> torch.Tensor:
+    x = torch.as_tensor(np.asarray(images), dtype=torch.float32)
+    return x[None] if x.dim() == 3 else x
+
+
+@torch.no_grad()
+def relight_batch(model: RelightNetSingleImage, images, masks_u8, lights, ambient: float = 0.5,
+                  focal: float = 1570.0, device="cuda", epoch: int = 200):
+    """images (B,H,W,3) float [0,1]; masks_u8 (H,W) shared skin mask (the S1/S8 model takes ONE mask per
+    forward, S1:488) ; lights (B,3) target directions.  The lighting head's first output is the ambient the
+    model uses (plus the model's ambient_offset); `ambient` only feeds the unused target argument, as in S1:588.
+    Returns the model's 10-tuple (device tensors)."""
+    x = _as_batch(images).to(device)
+    B, H, W, _ = x.shape
+    mask = torch.as_tensor(np.asarray(masks_u8), dtype=torch.float64).reshape(H, W, 1) / 255.0     # S1:580
+    tl = torch.as_tensor(np.asarray(lights), dtype=torch.float32).reshape(B, 3, 1, 1).to(device)
+    ta = torch.full((B, 1, 1), float(ambient), dtype=torch.float32, device=device)
+    return model(x, epoch, camera_matrix(focal, H, W, device), mask.to(device), tl, ta, mask[None].to(device))
+
+
+@torch.no_grad()
+def relight_single_image(model: RelightNetSingleImage, image, mask_u8, light, ambient: float = 0.5,
+                         focal: float = 1570.0, device="cuda") -> np.ndarray:
+    """S1:569-620 for one image: returns the composite (H,W,3) uint8 RGB (rendered face pasted into the input)."""
+    out = relight_batch(model, image, mask_u8, np.asarray(light, np.float32)[None], ambient, focal, device)
+    comp = pp.composite_into_input(np.asarray(image, np.float64), out[5][0].cpu().numpy(),
+                                   np.asarray(mask_u8, np.float64) / 255.0)
+    return pp.to_uint8(comp)
+
+
+@torch.no_grad()
+def lighting_transfer(model: RelightNetLightingTransfer, input_image, reference_image, mask_u8,
+                      focal: float = 700.0, device="cuda") -> Dict[str, np.ndarray]:
+    """SLT:535-579: pass 1 on the reference image with a zero target light reads the estimated light and ambient
+    (SLT:543); pass 2 relights the input image with them (SLT:545).  Returns the six images SLT:574-579 writes
+    (float [0,255]) plus the estimated light."""
+    xin, xref = _as_batch(input_image).to(device), _as_batch(reference_image).to(device)
+    _, H, W, _ = xin.shape
+    K = camera_matrix(focal, H, W, device)
+    mask = (torch.as_tensor(np.asarray(mask_u8), dtype=torch.float64).reshape(H, W, 1) / 255.0).to(device)
+    zero_l = torch.zeros(1, 3, 1, 1, device=device)
+    zero_a = torch.zeros(1, 1, 1, device=device)
+    est = model(xref, 200, K, mask, zero_l, zero_a)
+    est_light, est_amb = est[10], est[11]
+    out = model(xin, 200, K, mask, est_light.reshape(1, 3, 1, 1).float(), est_amb.reshape(1, 1, 1).float())
+    imgs = pp.diagnostic_images(np.asarray(input_image, np.float64), out[0][0].cpu().numpy(), out[1].cpu().numpy(), 0,
+                                out[2][0].cpu().numpy(), out[5][0].cpu().numpy(), out[8][0].cpu().numpy(),
+                                out[9][0].cpu().numpy(), np.asarray(mask_u8, np.float64) / 255.0)
+    imgs["estimated_light"] = est_light.reshape(3).cpu().numpy()
+    imgs["estimated_ambient"] = est_amb.reshape(1).cpu().numpy()
+    return imgs

@@ -116,7 +116,7 @@ def test_trainer_steps_run_and_update_parameters():
     """Full training step (T8:617-656) around the HIP block on one GPU, batch 4, two iterations."""
     from geomconsistentfr_amd.train import TrainConfig, Trainer, synthetic_batch
     torch.manual_seed(0)
-    tr = Trainer(TrainConfig(), device=DEV)
+    tr = Trainer(TrainConfig(miopen_find=False), device=DEV)      # find mode costs ~50 s of tuning on first use
     before = torch.cat([p.detach().flatten().clone() for p in tr.model.parameters()])
     d_before = torch.cat([p.detach().flatten().clone() for p in tr.patchgan.parameters()])
     batch = synthetic_batch(4, 0, device=DEV)
@@ -129,3 +129,44 @@ def test_trainer_steps_run_and_update_parameters():
     d_after = torch.cat([p.detach().flatten() for p in tr.patchgan.parameters()])
     assert not torch.equal(before, after) and not torch.equal(d_before, d_after)
     assert torch.isfinite(after).all()
+
+
+def test_inference_helpers_follow_the_scripts():
+    """relight_single_image / relight_batch / lighting_transfer == the manual S1 / SLT call sequences."""
+    from geomconsistentfr_amd import postprocess as pp
+    from geomconsistentfr_amd.inference import (LIGHT_DIRECTIONS, camera_matrix, lighting_transfer, relight_batch,
+                                                relight_single_image)
+    from geomconsistentfr_amd.relightnet import RelightNetLightingTransfer, RelightNetSingleImage
+    assert len(LIGHT_DIRECTIONS) == 11
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+    img = rng.random((H, W, 3)).astype(np.float32)
+    ref = rng.random((H, W, 3)).astype(np.float32)
+    r, c = np.mgrid[0:H, 0:W]
+    mask = np.where((((c - 128) / 80.0) ** 2 + ((r - 128) / 100.0) ** 2) < 1, 255, 0).astype(np.uint8)
+    mask[100:110, 100:110] = 64                                              # the shipped masks have 4 grey levels
+
+    s1 = RelightNetSingleImage().to(DEV).eval()
+    light = LIGHT_DIRECTIONS["top_A00E45"]
+    comp = relight_single_image(s1, img, mask, light, device=DEV)
+    assert comp.dtype == np.uint8 and comp.shape == (H, W, 3)
+    with torch.no_grad():                                                    # the manual sequence of S1:582-620
+        m = torch.from_numpy(mask.astype(np.float64)).reshape(H, W, 1).to(DEV) / 255.0
+        out = s1(torch.from_numpy(img)[None].to(DEV), 200, camera_matrix(1570.0, H, W, DEV), m,
+                 torch.tensor(light, dtype=torch.float32, device=DEV).view(1, 3, 1, 1),
+                 torch.full((1, 1, 1), 0.5, device=DEV), m[None])
+    exp = pp.to_uint8(pp.composite_into_input(img.astype(np.float64), out[5][0].cpu().numpy(), mask / 255.0))
+    assert np.abs(comp.astype(int) - exp.astype(int)).max() <= 1      # two forwards: MIOpen may pick different conv paths
+    np.testing.assert_array_equal(comp[mask == 0], pp.to_uint8(img.astype(np.float64) * 255.0)[mask == 0])
+
+    lights = np.array([LIGHT_DIRECTIONS[k] for k in ("multipie_04", "multipie_18", "bottom_left_A60E-20")], np.float32)
+    outs = relight_batch(s1, np.stack([img, ref, img]), mask, lights, device=DEV)
+    assert len(outs) == 10 and tuple(outs[5].shape) == (3, 3, H, W)
+    single = relight_batch(s1, img[None], mask, lights[:1], device=DEV)
+    assert float((outs[2][0] - single[2][0]).abs().max()) <= 1e-5           # batch item == single forward (eval BN)
+
+    slt = RelightNetLightingTransfer().to(DEV).eval()
+    res = lighting_transfer(slt, img, ref, mask, device=DEV)
+    assert {"rendered_image", "shadow_mask", "albedo", "depth", "shading", "surface_normals", "estimated_light",
+            "estimated_ambient"} <= set(res)
+    assert abs(float(np.linalg.norm(res["estimated_light"])) - 1.0) < 1e-5 and res["estimated_light"][2] > 0
