@@ -133,6 +133,15 @@ def generator_losses(out, batch, logits_fake_for_g) -> Dict[str, torch.Tensor]:
     return L
 
 
+def discriminator_losses(disc: nn.Module, fake: torch.Tensor, real: torch.Tensor):
+    """T8:619-623: two separate forwards (batch-stat BatchNorm sees fake and real separately), BCE x0.01 each."""
+    lf = disc(fake)
+    lr_ = disc(real)
+    d_fake = 0.01 * F.binary_cross_entropy_with_logits(lf, torch.zeros_like(lf))
+    d_real = 0.01 * F.binary_cross_entropy_with_logits(lr_, torch.ones_like(lr_))
+    return d_fake, d_real
+
+
 @dataclass
 class TrainConfig:
     lr: float = 1e-4            # T8:44
@@ -159,8 +168,13 @@ class Trainer:
         if distributed:
             from torch.nn.parallel import DistributedDataParallel as DDP
             ids = [self.device.index] if self.device.type == "cuda" else None
-            self.net = DDP(self.model, device_ids=ids, bucket_cap_mb=cfg.bucket_cap_mb, gradient_as_bucket_view=True)
-            self.disc = DDP(self.patchgan, device_ids=ids, bucket_cap_mb=cfg.bucket_cap_mb, gradient_as_bucket_view=True)
+            # broadcast_buffers=False: BatchNorm running statistics stay per GPU (module docstring), and the
+            # discriminator runs two forwards (fake, real) before one backward -- DDP's per-forward buffer
+            # broadcast would overwrite BN buffers in place between them and break autograd's version check.
+            kw = dict(device_ids=ids, bucket_cap_mb=cfg.bucket_cap_mb, gradient_as_bucket_view=True,
+                      broadcast_buffers=False)
+            self.net = DDP(self.model, **kw)
+            self.disc = DDP(self.patchgan, **kw)
         self.opt = torch.optim.Adam(self.model.parameters(), lr=cfg.lr)                  # T8:589
         self.opt_d = torch.optim.Adam(self.patchgan.parameters(), lr=cfg.lr)             # T8:590
         K = torch.zeros(1, 3, 3, dtype=torch.float64)
@@ -180,10 +194,7 @@ class Trainer:
         # ---- discriminator (T8:617-629) ----
         if j % self.cfg.gd_ratio == 0:
             self.opt_d.zero_grad(set_to_none=True)
-            lf = self.disc(composite.detach())
-            lr_ = self.disc(img)
-            d_fake = 0.01 * F.binary_cross_entropy_with_logits(lf, torch.zeros_like(lf))
-            d_real = 0.01 * F.binary_cross_entropy_with_logits(lr_, torch.ones_like(lr_))
+            d_fake, d_real = discriminator_losses(self.disc, composite.detach(), img)
             (d_fake + d_real).backward()
             self.opt_d.step()
             if log:

@@ -117,6 +117,51 @@ def _ddp_worker_body(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _ddp_disc_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from geomconsistentfr_amd.relightnet import PatchGAN
+        from geomconsistentfr_amd.train import discriminator_losses
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.set_num_threads(2)
+        torch.manual_seed(7)
+        disc = PatchGAN()
+        ddp = DDP(disc, bucket_cap_mb=32, gradient_as_bucket_view=True, broadcast_buffers=False)
+        g = torch.Generator().manual_seed(100 + rank)
+        fake, real = torch.rand(1, 3, 64, 64, generator=g), torch.rand(1, 3, 64, 64, generator=g)
+        d_fake, d_real = discriminator_losses(ddp, fake, real)          # two forwards, then ONE backward (T8:619-625)
+        (d_fake + d_real).backward()
+        grad = torch.cat([p.grad.flatten() for p in disc.parameters()])
+        gathered = [torch.zeros_like(grad) for _ in range(world)]
+        dist.all_gather(gathered, grad)
+        q.put((rank, float((gathered[0] - gathered[1]).abs().max()), float(grad.abs().max()), grad.numel()))
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, "error: %r" % (e,), 0.0, 0))
+        raise
+
+
+def test_gloo_world2_discriminator_step_two_forwards_one_backward():
+    """Regression: DDP's default per-forward buffer broadcast breaks the D step (two forwards before one backward);
+    Trainer wraps with broadcast_buffers=False.  After backward every rank holds the same averaged gradient."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_disc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    assert all(not isinstance(r[1], str) for r in res), res
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, diff, scale, n in res:
+        assert n == 2_766_529 and scale > 0 and diff == 0.0
+
+
 def test_gloo_world2_gradient_allreduce_matches_mean_of_shards():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

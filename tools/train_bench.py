@@ -22,15 +22,24 @@ def main():
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--grep", type=str, default="", help="with --profile: only rows whose name contains this")
+    ap.add_argument("--ddp", action="store_true", help="wrap in DistributedDataParallel over RCCL (launch with torchrun)")
     a = ap.parse_args()
-    dev = "cuda:0"
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = "cuda:%d" % local_rank
+    torch.cuda.set_device(local_rank)
+    if a.ddp:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
     if a.miopen_find:
         torch.backends.cudnn.benchmark = True
-    tr = Trainer(TrainConfig(), device=dev)
+    tr = Trainer(TrainConfig(miopen_find=a.miopen_find), device=dev, distributed=a.ddp)
     if a.channels_last:
         tr.model.to(memory_format=torch.channels_last)
         tr.patchgan.to(memory_format=torch.channels_last)
-    batch = synthetic_batch(a.batch, 0, device=dev)
+    batch = synthetic_batch(a.batch, rank * 1_000_000, device=dev)      # whole faces per rank, seed = rank*1e6 + index
     for j in range(a.warmup):
         tr.step(batch, 200, j, log=False)
     torch.cuda.synchronize()
@@ -39,9 +48,13 @@ def main():
         tr.step(batch, 200, j, log=False)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / a.steps
-    print(json.dumps({"workload": "train step, batch %d, 256x256x160" % a.batch, "ms_per_step": 1e3 * dt,
-                      "faces_per_sec": a.batch / dt, "ray_steps_per_sec": a.batch * 256 * 256 * 160 / dt}))
-    if a.profile:
+    if rank == 0:
+        print(json.dumps({"workload": "train step, batch %d per GPU x %d GPU(s), 256x256x160" % (a.batch, world),
+                          "ddp": a.ddp, "ms_per_step": 1e3 * dt, "faces_per_sec": world * a.batch / dt,
+                          "ray_steps_per_sec": world * a.batch * 256 * 256 * 160 / dt}))
+    if a.ddp:
+        dist.barrier()
+    if a.profile and rank == 0:
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
             for j in range(3):
@@ -57,3 +70,5 @@ def main():
 
 if __name__ == "__main__":
     main()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
