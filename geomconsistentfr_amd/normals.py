@@ -9,10 +9,10 @@ kornia 0.4.1's published algorithm --
     n = normalize(cross(dP/du, dP/dv))                                   F.normalize, eps 1e-12
 -- and everything downstream of it (shading given normals) is pinned by reference code.
 
-Two implementations of the same statement:
-  * tensors on a ROCm device -> the HIP kernels gcfr_normals_fwd / gcfr_normals_bwd (csrc/gcfr_normals.hip)
-    behind a torch.autograd.Function (no fallback: a missing library raises);
-  * host tensors -> plain torch ops (`depth_to_normals_torch`), used by the CPU tests and as the readable spec.
+`depth_to_normals` is the product path: the HIP kernels gcfr_normals_fwd / gcfr_normals_bwd
+(csrc/gcfr_normals.hip) behind a torch.autograd.Function.  It has NO CPU path: host tensors or a missing
+library raise GcfrError.  `depth_to_normals_torch` states the same algorithm in torch ops; it is the readable
+specification the kernels are tested against and is never called by the product.
 """
 import torch
 import torch.nn.functional as F
@@ -63,9 +63,10 @@ def depth_to_normals(depth: torch.Tensor, camera_matrix: torch.Tensor, negate_y:
                      z_offset: float = 0.0) -> torch.Tensor:
     """depth (B,1,H,W), camera_matrix (1|B,3,3) -> unit normals (B,3,H,W), y negated as the reference does
     right after the call (T8:354).  `z_offset` is added to the depth in f32 first (T8:353: +1610).
-    Device tensors run the HIP kernels; host tensors the torch restatement."""
+    Device tensors only (HIP kernels); there is no CPU path."""
     if not depth.is_cuda:
-        return depth_to_normals_torch(depth + z_offset if z_offset else depth, camera_matrix, negate_y)
+        raise _lib.GcfrError("geomconsistentfr_amd has no CPU path: depth must be on a ROCm device "
+                             "(depth_to_normals_torch is the host-side specification used by the tests)")
     K = camera_matrix.detach().to("cpu", torch.float64)          # tiny; the reference builds it on the host (T8:571)
     if K.shape[0] != 1 and not bool((K == K[:1]).all()):
         return torch.cat([depth_to_normals(depth[i:i + 1], camera_matrix[i:i + 1], negate_y, z_offset)
@@ -75,7 +76,8 @@ def depth_to_normals(depth: torch.Tensor, camera_matrix: torch.Tensor, negate_y:
 
 
 def depth_to_normals_torch(depth: torch.Tensor, camera_matrix: torch.Tensor, negate_y: bool = True) -> torch.Tensor:
-    """Torch-op statement of the same algorithm (any device, differentiable by autograd)."""
+    """Torch-op statement of the same algorithm (any device, differentiable by autograd).  Specification /
+    test reference only -- not called by the product."""
     B, _, H, W = depth.shape
     K = camera_matrix.to(device=depth.device)
     ct = torch.promote_types(depth.dtype, K.dtype)            # the reference's K is f64 -> f64 maths

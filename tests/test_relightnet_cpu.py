@@ -46,8 +46,12 @@ def test_epoch_gates_switch_the_skip_connections():
 
 
 def test_normals_match_the_oracle_restatement():
-    from geomconsistentfr_amd.normals import depth_to_normals
+    from geomconsistentfr_amd._lib import GcfrError
+    from geomconsistentfr_amd.normals import depth_to_normals as product_normals
+    from geomconsistentfr_amd.normals import depth_to_normals_torch as depth_to_normals
     from normals_restatement import depth_to_normals as oracle_normals
+    with pytest.raises(GcfrError):                       # the product path refuses host tensors
+        product_normals(torch.zeros(1, 1, 8, 8), torch.eye(3, dtype=torch.float64)[None])
     rng = np.random.default_rng(3)
     depth = torch.from_numpy((30 * rng.random((2, 1, 64, 80))).astype(np.float32))
     K = torch.zeros(1, 3, 3, dtype=torch.float64)
