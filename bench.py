@@ -265,7 +265,9 @@ def main():
                        "parallelism": "dp%d" % world},
             "faces_per_sec": world * B * Ll * a.steps / elapsed,
             "ray_steps_per_sec_per_gpu": value / world,
-            "roofline": {"bound": "hbm", "kernel": "shadow_fwd_quad_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "note": "north_star's HBM accounting; the gathers are cache-served (traffic << "
+                         "algorithmic bytes, so frac can exceed 1) and the kernel is VALU-issue bound -- DESIGN.md 4.1",
+                         "kernel": "shadow_fwd_quad_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": shadow_ms,
                          "kernel_ray_steps_per_sec": B * Ll * Hh * Ww * Nn / (shadow_ms * 1e-3)},

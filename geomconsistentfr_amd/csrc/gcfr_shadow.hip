@@ -1,17 +1,23 @@
-// Ray-marched minimum point-to-line distance (the hot kernel) + light preparation, gfx950.
+// Ray-marched minimum point-to-line distance (the hot kernels), depth repack prepass, light preparation
+// and the forward C entry points, gfx950.
 //
 // Replaces train_raytracing_relighting_CelebAHQ_DSSIM_8x.py:357-363 and :371-515.  The reference
 // materialises (N,2,H,W) f64 sample grids per image (2.8 GB of temporaries per 256x256 face); here
 // one lane owns one pixel and walks its N samples in registers:
-//   - one wavefront = one TILE_H x TILE_W pixel tile (64 lanes); neighbouring lanes march
-//     neighbouring, nearly parallel rays, so every gather instruction of the wave touches a
-//     footprint about the size of the tile -> a handful of 128-B lines served by the CU's L1;
-//   - the per-image working set (H*W*4 B depth + H*W B mask = 320 KB at 256x256) lives in L2, so
-//     HBM traffic is compulsory only; the kernel is VALU / vector-memory-issue bound, not HBM bound;
+//   - one wavefront = one pixel tile (64 lanes); neighbouring lanes march neighbouring, nearly parallel
+//     rays, so every gather instruction of the wave touches a footprint about the size of the tile ->
+//     a handful of 128-B lines served by the CU's L1;
+//   - the per-image working set (depth + mask, 320 KB at 256x256; 1.3 MB repacked) lives in L2, so
+//     HBM traffic is compulsory only; the kernels are VALU / vector-memory-issue bound, not HBM bound;
 //   - the sample table is wave-uniform: it is read with scalar loads (SMEM), costing no VALU;
 //   - gathers use raw buffer loads (32-bit offsets off an SGPR descriptor: no 64-bit address VALU,
 //     hardware range check instead of per-sample clamps).
 // No MFMA: there is no dense contraction anywhere on this path.
+//
+// Two march kernels compute the same bits:
+//   shadow_fwd_kernel       plain form (no workspace): four 4-byte depth gathers per ray-step;
+//   shadow_fwd_quad_kernel  production form: repacked 2x2 texels, magic-number rint, exact skipping of
+//                           masked work, optional fused shading epilogue (see its header comment).
 #include "gcfr_device.hpp"
 
 #include "../../include/gcfr.h"
