@@ -117,6 +117,23 @@ def cpu_baseline(sample_faces=1, seed0=0):
             "faces_per_s": sample_faces / dt}
 
 
+def cpu_baseline_c(sample_faces=8, seed0=0):
+    """Second, much stronger CPU reference point: the scalar C oracle under OpenMP on all host threads
+    (shadow march + shade).  Reported next to `cpu_baseline`, which stays the op-for-op port of the reference."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    depth, mask, albedo, normals, light, amb = synth_faces(sample_faces, seed0)
+    tt = c_oracle.sample_table(0.025, 0.005, N_SAMPLES)
+    _, pt = c_oracle.light_prep(light, clamp_z_min=0.0)
+    c_oracle.shadow_min_distance(depth[:1], mask[:1], pt[:1, None, :], tt)          # warm-up
+    t = time.perf_counter()
+    md, _ = c_oracle.shadow_min_distance(depth, mask, pt[:, None, :], tt)
+    c_oracle.shade(normals.astype(np.float64), depth, albedo, pt[:, None, :], amb[:, None], md)
+    dt = time.perf_counter() - t
+    return {"value": sample_faces * H * W * N_SAMPLES / dt, "unit": "ray-steps/s", "cores": c_oracle.num_threads(),
+            "kind": "port", "sample": "%d faces 256x256x160, oracle/gcfr_oracle.c (scalar C, OpenMP), %.2f s" % (sample_faces, dt)}
+
+
 def pmc_traffic_bytes():
     """HBM bytes per shadow_fwd launch from the committed rocprofv3 PMC pass, or None."""
     p = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -274,6 +291,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline_c_openmp"] = cpu_baseline_c()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
