@@ -224,12 +224,24 @@ struct PrepassLights {  // optional: fold gcfr_light_prep into the prepass launc
 
 constexpr int kBBoxInit = 0x7f7f7f7f;  // "+infinity" for the int minima below
 
+// Wave-wide integer minimum, result wave-uniform (SGPR).  DPP row shifts + row broadcasts (gfx9): six
+// VALU-speed steps instead of six dependent ds_bpermute round trips (__shfl_xor), which dominated the
+// kernels' latency-bound prologues (measured: 20 us -> see DESIGN.md 4.1 "fixed cost").
+template <int CTRL, int ROW_MASK>
+__device__ inline int dpp_min_step(int v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, ROW_MASK, 0xf, false);
+    return min(v, moved);
+}
 __device__ inline int wave_min_i32(int v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        v = min(v, __shfl_xor(v, off, 64));
-    return v;
+    v = dpp_min_step<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_min_step<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_min_step<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_min_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each 16-lane row holds the row minimum
+    v = dpp_min_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_min_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave minimum
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Prepass.  Per image: (a) repack depth into 2x2-neighbourhood texels, (b) optional light preparation,
