@@ -296,3 +296,35 @@ def render(depth, albedo, light, ambient, normals, mask, params: RenderParams = 
         final_shading=fin,
         minimum_distance=md,
     )
+
+
+class GraphedRenderFwd:
+    """hipGraph replay of the forward block for fixed shapes.  Captures one `render_fwd` call (two kernels,
+    launched through ctypes on the capturing stream) on static buffers; `__call__` copies the new inputs into
+    them and replays.  Forward only (no autograd).  Measured on MI355X (tools/graph_latency.py): replay is
+    bit-identical to the eager call but NOT faster (B=1: 33.6 vs 35.6 us, B=8: 123 vs 120 us) -- with two
+    launches per step there is nothing for a graph to amortise; kept because it shows the entry points are
+    capture-safe (no allocation, no synchronisation inside)."""
+
+    def __init__(self, depth, mask, light, ambient, normals, albedo, params: RenderParams = RenderParams()):
+        _require_device(depth, mask, light, ambient, normals, albedo)
+        self.params = params
+        self.static = [t.detach().clone().contiguous() for t in (depth, mask, light, ambient, normals, albedo)]
+        self.static[1] = mask_to_u8(self.static[1])
+        sample_table(params, depth.device)                       # materialise the table outside the capture
+        s = torch.cuda.Stream(device=depth.device)
+        s.wait_stream(torch.cuda.current_stream(depth.device))
+        with torch.cuda.stream(s):                               # warm-up on the side stream, as torch requires
+            for _ in range(2):
+                render_fwd(*self.static, params, want_argmin=False)
+        torch.cuda.current_stream(depth.device).wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = render_fwd(*self.static, params, want_argmin=False)
+
+    def __call__(self, depth, mask, light, ambient, normals, albedo):
+        for dst, src in zip(self.static, (depth, mask, light, ambient, normals, albedo)):
+            if src is not dst:
+                dst.copy_(src if dst.dtype == src.dtype else src.to(dst.dtype))
+        self.graph.replay()
+        return self.out

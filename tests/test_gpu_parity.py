@@ -314,3 +314,28 @@ def test_python_boundary_rejects_bad_shapes():
     with pytest.raises(GcfrError):                                        # mask batch must be 1 or B
         shadow_min_distance(torch.zeros(3, 64, 64, device="cuda:0"), torch.ones(2, 64, 64, device="cuda:0"),
                             torch.ones(3, 1, 3, device="cuda:0"), RenderParams())
+
+
+def test_forward_is_hipgraph_capturable():
+    """The C entry points neither allocate nor synchronise: a torch.cuda.graph capture of render_fwd replays
+    bit-identically, also after the static inputs are overwritten."""
+    from geomconsistentfr_amd import RenderParams
+    from geomconsistentfr_amd import block as R
+    rng = np.random.default_rng(9)
+    B, Hs, Ws = 2, 64, 64
+    mk = lambda *s: to_dev(rng.random(s, dtype=np.float32))
+    depth, albedo, normals = to_dev((30 * rng.random((B, Hs, Ws))).astype(np.float32)), mk(B, 3, Hs, Ws), mk(B, 3, Hs, Ws) - 0.5
+    mask = to_dev((rng.random((B, Hs, Ws)) > 0.3).astype(np.uint8))
+    light, amb = to_dev(rng.standard_normal((B, 1, 3)).astype(np.float32)), mk(B, 1)
+    prm = RenderParams(n_samples=40, dt=0.02)
+    g = R.GraphedRenderFwd(depth, mask, light, amb, normals, albedo, prm)
+    ref = R.render_fwd(depth, mask, light, amb, normals, albedo, prm, want_argmin=False)
+    out = g(depth, mask, light, amb, normals, albedo)
+    torch.cuda.synchronize()
+    assert torch.equal(out["rendered_images"], ref["rendered_images"])
+    depth2 = torch.roll(depth, 3, dims=2).contiguous()
+    ref2 = R.render_fwd(depth2, mask, light, amb, normals, albedo, prm, want_argmin=False)
+    out2 = g(depth2, mask, light, amb, normals, albedo)
+    torch.cuda.synchronize()
+    assert torch.equal(out2["rendered_images"], ref2["rendered_images"])
+    assert torch.equal(out2["minimum_distance"], ref2["minimum_distance"])
