@@ -134,6 +134,24 @@ def cpu_baseline_c(sample_faces=8, seed0=0):
             "kind": "port", "sample": "%d faces 256x256x160, oracle/gcfr_oracle.c (scalar C, OpenMP), %.2f s" % (sample_faces, dt)}
 
 
+def measured_copy_bandwidth_gbs(dev, mb=1024, iters=5):
+    """Device-to-device copy rate (read + write bytes) -- the achievable-HBM denominator SURVEY.md 8d asks to
+    report beside the 8 TB/s spec peak."""
+    n = mb * 1024 * 1024 // 4
+    a = torch.empty(n, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    a.fill_(1.0)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * 4 * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def pmc_traffic_bytes():
     """HBM bytes per shadow_fwd launch from the committed rocprofv3 PMC pass, or None."""
     p = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -287,7 +305,8 @@ def main():
                          "kernel": "shadow_fwd_quad_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": shadow_ms,
-                         "kernel_ray_steps_per_sec": B * Ll * Hh * Ww * Nn / (shadow_ms * 1e-3)},
+                         "kernel_ray_steps_per_sec": B * Ll * Hh * Ww * Nn / (shadow_ms * 1e-3),
+                         "measured_copy_GBs": measured_copy_bandwidth_gbs(dev)},
         }
         if world == 1 and not a.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
