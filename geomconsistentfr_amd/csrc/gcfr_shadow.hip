@@ -225,8 +225,9 @@ struct PrepassLights {  // optional: fold gcfr_light_prep into the prepass launc
 constexpr int kBBoxInit = 0x7f7f7f7f;  // "+infinity" for the int minima below
 
 // Wave-wide integer minimum, result wave-uniform (SGPR).  DPP row shifts + row broadcasts (gfx9): six
-// VALU-speed steps instead of six dependent ds_bpermute round trips (__shfl_xor), which dominated the
-// kernels' latency-bound prologues (measured: 20 us -> see DESIGN.md 4.1 "fixed cost").
+// VALU-speed steps instead of six dependent ds_bpermute round trips (__shfl_xor) in the kernels'
+// latency-bound prologues (measured: fixed cost of the march at B=8 20.5 -> 19.5 us; LDS atomics instead
+// were 2.4x worse).
 template <int CTRL, int ROW_MASK>
 __device__ inline int dpp_min_step(int v)
 {
