@@ -134,6 +134,11 @@ __global__ __launch_bounds__(256) void shadow_fwd_kernel(ShadowArgs a)
     // unmasked samples and finish once per pixel.
     float bestS = __builtin_inff();
     int besti = -1;
+    // The running minimum it replaced last.  torch.min returns the first index of the minimal DISTANCE; two
+    // samples whose S differ by a few ulps can round to the same distance, and then the earlier one -- the
+    // predecessor in the chain of running minima -- is the reference's argmin (see the epilogue).
+    float prevS = __builtin_inff();
+    int prevk = -1;
     bool any_masked = false;
 
     for (int k = 0; k < N; ++k) {
@@ -172,12 +177,16 @@ __global__ __launch_bounds__(256) void shadow_fwd_kernel(ShadowArgs a)
         const bool masked = (mk == 0);
         any_masked |= masked;
         const bool take = !masked && (S < bestS);  // strict: first minimum wins (T8:514)
+        prevS = take ? bestS : prevS;
+        prevk = take ? besti : prevk;
         bestS = take ? S : bestS;
         besti = take ? k : besti;
     }
 
     const float den = __builtin_sqrtf(((rc.BCx * rc.BCx + rc.BCy * rc.BCy) + rc.BCz * rc.BCz) + kEps4);
     float d = __builtin_sqrtf(bestS) / den;  // +inf when every sample was masked
+    if (__builtin_sqrtf(prevS) / den == d)   // distance tie with the predecessor: the earlier index wins
+        besti = prevk;
     if (any_masked && !(d < kMaskedDistance)) {  // T8:512: masked samples count as 1e6
         d = kMaskedDistance;
         besti = -1;  // no gradient flows through a masked minimum
@@ -390,6 +399,8 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
 
     float bestS = __builtin_inff();
     int besti = -1;
+    float prevS = __builtin_inff();  // the running minimum replaced last (distance-tie resolution, see epilogue)
+    int prevk = -1;
     bool any_masked = false;
 
     // Candidate sample range.  A sample can only be unmasked if its rounded cell lies inside the bounding
@@ -559,18 +570,23 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
             const float Xz = __builtin_fmaf(BAx, BCy, -(BAy * BCx));
             const float S = ((Xx * Xx + Xy * Xy) + Xz * Xz) + kEps4;
             const bool take = !masked && (S < bestS);
-            bestS = take ? S : bestS;
-            if (WANT_ARGMIN)
+            if (WANT_ARGMIN) {
+                prevS = take ? bestS : prevS;
+                prevk = take ? besti : prevk;
                 besti = take ? k : besti;
+            }
+            bestS = take ? S : bestS;
         }
     }
 
     if (KSPLIT) {  // combine the four sample-range quarters of this tile
-        __shared__ float sS[4][64];
-        __shared__ int sK[4][64];
+        __shared__ float sS[4][64], sPS[4][64];
+        __shared__ int sK[4][64], sPK[4][64];
         __shared__ uint8_t sM[4][64];
         sS[wave][lane] = bestS;
         sK[wave][lane] = besti;
+        sPS[wave][lane] = prevS;
+        sPK[wave][lane] = prevk;
         sM[wave][lane] = any_masked ? 1 : 0;
         __syncthreads();
         if (wave != 0)
@@ -579,6 +595,12 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
         for (int q = 1; q < 4; ++q) {
             const float Sq = sS[q][lane];
             const bool take = Sq < bestS;  // strict: the earlier quarter keeps ties (first minimum, T8:514)
+            // predecessor of a new best from quarter q: q's own predecessor if it already beat the running
+            // best (it is part of the global chain of running minima), otherwise the running best it replaces
+            const float PSq = sPS[q][lane];
+            const bool local_pred = PSq < bestS;
+            prevS = take ? (local_pred ? PSq : bestS) : prevS;
+            prevk = take ? (local_pred ? sPK[q][lane] : besti) : prevk;
             bestS = take ? Sq : bestS;
             besti = take ? sK[q][lane] : besti;
             any_masked |= (sM[q][lane] != 0);
@@ -587,6 +609,11 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
 
     const float den = __builtin_sqrtf(((BCx * BCx + BCy * BCy) + BCz * BCz) + kEps4);
     float d = __builtin_sqrtf(bestS) / den;
+    // torch.min (T8:514) returns the FIRST index of the minimal distance.  sqrt and the division are monotone,
+    // so the minimal distance is the distance of the minimal S -- but a predecessor in the chain of running
+    // minima whose S is a few ulps larger can round to the same distance, and it comes first.
+    if (WANT_ARGMIN && __builtin_sqrtf(prevS) / den == d)
+        besti = prevk;
     if (any_masked && !(d < kMaskedDistance)) {
         d = kMaskedDistance;
         besti = -1;

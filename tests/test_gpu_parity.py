@@ -102,7 +102,7 @@ def test_shadow_matches_c_oracle(Hs, Ws, N, t0, dt):
     np.testing.assert_array_equal(md[~lit], md_o[~lit])
     # argmin: -1 marks "minimum is a masked sample" (no gradient); elsewhere identical up to exact ties
     assert np.all(am[~lit] == -1)
-    assert (am[lit] == am_o[lit]).mean() >= 0.9999
+    assert (am[lit] == am_o[lit]).mean() >= 0.999999          # identical up to triple distance ties
 
 
 def _full_size_inputs(B=8):
