@@ -26,6 +26,8 @@ _SIGNATURES = {
     "gcfr_shadow_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i]),
     "gcfr_tune": (_i, [_i, _i]),
     "gcfr_profile_events": (_i, [_p, _p]),
+    "gcfr_render_from_depth_fwd": (_i, [_p, _i, _f, _f, _p, _p, _i, _d, _d, _d, _d, _f, _i, _p, _p, _i, _i, _i, _i, _i, _p,
+                                        _f, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p]),
     "gcfr_normals_fwd": (_i, [_p, _i, _i, _i, _d, _d, _d, _d, _f, _i, _p, _p]),
     "gcfr_normals_bwd": (_i, [_p, _p, _i, _i, _i, _d, _d, _d, _d, _f, _i, _p, _p]),
     "gcfr_render_fwd": (_i, [_p, _i, _f, _f, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p, _f,

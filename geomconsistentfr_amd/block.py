@@ -154,11 +154,15 @@ def shade(normals, depth, albedo, light_pt, ambient, min_dist, params: RenderPar
 
 
 def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParams = RenderParams(),
-               want_argmin: bool = True):
+               want_argmin: bool = True, camera=None):
     """One enqueue for the whole forward block (gcfr_render_fwd): light prep, depth repack, ray march with
     the shading fused into its epilogue.  depth (B,H,W), mask (B|1,H,W), light (B,L,3) raw/target,
-    ambient (B,L), normals/albedo (B,3,H,W).  Returns a dict of f32 tensors (B,L,...)."""
-    _require_device(depth, mask, light, ambient, normals, albedo)
+    ambient (B,L), normals/albedo (B,3,H,W).  Returns a dict of f32 tensors (B,L,...).
+    normals=None with camera=(fx, fy, cx, cy, z_offset): the normals stage (T8:353-354) is fused into the
+    epilogue as well (gcfr_render_from_depth_fwd); the dict then also carries "surface_normals"."""
+    _require_device(depth, mask, light, ambient, albedo)
+    if normals is None and camera is None:
+        raise _lib.GcfrError("render_fwd needs either normals or camera=(fx, fy, cx, cy, z_offset)")
     L_ = _lib.load()
     depth = _f32c(depth)
     B, H, W = depth.shape
@@ -167,7 +171,9 @@ def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParam
     light = _f32c(light).reshape(B, -1, 3)
     L = light.shape[1]
     ambient = _f32c(ambient).reshape(B, L)
-    normals = _f32c(normals).reshape(B, 3, H, W)
+    if normals is not None:
+        _require_device(normals)
+        normals = _f32c(normals).reshape(B, 3, H, W)
     albedo = _f32c(albedo).reshape(B, 3, H, W)
     tt = sample_table(params, dev)
     f32 = dict(dtype=torch.float32, device=dev)
@@ -183,16 +189,29 @@ def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParam
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     box = ctypes_float4(params.bonus_box) if params.bonus_box is not None else None
     clamp = params.clamp_light_z_min is not None
+    out = dict(unit_light_direction=unit, light_pt=pt, minimum_distance=md, argmin=am, shadow_mask_weights=w,
+               full_shading=full, final_shading=fin, rendered_images=ren)
     with torch.cuda.device(dev):
-        _lib.check(L_.gcfr_render_fwd(
-            light.data_ptr(), int(clamp), float(params.clamp_light_z_min or 0.0), float(params.light_distance),
-            depth.data_ptr(), mask_u8.data_ptr(), mask_u8.shape[0], normals.data_ptr(), albedo.data_ptr(),
-            ambient.data_ptr(), B, L, H, W, params.n_samples, tt.data_ptr(), float(params.inside_bonus), box,
-            float(params.directional_intensity), unit.data_ptr(), pt.data_ptr(), md.data_ptr(), _opt_ptr(am),
-            w.data_ptr(), full.data_ptr(), fin.data_ptr(), ren.data_ptr(), ws.data_ptr(), ws_bytes,
-            _stream_ptr(dev)), "gcfr_render_fwd")
-    return dict(unit_light_direction=unit, light_pt=pt, minimum_distance=md, argmin=am, shadow_mask_weights=w,
-                full_shading=full, final_shading=fin, rendered_images=ren)
+        if normals is not None:
+            _lib.check(L_.gcfr_render_fwd(
+                light.data_ptr(), int(clamp), float(params.clamp_light_z_min or 0.0), float(params.light_distance),
+                depth.data_ptr(), mask_u8.data_ptr(), mask_u8.shape[0], normals.data_ptr(), albedo.data_ptr(),
+                ambient.data_ptr(), B, L, H, W, params.n_samples, tt.data_ptr(), float(params.inside_bonus), box,
+                float(params.directional_intensity), unit.data_ptr(), pt.data_ptr(), md.data_ptr(), _opt_ptr(am),
+                w.data_ptr(), full.data_ptr(), fin.data_ptr(), ren.data_ptr(), ws.data_ptr(), ws_bytes,
+                _stream_ptr(dev)), "gcfr_render_fwd")
+        else:
+            fx, fy, cx, cy, z_off = [float(v) for v in camera]
+            nout = torch.empty((B, 3, H, W), **f32)
+            _lib.check(L_.gcfr_render_from_depth_fwd(
+                light.data_ptr(), int(clamp), float(params.clamp_light_z_min or 0.0), float(params.light_distance),
+                depth.data_ptr(), mask_u8.data_ptr(), mask_u8.shape[0], fx, fy, cx, cy, z_off, 1, albedo.data_ptr(),
+                ambient.data_ptr(), B, L, H, W, params.n_samples, tt.data_ptr(), float(params.inside_bonus), box,
+                float(params.directional_intensity), unit.data_ptr(), pt.data_ptr(), md.data_ptr(), _opt_ptr(am),
+                nout.data_ptr(), w.data_ptr(), full.data_ptr(), fin.data_ptr(), ren.data_ptr(), ws.data_ptr(),
+                ws_bytes, _stream_ptr(dev)), "gcfr_render_from_depth_fwd")
+            out["surface_normals"] = nout
+    return out
 
 
 def _zeros(shape, dtype, device):
@@ -328,3 +347,30 @@ class GraphedRenderFwd:
                 dst.copy_(src if dst.dtype == src.dtype else src.to(dst.dtype))
         self.graph.replay()
         return self.out
+
+
+def render_from_depth(depth, albedo, light, ambient, camera_matrix, z_offset, mask,
+                      params: RenderParams = RenderParams()):
+    """The whole T8:353-522 seam for one light per image: normals from depth, shading, ray march, composite.
+    With autograd active the normals come from the differentiable `depth_to_normals` op and `render()`; under
+    no_grad (inference) everything runs in the two-launch fused forward (`gcfr_render_from_depth_fwd`).
+    Same dict as `render()` plus "surface_normals" (unit, y negated)."""
+    from .normals import depth_to_normals
+    B, _, H, W = depth.shape
+    needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (depth, albedo, light, ambient))
+    K = camera_matrix.detach().to("cpu", torch.float64)
+    per_image_K = K.shape[0] != 1 and not bool((K == K[:1]).all())
+    if needs_grad or per_image_K:
+        normals = depth_to_normals(depth, camera_matrix, z_offset=z_offset)
+        r = render(depth, albedo, light, ambient, normals, mask, params)
+        r["surface_normals"] = normals
+        return r
+    cam = (float(K[0, 0, 0]), float(K[0, 1, 1]), float(K[0, 0, 2]), float(K[0, 1, 2]), float(z_offset))
+    o = render_fwd(depth.reshape(B, H, W), mask.reshape(-1, H, W), light.reshape(B, 1, 3), ambient.reshape(B, 1),
+                   None, albedo, params, want_argmin=False, camera=cam)
+    amb = ambient.detach().to(torch.float32).reshape(B, 1, 1)
+    return dict(shadow_mask_weights=o["shadow_mask_weights"][:, 0], ambient_light=amb.expand(B, H, W),
+                full_shading=o["full_shading"][:, 0], rendered_images=o["rendered_images"][:, 0],
+                unit_light_direction=o["unit_light_direction"].reshape(B, 3, 1, 1), ambient_values=amb,
+                final_shading=o["final_shading"][:, 0], minimum_distance=o["minimum_distance"][:, 0],
+                surface_normals=o["surface_normals"])

@@ -133,4 +133,63 @@ __device__ inline Shaded shade_pixel(float x, float y, float zb, float nx, float
     return o;
 }
 
+// ---- surface normals from depth (kornia 0.4.1 restatement; see gcfr_normals.hip for the algorithm) ----
+struct NormalsArgs {
+    const float *depth;  // (B,H,W)
+    float *normals;      // (B,3,H,W)           forward output
+    const float *grad_normals;  // (B,3,H,W)    backward input
+    float *grad_depth;   // (B,H,W) +=          backward output
+    int32_t H, W;
+    double fx, fy, cx, cy;
+    float z_offset;
+    int32_t negate_y;
+};
+
+// Sobel weights (already / 8) indexed [dr+1][dc+1]
+__device__ constexpr double kSobelU[3][3] = {{-0.125, 0.0, 0.125}, {-0.25, 0.0, 0.25}, {-0.125, 0.0, 0.125}};
+__device__ constexpr double kSobelV[3][3] = {{-0.125, -0.25, -0.125}, {0.0, 0.0, 0.0}, {0.125, 0.25, 0.125}};
+
+struct Grad3 {
+    double du[3], dv[3];
+};
+
+// dP/du and dP/dv at pixel (r,c); neighbours are clamped to the image (replicate padding).
+__device__ inline Grad3 point_gradients(const NormalsArgs &a, const float *z, int r, int c)
+{
+    Grad3 g = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr) {
+#pragma unroll
+        for (int dc = -1; dc <= 1; ++dc) {
+            const int rr = min(max(r + dr, 0), a.H - 1), cc = min(max(c + dc, 0), a.W - 1);
+            const double d = (double)(z[(size_t)rr * a.W + cc] + a.z_offset);  // depth + 1610 in f32 (T8:353)
+            const double X = ((double)cc - a.cx) / a.fx * d;
+            const double Y = ((double)rr - a.cy) / a.fy * d;
+            const double ku = kSobelU[dr + 1][dc + 1], kv = kSobelV[dr + 1][dc + 1];
+            g.du[0] += ku * X;
+            g.du[1] += ku * Y;
+            g.du[2] += ku * d;
+            g.dv[0] += kv * X;
+            g.dv[1] += kv * Y;
+            g.dv[2] += kv * d;
+        }
+    }
+    return g;
+}
+
+// Unit normal of pixel (r,c) as f32, y negated if requested (T8:353-354) -- shared by normals_fwd_kernel and
+// the march kernel's fused epilogue so that both produce the same bits.
+__device__ inline void unit_normal(const NormalsArgs &a, const float *z, int r, int c, float (&n)[3])
+{
+    const Grad3 g = point_gradients(a, z, r, c);
+    const double nx = g.du[1] * g.dv[2] - g.du[2] * g.dv[1];
+    const double ny = g.du[2] * g.dv[0] - g.du[0] * g.dv[2];
+    const double nz = g.du[0] * g.dv[1] - g.du[1] * g.dv[0];
+    double nn = sqrt(nx * nx + ny * ny + nz * nz);
+    nn = nn > 1e-12 ? nn : 1e-12;
+    n[0] = (float)(nx / nn);
+    n[1] = (float)(a.negate_y ? -(ny / nn) : (ny / nn));  // T8:354
+    n[2] = (float)(nz / nn);
+}
+
 }  // namespace gcfr

@@ -18,49 +18,6 @@
 
 namespace gcfr {
 
-struct NormalsArgs {
-    const float *depth;  // (B,H,W)
-    float *normals;      // (B,3,H,W)           forward output
-    const float *grad_normals;  // (B,3,H,W)    backward input
-    float *grad_depth;   // (B,H,W) +=          backward output
-    int32_t H, W;
-    double fx, fy, cx, cy;
-    float z_offset;
-    int32_t negate_y;
-};
-
-// Sobel weights (already / 8) indexed [dr+1][dc+1]
-__device__ constexpr double kSobelU[3][3] = {{-0.125, 0.0, 0.125}, {-0.25, 0.0, 0.25}, {-0.125, 0.0, 0.125}};
-__device__ constexpr double kSobelV[3][3] = {{-0.125, -0.25, -0.125}, {0.0, 0.0, 0.0}, {0.125, 0.25, 0.125}};
-
-struct Grad3 {
-    double du[3], dv[3];
-};
-
-// dP/du and dP/dv at pixel (r,c); neighbours are clamped to the image (replicate padding).
-__device__ inline Grad3 point_gradients(const NormalsArgs &a, const float *z, int r, int c)
-{
-    Grad3 g = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-#pragma unroll
-    for (int dr = -1; dr <= 1; ++dr) {
-#pragma unroll
-        for (int dc = -1; dc <= 1; ++dc) {
-            const int rr = min(max(r + dr, 0), a.H - 1), cc = min(max(c + dc, 0), a.W - 1);
-            const double d = (double)(z[(size_t)rr * a.W + cc] + a.z_offset);  // depth + 1610 in f32 (T8:353)
-            const double X = ((double)cc - a.cx) / a.fx * d;
-            const double Y = ((double)rr - a.cy) / a.fy * d;
-            const double ku = kSobelU[dr + 1][dc + 1], kv = kSobelV[dr + 1][dc + 1];
-            g.du[0] += ku * X;
-            g.du[1] += ku * Y;
-            g.du[2] += ku * d;
-            g.dv[0] += kv * X;
-            g.dv[1] += kv * Y;
-            g.dv[2] += kv * d;
-        }
-    }
-    return g;
-}
-
 __global__ __launch_bounds__(256) void normals_fwd_kernel(NormalsArgs a)
 {
     const size_t P = (size_t)a.H * a.W;
@@ -69,16 +26,12 @@ __global__ __launch_bounds__(256) void normals_fwd_kernel(NormalsArgs a)
     if (p >= P)
         return;
     const int r = (int)(p / a.W), c = (int)(p - (size_t)r * a.W);
-    const Grad3 g = point_gradients(a, a.depth + (size_t)b * P, r, c);
-    const double nx = g.du[1] * g.dv[2] - g.du[2] * g.dv[1];
-    const double ny = g.du[2] * g.dv[0] - g.du[0] * g.dv[2];
-    const double nz = g.du[0] * g.dv[1] - g.du[1] * g.dv[0];
-    double nn = sqrt(nx * nx + ny * ny + nz * nz);
-    nn = nn > 1e-12 ? nn : 1e-12;
+    float n[3];
+    unit_normal(a, a.depth + (size_t)b * P, r, c, n);
     float *o = a.normals + (size_t)b * 3 * P + p;
-    o[0] = (float)(nx / nn);
-    o[P] = (float)(a.negate_y ? -(ny / nn) : (ny / nn));  // T8:354
-    o[2 * P] = (float)(nz / nn);
+    o[0] = n[0];
+    o[P] = n[1];
+    o[2 * P] = n[2];
 }
 
 __global__ __launch_bounds__(256) void normals_bwd_kernel(NormalsArgs a)

@@ -324,6 +324,9 @@ struct ShadowQuadArgs {
     float *shadow_w, *full, *final_shading, *rendered;
     float intensity;
     int32_t ksplit;  // host-side choice, see shadow_fwd_quad_kernel
+    // normals == nullptr: the epilogue computes the normal from the depth stencil itself (T8:353-354 fused)
+    NormalsArgs nrm;
+    float *normals_out;  // (B,3,H,W) or null
 };
 
 constexpr double kRintMagic = 6755399441055744.0;  // 2^52 + 2^51
@@ -630,9 +633,22 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
         if (WANT_ARGMIN)
             a.argmin[o] = besti;
         if (FUSE_SHADE) {
-            const float *nrm = a.normals + (size_t)b * 3 * P + pix;
-            const Shaded sh = shade_pixel(x, y, zb, nrm[0], nrm[P], nrm[2 * P], Cx, Cy, Cz, a.ambient[bl],
-                                          a.intensity, d);
+            float n[3];
+            if (a.normals) {
+                const float *nrm = a.normals + (size_t)b * 3 * P + pix;
+                n[0] = nrm[0];
+                n[1] = nrm[P];
+                n[2] = nrm[2 * P];
+            } else {  // normals fused: 3x3 depth stencil, same device function as normals_fwd_kernel
+                unit_normal(a.nrm, a.depth + (size_t)b * P, r, c, n);
+                if (a.normals_out && l == 0) {
+                    float *no = a.normals_out + (size_t)b * 3 * P + pix;
+                    no[0] = n[0];
+                    no[P] = n[1];
+                    no[2 * P] = n[2];
+                }
+            }
+            const Shaded sh = shade_pixel(x, y, zb, n[0], n[1], n[2], Cx, Cy, Cz, a.ambient[bl], a.intensity, d);
             if (a.shadow_w)
                 a.shadow_w[o] = sh.w;
             if (a.full)
@@ -791,6 +807,8 @@ static void launch_quad(const ShadowQuadArgs &a, bool even_half, bool want_argmi
 }
 
 struct FusedShade {  // operands of the fused shading epilogue; rendered == nullptr: march only
+    NormalsArgs nrm = {};            // used when normals == nullptr
+    float *normals_out = nullptr;
     const float *normals = nullptr, *albedo = nullptr, *ambient = nullptr;
     float *shadow_w = nullptr, *full = nullptr, *final_shading = nullptr, *rendered = nullptr;
     float intensity = 0.0f;
@@ -870,6 +888,11 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         a.final_shading = fs.final_shading;
         a.rendered = fs.rendered;
         a.intensity = fs.intensity;
+        a.nrm = fs.nrm;
+        a.nrm.depth = depth;
+        a.nrm.H = H;
+        a.nrm.W = W;
+        a.normals_out = fs.normals_out;
         const bool even_half = (((W / 2) & 1) == 0) && (((H / 2) & 1) == 0);
         const bool want = argmin != nullptr;
         switch (TILE_W) {
@@ -947,6 +970,48 @@ extern "C" int gcfr_render_fwd(const float *light_raw, int32_t clamp_z, float cl
     fs.lights.clamp_min = clamp_min;
     fs.lights.light_distance = light_distance;
     fs.normals = normals;
+    fs.albedo = albedo;
+    fs.ambient = ambient;
+    fs.shadow_w = shadow_w;
+    fs.full = full;
+    fs.final_shading = final_shading;
+    fs.rendered = rendered;
+    fs.intensity = intensity;
+    return shadow_fwd_impl(depth, mask_u8, mask_batch, light_pt_out, B, L, H, W, N, t_table, bonus,
+                           bonus_box, min_dist, argmin, workspace, workspace_bytes, stream, fs);
+}
+
+extern "C" int gcfr_render_from_depth_fwd(const float *light_raw, int32_t clamp_z, float clamp_min,
+                                          float light_distance, const float *depth,
+                                          const uint8_t *mask_u8, int32_t mask_batch, double fx, double fy,
+                                          double cx, double cy, float z_offset, int32_t negate_y,
+                                          const float *albedo, const float *ambient, int32_t B, int32_t L,
+                                          int32_t H, int32_t W, int32_t N, const double *t_table,
+                                          float bonus, const float *bonus_box, float intensity,
+                                          float *unit_out, float *light_pt_out, float *min_dist,
+                                          int32_t *argmin, float *normals_out, float *shadow_w, float *full,
+                                          float *final_shading, float *rendered, void *workspace,
+                                          size_t workspace_bytes, void *stream)
+{
+    if (!light_raw || !albedo || !ambient || !unit_out || !light_pt_out || !rendered || !workspace ||
+        B <= 0 || L <= 0 || fx == 0.0 || fy == 0.0)
+        return GCFR_ERR_INVALID_ARGUMENT;
+    FusedShade fs;
+    fs.lights.light_raw = light_raw;
+    fs.lights.unit_out = unit_out;
+    fs.lights.light_pt_out = light_pt_out;
+    fs.lights.L = L;
+    fs.lights.clamp_z = clamp_z;
+    fs.lights.clamp_min = clamp_min;
+    fs.lights.light_distance = light_distance;
+    fs.normals = nullptr;  // computed in the epilogue
+    fs.nrm.fx = fx;
+    fs.nrm.fy = fy;
+    fs.nrm.cx = cx;
+    fs.nrm.cy = cy;
+    fs.nrm.z_offset = z_offset;
+    fs.nrm.negate_y = negate_y;
+    fs.normals_out = normals_out;
     fs.albedo = albedo;
     fs.ambient = ambient;
     fs.shadow_w = shadow_w;

@@ -21,8 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .block import RenderParams, render
-from .normals import depth_to_normals
+from .block import RenderParams, render_from_depth
 
 
 def _lrelu(x):
@@ -133,9 +132,8 @@ class RelightNet(_Hourglass):
     def forward(self, img, epoch, intrinsic_matrix, masks):
         albedo, depth, SL = self.features(img, epoch)
         B = depth.shape[0]
-        normals = depth_to_normals(depth, intrinsic_matrix, z_offset=self.normal_z_offset)   # T8:353-354 (y negated)
-        r = render(depth, albedo, SL[:, 0, 0, 1:4], SL[:, 0, 0, 0], normals,
-                   masks.reshape(B, masks.shape[1], masks.shape[2]), self.render_params)
+        r = render_from_depth(depth, albedo, SL[:, 0, 0, 1:4], SL[:, 0, 0, 0], intrinsic_matrix, self.normal_z_offset,
+                              masks.reshape(B, masks.shape[1], masks.shape[2]), self.render_params)   # T8:353-522
         return (albedo, depth, r["shadow_mask_weights"], r["ambient_light"], r["full_shading"],
                 r["rendered_images"], r["unit_light_direction"], r["ambient_values"])   # T8:524
 
@@ -154,10 +152,10 @@ class RelightNetSingleImage(_Hourglass):
     def forward(self, img, epoch, intrinsic_matrix, mask, target_lighting, target_ambient_values, batch_mask=None):
         albedo, depth, SL = self.features(img, epoch)
         B, _, H, W = depth.shape
-        normals = depth_to_normals(depth, intrinsic_matrix, z_offset=self.normal_z_offset)
         ambient = SL[:, 0, 0, 0] + self.ambient_offset                                  # S1:342
-        r = render(depth, albedo, target_lighting.reshape(B, 3), ambient, normals, mask.reshape(1, H, W),
-                   self.render_params)
+        r = render_from_depth(depth, albedo, target_lighting.reshape(B, 3), ambient, intrinsic_matrix,
+                              self.normal_z_offset, mask.reshape(1, H, W), self.render_params)
+        normals = r["surface_normals"]
         return (albedo, depth, r["shadow_mask_weights"], r["ambient_light"], r["full_shading"],
                 r["rendered_images"], r["unit_light_direction"], r["ambient_values"], r["final_shading"],
                 F.normalize(normals, p=2, dim=1))                                        # S1:505
@@ -176,12 +174,12 @@ class RelightNetLightingTransfer(_Hourglass):
     def forward(self, img, epoch, intrinsic_matrix, mask, target_lighting, target_ambient_values):
         albedo, depth, SL = self.features(img, epoch)
         B, _, H, W = depth.shape
-        normals = depth_to_normals(depth, intrinsic_matrix, z_offset=self.normal_z_offset)
         est = SL[:, 0, 0, 1:4]
         est = torch.stack([est[:, 0], est[:, 1], torch.clamp_min(est[:, 2], self.estimate_z_min)], 1)
         est_unit = F.normalize(est, p=2, dim=1).reshape(B, 3, 1, 1)                     # SLT:329-335
-        r = render(depth, albedo, target_lighting.reshape(B, 3), target_ambient_values.reshape(B), normals,
-                   mask.reshape(1, H, W), self.render_params)
+        r = render_from_depth(depth, albedo, target_lighting.reshape(B, 3), target_ambient_values.reshape(B),
+                              intrinsic_matrix, self.normal_z_offset, mask.reshape(1, H, W), self.render_params)
+        normals = r["surface_normals"]
         return (albedo, depth, r["shadow_mask_weights"], r["ambient_light"], r["full_shading"],
                 r["rendered_images"], r["unit_light_direction"], r["ambient_values"], r["final_shading"],
                 F.normalize(normals, p=2, dim=1), est_unit, SL[:, :, :, 0])              # SLT:514

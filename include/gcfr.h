@@ -136,6 +136,21 @@ int gcfr_render_fwd(const float *light_raw, int32_t clamp_z, float clamp_min, fl
                     float *final_shading, float *rendered, void *workspace, size_t workspace_bytes,
                     void *stream);
 
+/*
+ * gcfr_render_fwd with the normals stage fused in: the march epilogue evaluates the 3x3 depth stencil of
+ * gcfr_normals_fwd itself (same device function, same bits), so T8:353-522 is two launches and the
+ * (B,3,H,W) normals tensor makes no HBM round trip.  normals_out (B,3,H,W) may be NULL.
+ */
+int gcfr_render_from_depth_fwd(const float *light_raw, int32_t clamp_z, float clamp_min,
+                               float light_distance, const float *depth, const uint8_t *mask_u8,
+                               int32_t mask_batch, double fx, double fy, double cx, double cy,
+                               float z_offset, int32_t negate_y, const float *albedo, const float *ambient,
+                               int32_t B, int32_t L, int32_t H, int32_t W, int32_t N, const double *t_table,
+                               float bonus, const float *bonus_box, float intensity, float *unit_out,
+                               float *light_pt_out, float *min_dist, int32_t *argmin, float *normals_out,
+                               float *shadow_w, float *full, float *final_shading, float *rendered,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
 /* Profiling hook: two hipEvent_t handles (or NULL, NULL to clear) that subsequent gcfr_shadow_fwd /
  * gcfr_render_fwd calls record immediately before and after the march kernel, on the launch stream.
  * Process-wide; used by bench.py to time the dominant kernel alone. */

@@ -54,3 +54,32 @@ def test_normals_per_image_camera_matrices():
     n1 = depth_to_normals(depth[1:], K[1:], z_offset=100.0)
     assert torch.equal(n, torch.cat([n0, n1]))
     np.testing.assert_allclose(n.norm(dim=1).cpu().numpy(), 1.0, atol=1e-6)
+
+
+def test_fused_normals_forward_is_bit_identical_to_the_three_stage_path():
+    """gcfr_render_from_depth_fwd (normals stencil inside the march epilogue) == gcfr_normals_fwd followed by
+    gcfr_render_fwd, bit for bit, including the returned normals; and render_from_depth picks it under no_grad."""
+    from geomconsistentfr_amd import RenderParams
+    from geomconsistentfr_amd import block as R
+    from geomconsistentfr_amd.normals import depth_to_normals
+    rng = np.random.default_rng(11)
+    B, H, W = 3, 96, 128
+    dev = torch.device(DEV)
+    depth = torch.from_numpy((30 * rng.random((B, H, W))).astype(np.float32)).to(dev)
+    mask = torch.from_numpy((rng.random((B, H, W)) > 0.3).astype(np.uint8)).to(dev)
+    albedo = torch.from_numpy(rng.random((B, 3, H, W), dtype=np.float32)).to(dev)
+    light = torch.from_numpy(rng.standard_normal((B, 2, 3)).astype(np.float32)).to(dev)
+    amb = torch.from_numpy(rng.random((B, 2), dtype=np.float32)).to(dev)
+    K = camera(1570.0, H, W).to(dev)
+    prm = RenderParams(n_samples=64, dt=0.0125)
+    n = depth_to_normals(depth[:, None], K, z_offset=1610.0)
+    a = R.render_fwd(depth, mask, light, amb, n, albedo, prm, want_argmin=True)
+    b = R.render_fwd(depth, mask, light, amb, None, albedo, prm, want_argmin=True,
+                     camera=(1570.0, 1570.0, W / 2.0, H / 2.0, 1610.0))
+    for k in ("minimum_distance", "argmin", "shadow_mask_weights", "full_shading", "final_shading", "rendered_images"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(b["surface_normals"], n)
+    with torch.no_grad():
+        r = R.render_from_depth(depth[:, None], albedo, light[:, 0], amb[:, 0], K, 1610.0, mask, prm)
+    assert torch.equal(r["rendered_images"], a["rendered_images"][:, 0])
+    assert torch.equal(r["surface_normals"], n)
