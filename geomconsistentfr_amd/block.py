@@ -349,23 +349,87 @@ class GraphedRenderFwd:
         return self.out
 
 
+class _RenderFromDepthFunction(torch.autograd.Function):
+    """Whole T8:353-522 seam, one light per image, differentiable w.r.t. depth, albedo, light, ambient.
+    Forward: gcfr_render_from_depth_fwd (two launches).  Backward: gcfr_render_bwd (one launch: shading,
+    ray-march and normals-stencil backward fused per pixel) + gcfr_light_prep_bwd."""
+
+    @staticmethod
+    def forward(ctx, depth, albedo, light, ambient, mask_u8, cam, params):
+        B, _, H, W = depth.shape
+        depth3 = _f32c(depth).reshape(B, H, W)
+        light2 = _f32c(light).reshape(B, 3)
+        amb = _f32c(ambient).reshape(B, 1)
+        albedo_c = _f32c(albedo)
+        need_grad = any(ctx.needs_input_grad[:4])
+        o = render_fwd(depth3, mask_u8, light2.reshape(B, 1, 3), amb, None, albedo_c, params,
+                       want_argmin=need_grad, camera=cam)
+        ctx.params, ctx.cam = params, cam
+        if need_grad:
+            ctx.save_for_backward(depth3, albedo_c, light2, amb, o["light_pt"].reshape(B, 3), o["minimum_distance"],
+                                  o["argmin"])
+        md0 = o["minimum_distance"][:, 0]
+        ctx.mark_non_differentiable(md0)
+        return (o["shadow_mask_weights"][:, 0], o["full_shading"][:, 0], o["final_shading"][:, 0],
+                o["rendered_images"][:, 0], o["unit_light_direction"].reshape(B, 3), o["surface_normals"], md0)
+
+    @staticmethod
+    def backward(ctx, g_w, g_full, g_fin, g_ren, g_unit, g_nrm, _g_md):
+        depth3, albedo, light2, amb, pt, md, am = ctx.saved_tensors
+        prm, cam = ctx.params, ctx.cam
+        L_ = _lib.load()
+        B, H, W = depth3.shape
+        dev = depth3.device
+        gw, gfull, gfin, gren, gnrm = [None if g is None else _f32c(g) for g in (g_w, g_full, g_fin, g_ren, g_nrm)]
+        grad_albedo = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+        grad_depth = _zeros((B, H, W), torch.float32, dev)
+        grad_pt = _zeros((B, 1, 3), torch.float64, dev)
+        grad_amb = _zeros((B, 1), torch.float64, dev)
+        grad_light = torch.empty((B, 3), dtype=torch.float32, device=dev)
+        tt = sample_table(prm, dev)
+        fx, fy, cx, cy, z_off = cam
+        with torch.cuda.device(dev):
+            st = _stream_ptr(dev)
+            _lib.check(L_.gcfr_render_bwd(depth3.data_ptr(), albedo.data_ptr(), pt.data_ptr(), amb.data_ptr(),
+                                          md.data_ptr(), am.data_ptr(), B, 1, H, W, prm.n_samples, tt.data_ptr(),
+                                          fx, fy, cx, cy, z_off, 1, float(prm.directional_intensity),
+                                          _opt_ptr(gw), _opt_ptr(gfull), _opt_ptr(gfin), _opt_ptr(gren), _opt_ptr(gnrm),
+                                          grad_albedo.data_ptr(), grad_depth.data_ptr(), grad_pt.data_ptr(),
+                                          grad_amb.data_ptr(), st), "gcfr_render_bwd")
+            gu = None if g_unit is None else _f32c(g_unit).reshape(B, 3)
+            clamp = prm.clamp_light_z_min is not None
+            _lib.check(L_.gcfr_light_prep_bwd(light2.data_ptr(), B, int(clamp), float(prm.clamp_light_z_min or 0.0),
+                                              float(prm.light_distance), _opt_ptr(gu), grad_pt.data_ptr(),
+                                              grad_light.data_ptr(), st), "gcfr_light_prep_bwd")
+        return (grad_depth.reshape(B, 1, H, W), grad_albedo, grad_light, grad_amb.reshape(B).float(), None, None, None)
+
+
 def render_from_depth(depth, albedo, light, ambient, camera_matrix, z_offset, mask,
                       params: RenderParams = RenderParams()):
     """The whole T8:353-522 seam for one light per image: normals from depth, shading, ray march, composite.
-    With autograd active the normals come from the differentiable `depth_to_normals` op and `render()`; under
-    no_grad (inference) everything runs in the two-launch fused forward (`gcfr_render_from_depth_fwd`).
+    Two launches forward (`gcfr_render_from_depth_fwd`: prepass, march with normals + shading in its epilogue) and,
+    with autograd active, one fused backward launch (`gcfr_render_bwd`) plus the tiny light-prep backward.
     Same dict as `render()` plus "surface_normals" (unit, y negated)."""
     from .normals import depth_to_normals
     B, _, H, W = depth.shape
     needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (depth, albedo, light, ambient))
     K = camera_matrix.detach().to("cpu", torch.float64)
     per_image_K = K.shape[0] != 1 and not bool((K == K[:1]).all())
-    if needs_grad or per_image_K:
+    if per_image_K:  # per-image camera matrices: the three-stage path handles them
         normals = depth_to_normals(depth, camera_matrix, z_offset=z_offset)
         r = render(depth, albedo, light, ambient, normals, mask, params)
         r["surface_normals"] = normals
         return r
     cam = (float(K[0, 0, 0]), float(K[0, 1, 1]), float(K[0, 0, 2]), float(K[0, 1, 2]), float(z_offset))
+    if needs_grad:
+        _require_device(depth, albedo, light, ambient, mask)
+        mask_u8 = mask_to_u8(mask).reshape(-1, H, W)
+        w, full, fin, ren, unit, nrm, md = _RenderFromDepthFunction.apply(
+            depth, albedo, light.reshape(B, 3), ambient.reshape(B), mask_u8, cam, params)
+        amb = ambient.to(torch.float32).reshape(B, 1, 1)
+        return dict(shadow_mask_weights=w, ambient_light=amb.expand(B, H, W), full_shading=full, rendered_images=ren,
+                    unit_light_direction=unit.reshape(B, 3, 1, 1), ambient_values=amb, final_shading=fin,
+                    minimum_distance=md, surface_normals=nrm)
     o = render_fwd(depth.reshape(B, H, W), mask.reshape(-1, H, W), light.reshape(B, 1, 3), ambient.reshape(B, 1),
                    None, albedo, params, want_argmin=False, camera=cam)
     amb = ambient.detach().to(torch.float32).reshape(B, 1, 1)

@@ -62,6 +62,133 @@ struct ShadowBwdArgs {
     int32_t L, H, W, N;
 };
 
+// Backward of the ray march for ONE pixel and light: re-evaluates the argmin sample k and applies the chain
+// rule (see the file header).  g32 = dLoss/d minimum_distance.  Scatters the depth gradients (five f32 atomics
+// into gz, the image's grad_depth plane) and returns the light-point gradient in gC.
+__device__ inline void shadow_bwd_pixel(const float *zimg, float *gz, const double *t_table, int H, int W,
+                                        int r, int c, float Cx, float Cy, float Cz, int k, float g32,
+                                        double (&gC)[3])
+{
+    const size_t p = (size_t)r * W + c;
+    const Box box = image_box(H, W);
+    const LightCase lc = classify_light(Cx, Cy, box);
+    const double halfW = W / 2.0, halfH = H / 2.0;
+    const float x = (float)c - W / 2.0f, y = H / 2.0f - (float)r;
+    const float zb = zimg[p];
+
+    // ---- forward recomputation at sample k (identical decisions to the forward kernel) ----
+    const float pden = (Cx - x) + kEps4;
+    const float m = (Cy - y) / pden;
+    const float ic = Cy - m * Cx;
+    float Ex, Ey;
+    end_point(x, y, Cx, Cy, box, lc, Ex, Ey);
+    // which candidate produced E, and whether the clamp cut it (zero gradient then)
+    //   kind 0: constant (light inside the image)   kind 1: X candidate (xb, m*xb+ic)
+    //   kind 2: Y candidate ((yb-ic)/(m+e), yb)
+    int kind;
+    float xb = 0.0f, yb = 0.0f;
+    if (lc.xcase == 1) {
+        kind = (lc.ycase == 1) ? 0 : 2;
+        yb = (lc.ycase == 0) ? box.y_lo : box.y_hi;
+    } else {
+        xb = (lc.xcase == 0) ? box.x_lo : box.x_hi;
+        if (lc.ycase == 1) {
+            kind = 1;
+        } else {
+            yb = (lc.ycase == 0) ? box.y_lo : box.y_hi;
+            const float Yx = (yb - ic) / (m + kEps4);
+            kind = (Yx >= box.x_lo && Yx <= box.x_hi) ? 2 : 1;
+        }
+    }
+    // unclamped candidate values, to detect the clamp (T8:462-465)
+    float ux_raw, uy_raw;
+    if (kind == 0) {
+        ux_raw = Cx;
+        uy_raw = Cy;
+    } else if (kind == 1) {
+        ux_raw = xb;
+        uy_raw = m * xb + ic;
+    } else {
+        ux_raw = (yb - ic) / (m + kEps4);
+        uy_raw = yb;
+    }
+    const bool live_x = !(ux_raw < box.x_lo) && !(ux_raw > box.x_hi);
+    const bool live_y = !(uy_raw < box.y_lo) && !(uy_raw > box.y_hi);
+
+    const float dxf = Ex - x, dyf = Ey - y;
+    const double t = t_table[k];
+    const double sx = (double)x + t * (double)dxf;
+    const double sy = (double)y + t * (double)dyf;
+    const double ux = (sx + halfW) - 0.0001, uy = (halfH - sy) - 0.0001;
+    const double fxd = floor(ux), gxd = ceil(ux), fyd = floor(uy), gyd = ceil(uy);
+    int fx = (int)fxd, gx = (int)gxd, fy = (int)fyd, gy = (int)gyd;
+    fx += (fx >> 31) & W;
+    fy += (fy >> 31) & H;
+    const double wx0 = gxd - ux, wx1 = ux - fxd, wy0 = gyd - uy, wy1 = uy - fyd;
+    const size_t iUL = (size_t)fy * W + fx, iUR = (size_t)fy * W + gx;
+    const size_t iLL = (size_t)gy * W + fx, iLR = (size_t)gy * W + gx;
+    const double zUL = zimg[iUL], zUR = zimg[iUR], zLL = zimg[iLL], zLR = zimg[iLR];
+    const double up = zUL * wx0 + zUR * wx1, low = zLL * wx0 + zLR * wx1;
+    const double zA = up * wy0 + low * wy1;
+    const float Axf = (float)(ux - halfW), Ayf = (float)(halfH - uy), Azf = (float)zA;
+    const double BAx = (double)(Axf - x), BAy = (double)(Ayf - y), BAz = (double)(Azf - zb);
+    const double BCx = (double)(Cx - x), BCy = (double)(Cy - y), BCz = (double)(Cz - zb);
+    const double Xx = BAy * BCz - BAz * BCy, Xy = BAz * BCx - BAx * BCz, Xz = BAx * BCy - BAy * BCx;
+    const double num = sqrt(Xx * Xx + Xy * Xy + Xz * Xz + 1e-4);
+    const double den = sqrt(BCx * BCx + BCy * BCy + BCz * BCz + 1e-4);
+
+    // ---- chain rule ----
+    const double g = (double)g32;
+    const double dnum = g / den, dden = -g * num / (den * den);
+    const double s1 = dnum / num;  // d(|X|^2+eps)^(1/2) = X/num
+    const double dXx = s1 * Xx, dXy = s1 * Xy, dXz = s1 * Xz;
+    const double s2 = dden / den;
+    double dBCx = s2 * BCx, dBCy = s2 * BCy, dBCz = s2 * BCz;
+    // X = BA x BC:  dBA = BC x dX ;  dBC += dX x BA
+    const double dBAx = BCy * dXz - BCz * dXy;
+    const double dBAy = BCz * dXx - BCx * dXz;
+    const double dBAz = BCx * dXy - BCy * dXx;
+    dBCx += dXy * BAz - dXz * BAy;
+    dBCy += dXz * BAx - dXx * BAz;
+    dBCz += dXx * BAy - dXy * BAx;
+    // B = (x, y, zb): only zb is differentiable
+    const double dzb = -dBAz - dBCz;
+    gC[0] = dBCx;
+    gC[1] = dBCy;
+    gC[2] = dBCz;
+    // A = (u_x - W/2, H/2 - u_y, zA)
+    const double dzA = dBAz;
+    const double dzA_dux = wy0 * (zUR - zUL) + wy1 * (zLR - zLL);
+    const double dzA_duy = low - up;
+    const double dux = dBAx + dzA * dzA_dux;
+    const double duy = -dBAy + dzA * dzA_duy;
+    // u_x = s_x + W/2 - e ;  u_y = H/2 - s_y - e ;  s = start + t*(E - start)
+    const double dEx = live_x ? t * dux : 0.0;
+    const double dEy = live_y ? -t * duy : 0.0;
+    double dm = 0.0, dic = 0.0;
+    if (kind == 1) {  // E = (xb, m*xb + ic)
+        dm = dEy * (double)xb;
+        dic = dEy;
+    } else if (kind == 2) {  // E = ((yb - ic)/(m + e), yb)
+        const double q = (double)(m + kEps4);
+        dic = -dEx / q;
+        dm = -dEx * (double)ux_raw / q;
+    }
+    // ic = Cy - m*Cx ;  m = (Cy - y)/(Cx - x + e)
+    gC[1] += dic;
+    dm += -dic * (double)Cx;
+    gC[0] += -dic * (double)m;
+    gC[1] += dm / (double)pden;
+    gC[0] += -dm * (double)m / (double)pden;
+
+    // depth: four bilinear corners + the pixel's own depth
+    atomicAdd(gz + iUL, (float)(dzA * wx0 * wy0));
+    atomicAdd(gz + iUR, (float)(dzA * wx1 * wy0));
+    atomicAdd(gz + iLL, (float)(dzA * wx0 * wy1));
+    atomicAdd(gz + iLR, (float)(dzA * wx1 * wy1));
+    atomicAdd(gz + p, (float)dzb);
+}
+
 __global__ __launch_bounds__(256) void shadow_bwd_kernel(ShadowBwdArgs a)
 {
     const int H = a.H, W = a.W;
@@ -76,126 +203,8 @@ __global__ __launch_bounds__(256) void shadow_bwd_kernel(ShadowBwdArgs a)
         const float g32 = a.grad_min_dist[(size_t)bl * P + p];
         if (k >= 0 && k < a.N && g32 != 0.0f) {
             const int r = (int)(p / W), c = (int)(p - (size_t)r * W);
-            const float *zimg = a.depth + (size_t)b * P;
-            float *gz = a.grad_depth + (size_t)b * P;
-            const float Cx = a.light_pt[3 * bl + 0], Cy = a.light_pt[3 * bl + 1], Cz = a.light_pt[3 * bl + 2];
-            const Box box = image_box(H, W);
-            const LightCase lc = classify_light(Cx, Cy, box);
-            const double halfW = W / 2.0, halfH = H / 2.0;
-            const float x = (float)c - W / 2.0f, y = H / 2.0f - (float)r;
-            const float zb = zimg[p];
-
-            // ---- forward recomputation at sample k (identical decisions to the forward kernel) ----
-            const float pden = (Cx - x) + kEps4;
-            const float m = (Cy - y) / pden;
-            const float ic = Cy - m * Cx;
-            float Ex, Ey;
-            end_point(x, y, Cx, Cy, box, lc, Ex, Ey);
-            // which candidate produced E, and whether the clamp cut it (zero gradient then)
-            //   kind 0: constant (light inside the image)   kind 1: X candidate (xb, m*xb+ic)
-            //   kind 2: Y candidate ((yb-ic)/(m+e), yb)
-            int kind;
-            float xb = 0.0f, yb = 0.0f;
-            if (lc.xcase == 1) {
-                kind = (lc.ycase == 1) ? 0 : 2;
-                yb = (lc.ycase == 0) ? box.y_lo : box.y_hi;
-            } else {
-                xb = (lc.xcase == 0) ? box.x_lo : box.x_hi;
-                if (lc.ycase == 1) {
-                    kind = 1;
-                } else {
-                    yb = (lc.ycase == 0) ? box.y_lo : box.y_hi;
-                    const float Yx = (yb - ic) / (m + kEps4);
-                    kind = (Yx >= box.x_lo && Yx <= box.x_hi) ? 2 : 1;
-                }
-            }
-            // unclamped candidate values, to detect the clamp (T8:462-465)
-            float ux_raw, uy_raw;
-            if (kind == 0) {
-                ux_raw = Cx;
-                uy_raw = Cy;
-            } else if (kind == 1) {
-                ux_raw = xb;
-                uy_raw = m * xb + ic;
-            } else {
-                ux_raw = (yb - ic) / (m + kEps4);
-                uy_raw = yb;
-            }
-            const bool live_x = !(ux_raw < box.x_lo) && !(ux_raw > box.x_hi);
-            const bool live_y = !(uy_raw < box.y_lo) && !(uy_raw > box.y_hi);
-
-            const float dxf = Ex - x, dyf = Ey - y;
-            const double t = a.t_table[k];
-            const double sx = (double)x + t * (double)dxf;
-            const double sy = (double)y + t * (double)dyf;
-            const double ux = (sx + halfW) - 0.0001, uy = (halfH - sy) - 0.0001;
-            const double fxd = floor(ux), gxd = ceil(ux), fyd = floor(uy), gyd = ceil(uy);
-            int fx = (int)fxd, gx = (int)gxd, fy = (int)fyd, gy = (int)gyd;
-            fx += (fx >> 31) & W;
-            fy += (fy >> 31) & H;
-            const double wx0 = gxd - ux, wx1 = ux - fxd, wy0 = gyd - uy, wy1 = uy - fyd;
-            const size_t iUL = (size_t)fy * W + fx, iUR = (size_t)fy * W + gx;
-            const size_t iLL = (size_t)gy * W + fx, iLR = (size_t)gy * W + gx;
-            const double zUL = zimg[iUL], zUR = zimg[iUR], zLL = zimg[iLL], zLR = zimg[iLR];
-            const double up = zUL * wx0 + zUR * wx1, low = zLL * wx0 + zLR * wx1;
-            const double zA = up * wy0 + low * wy1;
-            const float Axf = (float)(ux - halfW), Ayf = (float)(halfH - uy), Azf = (float)zA;
-            const double BAx = (double)(Axf - x), BAy = (double)(Ayf - y), BAz = (double)(Azf - zb);
-            const double BCx = (double)(Cx - x), BCy = (double)(Cy - y), BCz = (double)(Cz - zb);
-            const double Xx = BAy * BCz - BAz * BCy, Xy = BAz * BCx - BAx * BCz, Xz = BAx * BCy - BAy * BCx;
-            const double num = sqrt(Xx * Xx + Xy * Xy + Xz * Xz + 1e-4);
-            const double den = sqrt(BCx * BCx + BCy * BCy + BCz * BCz + 1e-4);
-
-            // ---- chain rule ----
-            const double g = (double)g32;
-            const double dnum = g / den, dden = -g * num / (den * den);
-            const double s1 = dnum / num;  // d(|X|^2+eps)^(1/2) = X/num
-            const double dXx = s1 * Xx, dXy = s1 * Xy, dXz = s1 * Xz;
-            const double s2 = dden / den;
-            double dBCx = s2 * BCx, dBCy = s2 * BCy, dBCz = s2 * BCz;
-            // X = BA x BC:  dBA = BC x dX ;  dBC += dX x BA
-            const double dBAx = BCy * dXz - BCz * dXy;
-            const double dBAy = BCz * dXx - BCx * dXz;
-            const double dBAz = BCx * dXy - BCy * dXx;
-            dBCx += dXy * BAz - dXz * BAy;
-            dBCy += dXz * BAx - dXx * BAz;
-            dBCz += dXx * BAy - dXy * BAx;
-            // B = (x, y, zb): only zb is differentiable
-            const double dzb = -dBAz - dBCz;
-            gC[0] = dBCx;
-            gC[1] = dBCy;
-            gC[2] = dBCz;
-            // A = (u_x - W/2, H/2 - u_y, zA)
-            const double dzA = dBAz;
-            const double dzA_dux = wy0 * (zUR - zUL) + wy1 * (zLR - zLL);
-            const double dzA_duy = low - up;
-            const double dux = dBAx + dzA * dzA_dux;
-            const double duy = -dBAy + dzA * dzA_duy;
-            // u_x = s_x + W/2 - e ;  u_y = H/2 - s_y - e ;  s = start + t*(E - start)
-            const double dEx = live_x ? t * dux : 0.0;
-            const double dEy = live_y ? -t * duy : 0.0;
-            double dm = 0.0, dic = 0.0;
-            if (kind == 1) {  // E = (xb, m*xb + ic)
-                dm = dEy * (double)xb;
-                dic = dEy;
-            } else if (kind == 2) {  // E = ((yb - ic)/(m + e), yb)
-                const double q = (double)(m + kEps4);
-                dic = -dEx / q;
-                dm = -dEx * (double)ux_raw / q;
-            }
-            // ic = Cy - m*Cx ;  m = (Cy - y)/(Cx - x + e)
-            gC[1] += dic;
-            dm += -dic * (double)Cx;
-            gC[0] += -dic * (double)m;
-            gC[1] += dm / (double)pden;
-            gC[0] += -dm * (double)m / (double)pden;
-
-            // depth: four bilinear corners + the pixel's own depth
-            atomicAdd(gz + iUL, (float)(dzA * wx0 * wy0));
-            atomicAdd(gz + iUR, (float)(dzA * wx1 * wy0));
-            atomicAdd(gz + iLL, (float)(dzA * wx0 * wy1));
-            atomicAdd(gz + iLR, (float)(dzA * wx1 * wy1));
-            atomicAdd(gz + p, (float)dzb);
+            shadow_bwd_pixel(a.depth + (size_t)b * P, a.grad_depth + (size_t)b * P, a.t_table, H, W, r, c,
+                             a.light_pt[3 * bl + 0], a.light_pt[3 * bl + 1], a.light_pt[3 * bl + 2], k, g32, gC);
         }
     }
     block_reduce_atomic<3>(gC, a.grad_light_pt + 3 * (size_t)bl);
@@ -212,11 +221,19 @@ struct ShadeBwdArgs {
     float *grad_depth;     // (B,H,W)    +=
     double *grad_light_pt; // (B,L,3)    +=
     double *grad_ambient;  // (B,L)      +=
-    float *grad_min_dist;  // (B,L,H,W)  =
+    float *grad_min_dist;  // (B,L,H,W)  =   (optional in the fused form)
     int32_t L, H, W;
     float intensity;
+    // fused form (FUSED = true): normals come from the depth stencil, grad_min_dist is consumed on the spot by
+    // the ray-march backward and grad_normals by the stencil backward -- one launch, no intermediate tensors
+    const int32_t *argmin;       // (B,L,H,W)
+    const double *t_table;       // (N)
+    int32_t N;
+    NormalsArgs nrm;
+    const float *g_normals_out;  // (B,3,H,W) upstream grad on the returned unit normals, may be null
 };
 
+template <bool FUSED>
 __global__ __launch_bounds__(256) void shade_bwd_kernel(ShadeBwdArgs a)
 {
     const int H = a.H, W = a.W, L = a.L;
@@ -227,10 +244,21 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(ShadeBwdArgs a)
     const size_t pp = live ? p : 0;
     const int r = (int)(pp / W), c = (int)(pp - (size_t)r * W);
     const float x = (float)c - W / 2.0f, y = H / 2.0f - (float)r;
-    const float zb = a.depth[(size_t)b * P + pp];
-    const double nx = a.normals[((size_t)b * 3 + 0) * P + pp];
-    const double ny = a.normals[((size_t)b * 3 + 1) * P + pp];
-    const double nz = a.normals[((size_t)b * 3 + 2) * P + pp];
+    const float *zimg = a.depth + (size_t)b * P;
+    float *gz = a.grad_depth + (size_t)b * P;
+    const float zb = zimg[pp];
+    double nx, ny, nz;
+    if (FUSED) {  // the f32 unit normal the forward epilogue fed to shade_pixel()
+        float n[3];
+        unit_normal(a.nrm, zimg, r, c, n);
+        nx = n[0];
+        ny = n[1];
+        nz = n[2];
+    } else {
+        nx = a.normals[((size_t)b * 3 + 0) * P + pp];
+        ny = a.normals[((size_t)b * 3 + 1) * P + pp];
+        nz = a.normals[((size_t)b * 3 + 2) * P + pp];
+    }
     double nn = sqrt(nx * nx + ny * ny + nz * nz);
     nn = nn > 1e-12 ? nn : 1e-12;
     const double n0 = nx / nn, n1 = ny / nn, n2 = nz / nn;
@@ -272,7 +300,20 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(ShadeBwdArgs a)
             const double dfull = dfin * w + (a.g_full ? (double)a.g_full[o] : 0.0);
             red[3] = dfin * (1.0 - w) + dfull;  // ambient enters final directly and through full
             // w = 1 - 4e/(1+e)^2, e = exp(-d):  dw/dd = 4e(1-e)/(1+e)^3  (T8:517)
-            a.grad_min_dist[o] = (float)(dw * (4.0 * e * (1.0 - e)) / (ope * ope * ope));
+            const float gmd = (float)(dw * (4.0 * e * (1.0 - e)) / (ope * ope * ope));
+            if (a.grad_min_dist)
+                a.grad_min_dist[o] = gmd;
+            if (FUSED) {  // ray-march backward through the argmin sample, right here
+                const int k = a.argmin[o];
+                if (k >= 0 && k < a.N && gmd != 0.0f) {
+                    double gC[3];
+                    shadow_bwd_pixel(zimg, gz, a.t_table, H, W, r, c, a.light_pt[3 * bl + 0], a.light_pt[3 * bl + 1],
+                                     a.light_pt[3 * bl + 2], k, gmd, gC);
+                    red[0] += gC[0];
+                    red[1] += gC[1];
+                    red[2] += gC[2];
+                }
+            }
             // full = amb + I*max(dot,0)  (T8:366)
             const double ddot = (dot > 0.0) ? dfull * (double)a.intensity : 0.0;
             const double dn0 = ddot * u0, dn1 = ddot * u1, dn2 = ddot * u2;  // d n_hat
@@ -285,9 +326,9 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(ShadeBwdArgs a)
             // l_hat = l/|l|, l = C - P
             const double ud = u0 * du0 + u1 * du1 + u2 * du2;
             const double dl0 = (du0 - u0 * ud) / ln, dl1 = (du1 - u1 * ud) / ln, dl2 = (du2 - u2 * ud) / ln;
-            red[0] = dl0;
-            red[1] = dl1;
-            red[2] = dl2;
+            red[0] += dl0;
+            red[1] += dl1;
+            red[2] += dl2;
             gzb -= dl2;
         }
         // per-(image, light) reductions: light point and ambient
@@ -297,13 +338,23 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(ShadeBwdArgs a)
         block_reduce_atomic<1>(red1, a.grad_ambient + bl);
     }
     if (live) {
-        a.grad_normals[((size_t)b * 3 + 0) * P + p] = (float)gn0;
-        a.grad_normals[((size_t)b * 3 + 1) * P + p] = (float)gn1;
-        a.grad_normals[((size_t)b * 3 + 2) * P + p] = (float)gn2;
+        if (FUSED) {  // stencil backward: grad w.r.t. the unit normal (rounded to f32 as the unfused path stores it)
+            double h0 = (double)(float)gn0, h1 = (double)(float)gn1, h2 = (double)(float)gn2;
+            if (a.g_normals_out) {
+                h0 += a.g_normals_out[((size_t)b * 3 + 0) * P + p];
+                h1 += a.g_normals_out[((size_t)b * 3 + 1) * P + p];
+                h2 += a.g_normals_out[((size_t)b * 3 + 2) * P + p];
+            }
+            normals_bwd_pixel(a.nrm, zimg, gz, r, c, h0, h1, h2);
+        } else {
+            a.grad_normals[((size_t)b * 3 + 0) * P + p] = (float)gn0;
+            a.grad_normals[((size_t)b * 3 + 1) * P + p] = (float)gn1;
+            a.grad_normals[((size_t)b * 3 + 2) * P + p] = (float)gn2;
+        }
         a.grad_albedo[((size_t)b * 3 + 0) * P + p] = (float)ga0;
         a.grad_albedo[((size_t)b * 3 + 1) * P + p] = (float)ga1;
         a.grad_albedo[((size_t)b * 3 + 2) * P + p] = (float)ga2;
-        atomicAdd(a.grad_depth + (size_t)b * P + p, (float)gzb);
+        atomicAdd(gz + p, (float)gzb);
     }
 }
 
@@ -389,11 +440,81 @@ extern "C" int gcfr_shade_bwd(const float *normals, const float *depth, const fl
         return GCFR_ERR_INVALID_ARGUMENT;
     if (B <= 0 || L <= 0 || H <= 0 || W <= 0 || B > 65535)
         return GCFR_ERR_INVALID_ARGUMENT;
-    ShadeBwdArgs a{normals, depth, albedo, light_pt, ambient, min_dist, g_shadow_w, g_full, g_final,
-                   g_rendered, grad_normals, grad_albedo, grad_depth, grad_light_pt, grad_ambient,
-                   grad_min_dist, L, H, W, intensity};
+    ShadeBwdArgs a{};
+    a.normals = normals;
+    a.depth = depth;
+    a.albedo = albedo;
+    a.light_pt = light_pt;
+    a.ambient = ambient;
+    a.min_dist = min_dist;
+    a.g_w = g_shadow_w;
+    a.g_full = g_full;
+    a.g_final = g_final;
+    a.g_rendered = g_rendered;
+    a.grad_normals = grad_normals;
+    a.grad_albedo = grad_albedo;
+    a.grad_depth = grad_depth;
+    a.grad_light_pt = grad_light_pt;
+    a.grad_ambient = grad_ambient;
+    a.grad_min_dist = grad_min_dist;
+    a.L = L;
+    a.H = H;
+    a.W = W;
+    a.intensity = intensity;
     const size_t P = (size_t)H * W;
-    hipLaunchKernelGGL(shade_bwd_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0,
+    hipLaunchKernelGGL(shade_bwd_kernel<false>, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    return launch_status();
+}
+
+extern "C" int gcfr_render_bwd(const float *depth, const float *albedo, const float *light_pt,
+                               const float *ambient, const float *min_dist, const int32_t *argmin, int32_t B,
+                               int32_t L, int32_t H, int32_t W, int32_t N, const double *t_table, double fx,
+                               double fy, double cx, double cy, float z_offset, int32_t negate_y,
+                               float intensity, const float *g_shadow_w, const float *g_full,
+                               const float *g_final, const float *g_rendered, const float *g_normals_out,
+                               float *grad_albedo, float *grad_depth, double *grad_light_pt,
+                               double *grad_ambient, void *stream)
+{
+    if (!depth || !albedo || !light_pt || !ambient || !min_dist || !argmin || !t_table || !grad_albedo ||
+        !grad_depth || !grad_light_pt || !grad_ambient)
+        return GCFR_ERR_INVALID_ARGUMENT;
+    if (B <= 0 || L <= 0 || N <= 0 || H < 2 || W < 2 || H > 4096 || W > 4096 || (H & 1) || (W & 1) || B > 65535 ||
+        fx == 0.0 || fy == 0.0)
+        return GCFR_ERR_INVALID_ARGUMENT;
+    ShadeBwdArgs a{};
+    a.depth = depth;
+    a.albedo = albedo;
+    a.light_pt = light_pt;
+    a.ambient = ambient;
+    a.min_dist = min_dist;
+    a.g_w = g_shadow_w;
+    a.g_full = g_full;
+    a.g_final = g_final;
+    a.g_rendered = g_rendered;
+    a.grad_albedo = grad_albedo;
+    a.grad_depth = grad_depth;
+    a.grad_light_pt = grad_light_pt;
+    a.grad_ambient = grad_ambient;
+    a.L = L;
+    a.H = H;
+    a.W = W;
+    a.intensity = intensity;
+    a.argmin = argmin;
+    a.t_table = t_table;
+    a.N = N;
+    a.nrm.depth = depth;
+    a.nrm.H = H;
+    a.nrm.W = W;
+    a.nrm.fx = fx;
+    a.nrm.fy = fy;
+    a.nrm.cx = cx;
+    a.nrm.cy = cy;
+    a.nrm.z_offset = z_offset;
+    a.nrm.negate_y = negate_y;
+    a.g_normals_out = g_normals_out;
+    const size_t P = (size_t)H * W;
+    hipLaunchKernelGGL(shade_bwd_kernel<true>, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0,
                        (hipStream_t)stream, a);
     return launch_status();
 }

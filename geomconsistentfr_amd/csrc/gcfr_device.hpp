@@ -192,4 +192,50 @@ __device__ inline void unit_normal(const NormalsArgs &a, const float *z, int r, 
     n[2] = (float)(nz / nn);
 }
 
+// Backward of unit_normal() for one pixel: (g0,g1,g2) = dLoss/d(unit normal output, y already negated);
+// scatters dLoss/d depth to the eight stencil neighbours (f32 atomics into gz, the image's grad_depth plane).
+__device__ inline void normals_bwd_pixel(const NormalsArgs &a, const float *z, float *gz, int r, int c,
+                                         double g0, double g1_in, double g2)
+{
+    const Grad3 g = point_gradients(a, z, r, c);
+    const double cx_ = g.du[1] * g.dv[2] - g.du[2] * g.dv[1];
+    const double cy_ = g.du[2] * g.dv[0] - g.du[0] * g.dv[2];
+    const double cz_ = g.du[0] * g.dv[1] - g.du[1] * g.dv[0];
+    const double nrm = sqrt(cx_ * cx_ + cy_ * cy_ + cz_ * cz_);
+    const double nn = nrm > 1e-12 ? nrm : 1e-12;
+    const double n0 = cx_ / nn, n1 = cy_ / nn, n2 = cz_ / nn;
+    const double g1 = a.negate_y ? -g1_in : g1_in;
+    // n = c/|c|  (if |c| <= eps the denominator is the constant eps)
+    double dc0, dc1, dc2;
+    if (nrm > 1e-12) {
+        const double ng = n0 * g0 + n1 * g1 + n2 * g2;
+        dc0 = (g0 - n0 * ng) / nn;
+        dc1 = (g1 - n1 * ng) / nn;
+        dc2 = (g2 - n2 * ng) / nn;
+    } else {
+        dc0 = g0 / nn;
+        dc1 = g1 / nn;
+        dc2 = g2 / nn;
+    }
+    // c = du x dv:  d(du) = dv x dc,  d(dv) = dc x du
+    const double ddu[3] = {g.dv[1] * dc2 - g.dv[2] * dc1, g.dv[2] * dc0 - g.dv[0] * dc2, g.dv[0] * dc1 - g.dv[1] * dc0};
+    const double ddv[3] = {dc1 * g.du[2] - dc2 * g.du[1], dc2 * g.du[0] - dc0 * g.du[2], dc0 * g.du[1] - dc1 * g.du[0]};
+#pragma unroll
+    for (int dr = -1; dr <= 1; ++dr) {
+#pragma unroll
+        for (int dc = -1; dc <= 1; ++dc) {
+            const double ku = kSobelU[dr + 1][dc + 1], kv = kSobelV[dr + 1][dc + 1];
+            if (ku == 0.0 && kv == 0.0)
+                continue;
+            const int rr = min(max(r + dr, 0), a.H - 1), cc = min(max(c + dc, 0), a.W - 1);
+            const double ax = ((double)cc - a.cx) / a.fx, ay = ((double)rr - a.cy) / a.fy;
+            // P_j = (ax*d, ay*d, d):  dd_j = ax*dP_x + ay*dP_y + dP_z,  dP = ku*d(du) + kv*d(dv)
+            const double dPx = ku * ddu[0] + kv * ddv[0];
+            const double dPy = ku * ddu[1] + kv * ddv[1];
+            const double dPz = ku * ddu[2] + kv * ddv[2];
+            atomicAdd(gz + (size_t)rr * a.W + cc, (float)(ax * dPx + ay * dPy + dPz));
+        }
+    }
+}
+
 }  // namespace gcfr

@@ -159,3 +159,71 @@ def test_backward_is_repeatable_within_atomic_jitter():
     scale = np.abs(a[0]).max()
     assert np.abs(a[0] - b[0]).max() <= 1e-6 * scale          # f32 atomics: order jitter only
     np.testing.assert_allclose(a[2], b[2], rtol=1e-6)
+
+
+def _run_fused(case, which, seed):
+    """Same as _run_hip but through render_from_depth: fused forward (normals in the march epilogue) and the
+    single fused backward launch (gcfr_render_bwd)."""
+    from geomconsistentfr_amd.block import render_from_depth
+    depth = _leaf(case["depth"][:, None])
+    alb, light, amb = _leaf(case["albedo"]), _leaf(case["light"]), _leaf(case["ambient"])
+    o = render_from_depth(depth, alb, light, amb, camera(1570.0).to(dev()), 1610.0,
+                          torch.from_numpy(case["mask"]).to(dev()))
+    rng = np.random.default_rng(seed)
+    G_r = torch.from_numpy(rng.random((3, 3, H, W), dtype=np.float32)).to(dev())
+    G_w = torch.from_numpy(rng.random((3, H, W), dtype=np.float32)).to(dev())
+    loss = (o["shadow_mask_weights"] * G_w).sum()
+    if which == "full":
+        loss = loss + (o["rendered_images"] * G_r).sum()
+    loss.backward()
+    return depth.grad[:, 0].cpu().numpy(), alb.grad, light.grad.cpu().numpy(), amb.grad.cpu().numpy()
+
+
+def test_fused_backward_matches_reference_autograd():
+    name, case = next(t8_batches())
+    exp = case["expect"]
+    gd, ga, gl, gamb = _run_fused(case, "full", int(exp["grad_full_seed"]))
+    _check_depth_grad(gd, exp["grad_full_depth"])
+    l4 = exp["grad_full_light4"]
+    np.testing.assert_allclose(gl, l4[:, 1:4], rtol=1e-4, atol=1e-4 * np.abs(l4[:, 1:4]).max())
+    np.testing.assert_allclose(gamb, l4[:, 0], rtol=1e-5)
+    assert np.abs(ga[0].cpu().numpy() - exp["grad_full_albedo"]).max() <= 1e-5
+    gd2, _, gl2, _ = _run_fused(case, "shadow", int(exp["grad_shadow_seed"]))
+    _check_depth_grad(gd2, exp["grad_shadow_depth"])
+    l4s = exp["grad_shadow_light4"]
+    np.testing.assert_allclose(gl2, l4s[:, 1:4], rtol=1e-4, atol=1e-4 * np.abs(l4s[:, 1:4]).max())
+
+
+def test_fused_backward_equals_three_kernel_backward():
+    """One launch vs shade_bwd -> shadow_bwd -> normals_bwd: same device functions, so equal up to atomic order;
+    also with an upstream gradient on the returned normals."""
+    from geomconsistentfr_amd import render
+    from geomconsistentfr_amd.block import render_from_depth
+    from geomconsistentfr_amd.normals import depth_to_normals
+    rng = np.random.default_rng(21)
+    B, Hs, Ws = 2, 64, 96
+    r, c = np.mgrid[0:Hs, 0:Ws]
+    depth = np.stack([(15 * np.exp(-(((c - 40) / 20.0) ** 2 + ((r - 30) / 15.0) ** 2)) + rng.random((Hs, Ws))).astype(np.float32)
+                      for _ in range(B)])[:, None]
+    mask = (rng.random((B, Hs, Ws)) > 0.15).astype(np.uint8)
+    albedo = rng.random((B, 3, Hs, Ws), dtype=np.float32)
+    light = np.array([[0.3, 0.5, 0.8], [-0.9, 0.1, 0.2]], np.float32)
+    amb = np.array([0.45, 0.6], np.float32)
+    K = camera(800.0, Hs, Ws).to(dev())
+    G = {k: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev()) for k, s in
+         [("shadow_mask_weights", (B, Hs, Ws)), ("full_shading", (B, Hs, Ws)), ("final_shading", (B, Hs, Ws)),
+          ("rendered_images", (B, 3, Hs, Ws)), ("surface_normals", (B, 3, Hs, Ws))]}
+    grads = []
+    for fused in (True, False):
+        leaves = [_leaf(a) for a in (depth, albedo, light, amb)]
+        if fused:
+            o = render_from_depth(leaves[0], leaves[1], leaves[2], leaves[3], K, 900.0, torch.from_numpy(mask).to(dev()))
+        else:
+            n = depth_to_normals(leaves[0], K, z_offset=900.0)
+            o = render(leaves[0], leaves[1], leaves[2], leaves[3], n, torch.from_numpy(mask).to(dev()))
+            o["surface_normals"] = n
+        sum((o[k] * g).sum() for k, g in G.items()).backward()
+        grads.append([l.grad.cpu().numpy() for l in leaves])
+    for name, a, b in zip(["depth", "albedo", "light", "ambient"], *grads):
+        scale = max(np.abs(b).max(), 1e-6)
+        assert np.abs(a - b).max() <= 2e-6 * scale, (name, np.abs(a - b).max(), scale)
