@@ -4,7 +4,8 @@
 Metric (BASELINE.json): ray-steps/s (whole job) + relit faces/s on 256x256 faces, 160 march steps.
 Workload at N=1: BASELINE configs[1] -- batch of 8 synthetic 256x256 faces, one light each,
 forward-only shadow + shade.  One "step" = one pass of the hot path over one batch:
-gcfr_light_prep -> gcfr_shadow_fwd -> gcfr_shade_fwd, inputs resident in HBM.
+one gcfr_render_fwd enqueue (depth repack + light prep, then the ray march with the shading fused into
+its epilogue), inputs resident in HBM.  --from-depth also fuses the normals stencil (+3 %).
 ray_steps = B*L*H*W*N nominal, never "steps executed".
 
 Multi-GPU (`torchrun --nproc-per-node N bench.py --gpus N`): faces are independent, so each rank
@@ -172,6 +173,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--direct", action="store_true", help="A/B: direct-gather kernel (no workspace prepass)")
     ap.add_argument("--unfused", action="store_true", help="A/B: three separate entry points instead of gcfr_render_fwd")
+    ap.add_argument("--from-depth", action="store_true",
+                    help="also compute the normals (T8:353-354) inside the march epilogue instead of reading them "
+                         "(SURVEY 8d's 17.4 B/ray-step accounting counts normals as a 12 B/pixel input, the default)")
     ap.add_argument("--size", type=int, default=256, help="other workloads: image side (config 5: 512)")
     ap.add_argument("--lights", type=int, default=1, help="lights per face (config 5: 18)")
     ap.add_argument("--samples", type=int, default=160, help="march steps (config 5: 320)")
@@ -246,8 +250,10 @@ def main():
                                           use_workspace=not a.direct)
             out = R.shade(d_normals, d_depth, d_albedo, pt.reshape(B, Ll, 3), d_amb.reshape(B, Ll), md, prm)
         else:
-            out = R.render_fwd(d_depth, d_mask, d_light.reshape(B, Ll, 3), d_amb.reshape(B, Ll), d_normals, d_albedo,
-                               prm, want_argmin=False)
+            out = R.render_fwd(d_depth, d_mask, d_light.reshape(B, Ll, 3), d_amb.reshape(B, Ll),
+                               None if a.from_depth else d_normals, d_albedo, prm, want_argmin=False,
+                               camera=(1570.0 * Hh / 256.0, 1570.0 * Hh / 256.0, Ww / 2.0, Hh / 2.0, 1610.0)
+                               if a.from_depth else None)
         if timed:
             _lib.check(L_.gcfr_profile_events(None, None), "gcfr_profile_events")
         return out
