@@ -9,26 +9,15 @@ kornia 0.4.1's published algorithm --
     n = normalize(cross(dP/du, dP/dv))                                   F.normalize, eps 1e-12
 -- and everything downstream of it (shading given normals) is pinned by reference code.
 
-`depth_to_normals` is the product path: the HIP kernels gcfr_normals_fwd / gcfr_normals_bwd
-(csrc/gcfr_normals.hip) behind a torch.autograd.Function.  It has NO CPU path: host tensors or a missing
-library raise GcfrError.  `depth_to_normals_torch` states the same algorithm in torch ops; it is the readable
-specification the kernels are tested against and is never called by the product.
+`depth_to_normals` runs the HIP kernels gcfr_normals_fwd / gcfr_normals_bwd (csrc/gcfr_normals.hip) behind a
+torch.autograd.Function.  It has NO CPU path: host tensors or a missing library raise GcfrError.  The torch-op
+statement of the same algorithm the kernels are tested against lives with the test infrastructure
+(oracle/normals_restatement.py).  The RelightNet mirrors do not call this op: they use block.render_from_depth,
+where the same stencil is fused into the march kernel's epilogue and into the fused backward.
 """
 import torch
-import torch.nn.functional as F
 
 from . import _lib
-
-
-def _sobel(p):
-    """p (B,C,H,W) -> (d/du, d/dv), each (B,C,H,W); normalised Sobel with replicate padding."""
-    q = F.pad(p, [1, 1, 1, 1], mode="replicate")
-    tl, tc, tr = q[..., :-2, :-2], q[..., :-2, 1:-1], q[..., :-2, 2:]
-    ml, mr = q[..., 1:-1, :-2], q[..., 1:-1, 2:]
-    bl, bc, br = q[..., 2:, :-2], q[..., 2:, 1:-1], q[..., 2:, 2:]
-    du = ((tr - tl) + 2.0 * (mr - ml) + (br - bl)) / 8.0
-    dv = ((bl - tl) + 2.0 * (bc - tc) + (br - tr)) / 8.0
-    return du, dv
 
 
 class _NormalsFunction(torch.autograd.Function):
@@ -66,29 +55,10 @@ def depth_to_normals(depth: torch.Tensor, camera_matrix: torch.Tensor, negate_y:
     Device tensors only (HIP kernels); there is no CPU path."""
     if not depth.is_cuda:
         raise _lib.GcfrError("geomconsistentfr_amd has no CPU path: depth must be on a ROCm device "
-                             "(depth_to_normals_torch is the host-side specification used by the tests)")
+                             "(oracle/normals_restatement.py is the host-side specification used by the tests)")
     K = camera_matrix.detach().to("cpu", torch.float64)          # tiny; the reference builds it on the host (T8:571)
     if K.shape[0] != 1 and not bool((K == K[:1]).all()):
         return torch.cat([depth_to_normals(depth[i:i + 1], camera_matrix[i:i + 1], negate_y, z_offset)
                           for i in range(depth.shape[0])])
     fx, fy, cx, cy = (float(K[0, 0, 0]), float(K[0, 1, 1]), float(K[0, 0, 2]), float(K[0, 1, 2]))
     return _NormalsFunction.apply(depth, fx, fy, cx, cy, z_offset, negate_y)
-
-
-def depth_to_normals_torch(depth: torch.Tensor, camera_matrix: torch.Tensor, negate_y: bool = True) -> torch.Tensor:
-    """Torch-op statement of the same algorithm (any device, differentiable by autograd).  Specification /
-    test reference only -- not called by the product."""
-    B, _, H, W = depth.shape
-    K = camera_matrix.to(device=depth.device)
-    ct = torch.promote_types(depth.dtype, K.dtype)            # the reference's K is f64 -> f64 maths
-    d = depth.to(ct)
-    u = torch.arange(W, dtype=ct, device=depth.device).view(1, 1, 1, W)
-    v = torch.arange(H, dtype=ct, device=depth.device).view(1, 1, H, 1)
-    fx, fy = K[:, 0, 0].view(-1, 1, 1, 1).to(ct), K[:, 1, 1].view(-1, 1, 1, 1).to(ct)
-    cx, cy = K[:, 0, 2].view(-1, 1, 1, 1).to(ct), K[:, 1, 2].view(-1, 1, 1, 1).to(ct)
-    pts = torch.cat([(u - cx) / fx * d, (v - cy) / fy * d, d], dim=1)
-    du, dv = _sobel(pts)
-    n = F.normalize(torch.cross(du, dv, dim=1), dim=1, p=2)
-    if negate_y:
-        n = torch.cat([n[:, 0:1], -n[:, 1:2], n[:, 2:3]], dim=1)
-    return n.to(depth.dtype)
