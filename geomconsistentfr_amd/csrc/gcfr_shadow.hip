@@ -315,7 +315,8 @@ struct ShadowQuadArgs {
     float *min_dist;        // (B,L,H,W)
     int32_t *argmin;        // (B,L,H,W) or null
     int32_t mask_batch, B, L, H, W, N;
-    int32_t quads_x, quads_per_image;  // 4-tile block columns / blocks per (image, light)
+    int32_t quads_x, quads_y;  // grid x / y: 4-tile (or, k-split, 1-tile) block columns and tile rows
+    int32_t bl_offset;         // first (image, light) index of this launch (grid z is limited to 65535)
     float bonus, bx_lo, bx_hi, by_lo, by_hi;
     // fused shading epilogue (FUSE_SHADE): T8:364-369, 517-522 on the pixel the lane just marched
     const float *normals;   // (B,3,H,W)
@@ -355,17 +356,14 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
     const int k_lo = KSPLIT ? wave * chunk : 0;
     const int N = KSPLIT ? min(a.N, k_lo + chunk) : a.N;  // exclusive upper bound ("N" below)
 
-    // blockIdx -> (image, light, tile quad), image-major.  An XCD-affine remap (all blocks of an image
-    // on one XCD) was measured 12 % SLOWER at B=8 -- one image per XCD makes the slowest image set the
-    // kernel time, and the CU L1 already serves 99.7 % of the gathers -- so blocks stay round-robin.
-    const int per_image = a.quads_per_image * L;
-    const int b = blockIdx.x / per_image;
-    const int rem = blockIdx.x - b * per_image;
-    const int l = rem / a.quads_per_image;
-    const int q = rem - l * a.quads_per_image;
-    const int bl = b * L + l;
-    const int qy = q / a.quads_x, qx = q - qy * a.quads_x;
-
+    // 3-D grid: x = tile-quad column, y = tile row, z = (image, light) -- no integer divisions in the prologue,
+    // and the dispatch order (x fastest, z slowest) is image-major with row-major tiles.  An XCD-affine remap
+    // (all blocks of an image on one XCD) was measured 12 % SLOWER at B=8 -- one image per XCD makes the
+    // slowest image set the kernel time, and the CU L1 already serves the gathers -- so blocks stay round-robin.
+    const int qx = blockIdx.x, qy = blockIdx.y;
+    const int bl = a.bl_offset + (int)blockIdx.z;
+    const int b = bl / L;
+    const int l = bl - b * L;
     int r = qy * TILE_H + lane / TILE_W;
     int c = (qx * WAVES + (KSPLIT ? 0 : wave)) * TILE_W + (lane % TILE_W);
     const bool valid = (r < H) && (c < W);
@@ -450,15 +448,18 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
             const float Y0 = halfHf - (float)r_max - 0.51f, Y1 = halfHf - (float)r_min + 0.51f;
             float ta = -3.0e38f, tb = 3.0e38f;
             bool empty = !finite_ray;
+            // (v_rcp_f32, 1 ulp: the 0.01-pixel margin dwarfs it; four IEEE divisions cost ~50 VALU per wave)
             if (dxf != 0.0f) {
-                const float t1 = (X0 - x) / dxf, t2 = (X1 - x) / dxf;
+                const float inv = __builtin_amdgcn_rcpf(dxf);
+                const float t1 = (X0 - x) * inv, t2 = (X1 - x) * inv;
                 ta = fmaxf(ta, fminf(t1, t2));
                 tb = fminf(tb, fmaxf(t1, t2));
             } else {
                 empty = empty || (x < X0) || (x > X1);
             }
             if (dyf != 0.0f) {
-                const float t1 = (Y0 - y) / dyf, t2 = (Y1 - y) / dyf;
+                const float inv = __builtin_amdgcn_rcpf(dyf);
+                const float t1 = (Y0 - y) * inv, t2 = (Y1 - y) * inv;
                 ta = fmaxf(ta, fminf(t1, t2));
                 tb = fminf(tb, fmaxf(t1, t2));
             } else {
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
             }
             if (!empty && ta <= tb) {
                 const float t_first = (float)a.t_table[0];
-                const float inv_dt = (float)(a.N - 1) / ((float)a.t_table[a.N - 1] - t_first);
+                const float inv_dt = (float)(a.N - 1) * __builtin_amdgcn_rcpf((float)a.t_table[a.N - 1] - t_first);
                 const float ka = (ta - t_first) * inv_dt, kb = (tb - t_first) * inv_dt;
                 // clamp in float first: ta / tb may be +-3e38
                 lane_lo = (int)fminf(fmaxf(floorf(ka) - 1.0f, 0.0f), (float)a.N);
@@ -750,12 +751,10 @@ extern "C" int gcfr_profile_events(void *start, void *stop)
 }
 
 template <int TILE_W, int DEPTH, bool FUSE, bool KSPLIT>
-static void launch_quad5(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
-                         hipStream_t st)
+static void launch_quad5(const ShadowQuadArgs &a, bool even_half, bool want_argmin, dim3 grid, hipStream_t st)
 {
 #define GCFR_LAUNCH(E, A) \
-    hipLaunchKernelGGL((shadow_fwd_quad_kernel<TILE_W, E, A, DEPTH, FUSE, KSPLIT>), dim3(blocks), dim3(256), 0, \
-                       st, a)
+    hipLaunchKernelGGL((shadow_fwd_quad_kernel<TILE_W, E, A, DEPTH, FUSE, KSPLIT>), grid, dim3(256), 0, st, a)
     if (even_half) {
         if (want_argmin)
             GCFR_LAUNCH(true, true);
@@ -771,37 +770,38 @@ static void launch_quad5(const ShadowQuadArgs &a, bool even_half, bool want_argm
 }
 
 template <int TILE_W, int DEPTH, bool FUSE>
-static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
-                         hipStream_t st)
+static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argmin, dim3 grid, hipStream_t st)
 {
     if (a.ksplit)
-        launch_quad5<TILE_W, DEPTH, FUSE, true>(a, even_half, want_argmin, blocks, st);
+        launch_quad5<TILE_W, DEPTH, FUSE, true>(a, even_half, want_argmin, grid, st);
     else
-        launch_quad5<TILE_W, DEPTH, FUSE, false>(a, even_half, want_argmin, blocks, st);
+        launch_quad5<TILE_W, DEPTH, FUSE, false>(a, even_half, want_argmin, grid, st);
 }
 
 template <int TILE_W, int DEPTH>
-static void launch_quad3(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
-                         hipStream_t st)
+static void launch_quad3(const ShadowQuadArgs &a, bool even_half, bool want_argmin, dim3 grid, hipStream_t st)
 {
     if (a.rendered)
-        launch_quad4<TILE_W, DEPTH, true>(a, even_half, want_argmin, blocks, st);
+        launch_quad4<TILE_W, DEPTH, true>(a, even_half, want_argmin, grid, st);
     else
-        launch_quad4<TILE_W, DEPTH, false>(a, even_half, want_argmin, blocks, st);
+        launch_quad4<TILE_W, DEPTH, false>(a, even_half, want_argmin, grid, st);
 }
 
 template <int TILE_W>
-static void launch_quad(const ShadowQuadArgs &a, bool even_half, bool want_argmin, unsigned blocks,
-                        hipStream_t st)
+static void launch_quad(ShadowQuadArgs a, bool even_half, bool want_argmin, int total_bl, hipStream_t st)
 {
     if (g_ev_start)
         (void)hipEventRecord(g_ev_start, st);
-    if (g_depth == 1)
-        launch_quad3<TILE_W, 1>(a, even_half, want_argmin, blocks, st);
-    else if (g_depth == 2)
-        launch_quad3<TILE_W, 2>(a, even_half, want_argmin, blocks, st);
-    else
-        launch_quad3<TILE_W, 4>(a, even_half, want_argmin, blocks, st);
+    for (int z0 = 0; z0 < total_bl; z0 += 65535) {  // grid z is limited to 65535 (image, light) pairs per launch
+        a.bl_offset = z0;
+        const dim3 grid((unsigned)a.quads_x, (unsigned)a.quads_y, (unsigned)((total_bl - z0) < 65535 ? (total_bl - z0) : 65535));
+        if (g_depth == 1)
+            launch_quad3<TILE_W, 1>(a, even_half, want_argmin, grid, st);
+        else if (g_depth == 2)
+            launch_quad3<TILE_W, 2>(a, even_half, want_argmin, grid, st);
+        else
+            launch_quad3<TILE_W, 4>(a, even_half, want_argmin, grid, st);
+    }
     if (g_ev_stop)
         (void)hipEventRecord(g_ev_stop, st);
 }
@@ -871,9 +871,9 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         const bool ksplit = (g_ksplit < 0) ? (tiles_total <= 4096 && N >= 16) : (g_ksplit == 1);  // measured: helps B<=4 at 256^2
         a.ksplit = ksplit ? 1 : 0;
         a.quads_x = ksplit ? tiles_x : quads_x;
-        a.quads_per_image = a.quads_x * ((H + TILE_H - 1) / TILE_H);
-        const long long qblocks = (long long)B * L * a.quads_per_image;
-        if (qblocks > 0x7fffffffLL)
+        a.quads_y = (H + TILE_H - 1) / TILE_H;
+        a.bl_offset = 0;
+        if ((long long)B * L > 0x7fffffffLL / 4)
             return GCFR_ERR_INVALID_ARGUMENT;
         a.bonus = bonus;
         a.bx_lo = bx[0];
@@ -897,16 +897,16 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         const bool want = argmin != nullptr;
         switch (TILE_W) {
         case 8:
-            launch_quad<8>(a, even_half, want, (unsigned)qblocks, st);
+            launch_quad<8>(a, even_half, want, B * L, st);
             break;
         case 32:
-            launch_quad<32>(a, even_half, want, (unsigned)qblocks, st);
+            launch_quad<32>(a, even_half, want, B * L, st);
             break;
         case 64:
-            launch_quad<64>(a, even_half, want, (unsigned)qblocks, st);
+            launch_quad<64>(a, even_half, want, B * L, st);
             break;
         default:
-            launch_quad<16>(a, even_half, want, (unsigned)qblocks, st);
+            launch_quad<16>(a, even_half, want, B * L, st);
             break;
         }
         return launch_status();
