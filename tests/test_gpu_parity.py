@@ -75,7 +75,7 @@ def test_render_matches_reference_golden(name, case):
 
 @pytest.mark.parametrize("Hs,Ws,N,t0,dt", [(64, 64, 48, 0.025, 0.016), (48, 96, 37, 0.02, 0.02),
                                             (130, 70, 160, 0.025, 0.005), (256, 256, 160, 0.025, 0.005),
-                                            (512, 512, 320, 0.025, 0.0025)])
+                                            (512, 512, 320, 0.025, 0.0025), (1024, 2048, 12, 0.025, 0.06)])
 def test_shadow_matches_c_oracle(Hs, Ws, N, t0, dt):
     """min distance + argmin against the C oracle, including non-tile-multiple sizes and config 5's size."""
     import c_oracle
@@ -339,3 +339,24 @@ def test_forward_is_hipgraph_capturable():
     torch.cuda.synchronize()
     assert torch.equal(out2["rendered_images"], ref2["rendered_images"])
     assert torch.equal(out2["minimum_distance"], ref2["minimum_distance"])
+
+
+def test_maximum_supported_size():
+    """4096 x 4096 (the ABI's upper bound) with a short sample table: bit-equal to the oracle, both kernels."""
+    import c_oracle
+    from geomconsistentfr_amd import RenderParams, shadow_min_distance, light_prep
+    Hs = Ws = 4096
+    rng = np.random.default_rng(4096)
+    depth = (50 * rng.random((1, Hs, Ws), dtype=np.float32))
+    r, c = np.ogrid[0:Hs, 0:Ws]
+    mask = ((((c - 2000) / 1500.0) ** 2 + ((r - 2100) / 1800.0) ** 2) < 1).astype(np.uint8)[None]
+    light = np.array([[0.4, -0.3, 0.6]], np.float32)
+    prm = RenderParams(n_samples=4, t0=0.025, dt=0.2)
+    _, pt = light_prep(to_dev(light), prm)
+    md_o, am_o = c_oracle.shadow_min_distance(depth, mask, c_oracle.light_prep(light, clamp_z_min=0.0)[1][:, None, :],
+                                              c_oracle.sample_table(0.025, 0.2, 4))
+    for ws in (True, False):
+        md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt.reshape(1, 1, 3), prm, use_workspace=ws)
+        assert np.array_equal(md.cpu().numpy(), md_o), ws
+        lit = md_o < 1e5
+        assert np.array_equal(am.cpu().numpy()[lit], am_o[lit]), ws
