@@ -254,6 +254,71 @@ __device__ inline int wave_min_i32(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// float <-> int with the same ordering (so the integer DPP minimum above serves floats too)
+__device__ inline int f32_sortable(float f)
+{
+    const int i = __builtin_bit_cast(int, f);
+    return i ^ ((i >> 31) & 0x7fffffff);
+}
+__device__ inline float f32_unsortable(int i)
+{
+    return __builtin_bit_cast(float, i ^ ((i >> 31) & 0x7fffffff));
+}
+
+// ----------------------------------------------------------------------------------------------
+// Depth bounds ("hierarchical z") grid.  Tile (i, j) of stride s = 2^ls holds the minimum and maximum
+// depth over the 2s x 2s cells whose EXTENDED indices (row r+1, column c+1, with r = c = -1 the
+// reference's wrap-around to the last row / column) lie in [i*s, i*s + 2s) x [j*s, j*s + 2s): tiles
+// overlap by half, so any footprint of at most s+1 cells per axis lies inside the tile that its lowest
+// index selects.  The march uses it to skip sample groups that provably cannot lower a lane's running
+// minimum (see shadow_fwd_quad_kernel); s is the smallest power of two >= 4 that covers the cells one
+// group of `group` consecutive samples can touch, derived from the sample table on the device by both
+// kernels.  The host sizes the grid for s = 4.
+// ----------------------------------------------------------------------------------------------
+__device__ inline int zb_log2_stride(int H, int W, int N, const double *t_table, int group)
+{
+    if (N < 2)
+        return 2;
+    const float step = fabsf((float)((t_table[N - 1] - t_table[0]) / (double)(N - 1)));
+    const float fd = (float)(group - 1) * step * (float)max(H, W);  // rint(s) moves by <= floor(fd) + 1 cells
+    const int need = (int)fminf(fmaxf(fd, 0.0f), 1024.0f) + 3;      // + the cell either side (floor / ceil)
+    int ls = 2;
+    while ((1 << ls) < need && ls < 6)
+        ++ls;
+    return ls;
+}
+
+__host__ __device__ inline int zb_max_tiles(int H, int W) { return ((H >> 2) + 1) * ((W >> 2) + 1); }
+
+__global__ __launch_bounds__(256) void build_zbounds_kernel(const float *__restrict__ depth,
+                                                            float2 *__restrict__ zb, int H, int W, int N,
+                                                            const double *__restrict__ t_table, int group)
+{
+    const int ls = zb_log2_stride(H, W, N, t_table, group);
+    const int ntw = (W >> ls) + 1, nth = (H >> ls) + 1;
+    const int tile = blockIdx.x * 4 + (int)(threadIdx.x >> 6);  // one wave per tile
+    if (tile >= nth * ntw)
+        return;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int ti = tile / ntw, tj = tile - ti * ntw;
+    const int side = 2 << ls;
+    const float *z = depth + (size_t)b * H * W;
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+    for (int e = lane; e < side * side; e += 64) {
+        const int er = (ti << ls) + (e >> (ls + 1)), ec = (tj << ls) + (e & (side - 1));
+        if (er <= H && ec <= W) {
+            const int r = er == 0 ? H - 1 : er - 1, c = ec == 0 ? W - 1 : ec - 1;
+            const float v = z[(size_t)r * W + c];
+            lo = fminf(lo, v);  // NaN cells are ignored: a NaN sample never wins the minimum anyway
+            hi = fmaxf(hi, v);
+        }
+    }
+    const float wlo = f32_unsortable(wave_min_i32(f32_sortable(lo)));
+    const float whi = -f32_unsortable(wave_min_i32(f32_sortable(-hi)));
+    if (lane == 0)
+        zb[(size_t)b * zb_max_tiles(H, W) + tile] = make_float2(wlo, whi);
+}
+
 // Prepass.  Per image: (a) repack depth into 2x2-neighbourhood texels, (b) optional light preparation,
 // (c) per-block partial bounding boxes of the mask's non-zero cells as four minima
 // {r_min, c_min, -r_max, -c_max} (kBBoxInit where the block saw no non-zero cell).
@@ -309,6 +374,7 @@ struct ShadowQuadArgs {
     const float *depth;     // (B,H,W)      own-pixel depth
     const float4 *quad;     // (B,H+1,W+1)  prepass output
     const int *bbox;        // (MB,P/256,4) prepass output: partial mask bounding boxes {r_min, c_min, -r_max, -c_max}
+    const float2 *zb;       // (B,zb_max_tiles) prepass output: depth bounds grid, or null (bound skip off)
     const uint8_t *mask;    // (MB,H,W)
     const float *light_pt;  // (B,L,3)
     const double *t_table;  // (N)
@@ -485,6 +551,44 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
         k_end = ne;
     }
 
+    // Depth-bound skip (exact).  For the sample point A = (s_k, z) of this ray,
+    //     S_k >= Xx^2 + Xy^2 >= G^2,   G = n (z - zb) - BCz (BA_xy . u)/n,   u = BC_xy, n = |u|
+    // (Cauchy-Schwarz on the two cross-product components that involve z): n (z - zb) is how far the sampled
+    // surface is from the pixel's own depth and the second term how high the ray is there, both scaled by n.
+    // (BA_xy . u)/n is t_k (d . u)/n to within 7e-4 (the 1e-4 offset and the f32 roundings of T8:480-487), so
+    // over one group of samples and z in [zmin, zmax] -- the depth bounds of the cells the group can touch,
+    // from the prepass' grid -- |G| is at least `gap` below, evaluated at the group's first and last sample.
+    // The reference's bilinear weights are both 0 when a coordinate is integral, which samples z = 0: that
+    // isolated value is tested too (gap0).  K1 + K2 r over-estimates every rounding between G and the f32 S
+    // the body would compute (r bounds |BA|'s components); a lane votes "skip" only if the bound exceeds its
+    // running minimum by a further 0.1 %, so a skipped sample could not have been taken and the minimum,
+    // its index and the tie predecessor are what the full march gives.
+    const bool use_zb = a.zb != nullptr;
+    const int zls = use_zb ? __builtin_amdgcn_readfirstlane(zb_log2_stride(H, W, a.N, a.t_table, DEPTH)) : 2;
+    const int zntw = (W >> zls) + 1;
+    const __amdgpu_buffer_rsrc_t zr =
+        make_rsrc(a.zb + (size_t)b * zb_max_tiles(H, W), zb_max_tiles(H, W) * (int)sizeof(float2));
+    const float nrm = __builtin_sqrtf(BCx * BCx + BCy * BCy);
+    const float c1 = BCz * ((dxf * BCx + dyf * BCy) / nrm);
+    const float Qz = nrm * zb;
+    const float t_abs = fmaxf(fabsf((float)a.t_table[0]), fabsf((float)a.t_table[a.N - 1]));
+    float K1 = 4e-3f * fabsf(BCz) + 1e-6f * fabsf(c1) * t_abs;
+    const float K2 = 1e-6f * nrm + 2e-7f * ((fabsf(BCx) + fabsf(BCy)) + fabsf(BCz));
+    const float R0 = fmaxf(fabsf(zb), (float)max(H, W));
+    if (!(nrm > 0.0f) || !finite_ray || !(K1 - K1 == 0.0f))
+        K1 = __builtin_inff();  // never skips
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // bounds of the cells a group can touch, given the rounded cells of its first and last sample:
+    // floor(u) and ceil(u) lie in [rint(s) - 1, rint(s) + 1], so the extended indices are [min, max + 2]
+    auto zb_fetch = [&](int ca, int ra, int cb, int rb, bool &covered) -> f32x2 {
+        const int cmin = min(ca, cb), cmax = max(ca, cb), rmin = min(ra, rb), rmax = max(ra, rb);
+        const int tj = cmin >> zls, ti = rmin >> zls;
+        covered = (cmin >= 0) && (rmin >= 0) && (cmax <= W - 1) && (rmax <= H - 1) &&
+                  (cmax + 2 <= ((tj + 2) << zls) - 1) && (rmax + 2 <= ((ti + 2) << zls) - 1);
+        const int off = covered ? (__mul24(ti, zntw) + tj) << 3 : 0;
+        return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(zr, off, 0, 0));
+    };
+
     // Two-stage software pipeline.  Stage A (sample k+1): position, rounded cell, issue the mask byte
     // gather.  Stage B (sample k): if NO lane of the wave has an unmasked sample, the whole bilinear /
     // distance body is skipped -- masked samples only contribute "1e6" (T8:512), which `any_masked`
@@ -495,8 +599,7 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
         sx = x64 + t * dx64;            // T8:472 / 480 (f64, mul and add rounded separately)
         sy = y64 + t * dy64;
     };
-    auto mask_offset = [&](double sx, double sy) -> int {  // T8:472-477, 510
-        int col_r, row_r;
+    auto mask_offset = [&](double sx, double sy, int &col_r, int &row_r) -> int {  // T8:472-477, 510
         if (EVEN_HALF) {
             col_r = lo32(sx + Mx);  // rint(sx) + W/2
             row_r = lo32(My - sy);  // H/2 - rint(sy)
@@ -514,29 +617,54 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
     // (first) argmin, so the tail needs no branch.
     auto clampk = [&](int k) { return k < k_end ? k : k_end - 1; };
     uint32_t ring[DEPTH];
+    f32x2 ring_z = {0.0f, 0.0f};
+    bool ring_cov = false;
     if (k_begin < k_end) {
+        int cj[DEPTH], rj[DEPTH];
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
             double px, py;
             sample_pos(clampk(k_begin + j), px, py);
-            ring[j] = buf_load_u8(mr, mask_offset(px, py));
+            ring[j] = buf_load_u8(mr, mask_offset(px, py, cj[j], rj[j]));
         }
+        if (use_zb)
+            ring_z = zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1], ring_cov);
     }
 
     for (int k0 = k_begin; k0 < k_end; k0 += DEPTH) {
         uint32_t mk[DEPTH];
         bool none = true;
+        const f32x2 zbnd = ring_z;
+        const bool zcov = ring_cov;
+        {
+            int cj[DEPTH], rj[DEPTH];
 #pragma unroll
-        for (int j = 0; j < DEPTH; ++j) {
-            mk[j] = ring[j];
-            double px, py;  // gather the next group's mask bytes
-            sample_pos(clampk(k0 + DEPTH + j), px, py);
-            ring[j] = buf_load_u8(mr, mask_offset(px, py));
-            none = none && (mk[j] == 0);
-            any_masked |= (mk[j] == 0);
+            for (int j = 0; j < DEPTH; ++j) {
+                mk[j] = ring[j];
+                double px, py;  // gather the next group's mask bytes
+                sample_pos(clampk(k0 + DEPTH + j), px, py);
+                ring[j] = buf_load_u8(mr, mask_offset(px, py, cj[j], rj[j]));
+                none = none && (mk[j] == 0);
+                any_masked |= (mk[j] == 0);
+            }
+            if (use_zb)  // ... and its depth bounds
+                ring_z = zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1], ring_cov);
         }
         if (__builtin_amdgcn_ballot_w64(!none) == 0ull)
             continue;
+        if (use_zb) {
+            const float ta = (float)a.t_table[k0], tb = (float)a.t_table[clampk(k0 + DEPTH - 1)];
+            const float Ta = c1 * ta, Tb = c1 * tb;
+            const float Tlo = fminf(Ta, Tb), Thi = fmaxf(Ta, Tb);
+            const float Pmin = __builtin_fmaf(nrm, zbnd.x, -Qz), Pmax = __builtin_fmaf(nrm, zbnd.y, -Qz);
+            const float gap = fmaxf(Pmin - Thi, Tlo - Pmax);   // > 0 iff the ray clears [zmin, zmax] all along the group
+            const float gap0 = fmaxf(-Qz - Thi, Tlo + Qz);     // the same for the isolated value z = 0
+            const float rr = fmaxf(fmaxf(fabsf(zbnd.x - zb), fabsf(zbnd.y - zb)), R0);
+            const float g = fminf(gap, gap0) - __builtin_fmaf(K2, rr, K1);
+            const bool cannot_win = zcov && (g > 0.0f) && (g * g * 0.998f > bestS);
+            if (__builtin_amdgcn_ballot_w64(!none && !cannot_win) == 0ull)
+                continue;
+        }
         // phase 1: positions and texel gathers for the whole group (all in flight together)
         double ux[DEPTH], uy[DEPTH], fxd[DEPTH], fyd[DEPTH];
         f32x4 qv[DEPTH];
@@ -708,6 +836,7 @@ extern "C" int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_
 static int g_tile_w = 32;  // pixels per tile row: 8, 16, 32 or 64 (tile = 64/tile_w rows)
 static int g_depth = 4;    // samples per group (skip granularity / gathers in flight): 1, 2 or 4
 static int g_ksplit = -1;  // sample-range split over the 4 waves of a workgroup: 0 off, 1 on, -1 auto
+static int g_zbound = 1;   // depth-bound group skip (exact): 1 on, 0 off
 
 extern "C" int gcfr_tune(int32_t key, int32_t value)
 {
@@ -727,6 +856,11 @@ extern "C" int gcfr_tune(int32_t key, int32_t value)
             return GCFR_ERR_INVALID_ARGUMENT;
         g_ksplit = value;
         return GCFR_OK;
+    case 3:
+        if (value != 0 && value != 1)
+            return GCFR_ERR_INVALID_ARGUMENT;
+        g_zbound = value;
+        return GCFR_OK;
     default:
         return GCFR_ERR_INVALID_ARGUMENT;
     }
@@ -737,7 +871,8 @@ extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
     if (B <= 0 || H <= 0 || W <= 0)
         return 0;
     const size_t n_partials = ((size_t)H * W + 255) / 256;
-    return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4) + (size_t)B * n_partials * 4 * sizeof(int);
+    return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4) + (size_t)B * n_partials * 4 * sizeof(int) +
+           (size_t)B * (size_t)zb_max_tiles(H, W) * sizeof(float2);
 }
 
 // Optional profiling hook: events recorded around the dominant (march) kernel of the next launches.
@@ -850,7 +985,13 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         int *bbox = (int *)((char *)workspace + (size_t)B * texels * sizeof(float4));
         hipLaunchKernelGGL(build_quad_kernel, dim3((texels + 255) / 256, B), dim3(256), 0, st, depth,
                            (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox);
+        const size_t n_partials = ((size_t)H * W + 255) / 256;
+        float2 *zb = (float2 *)((char *)bbox + (size_t)B * n_partials * 4 * sizeof(int));
+        if (g_zbound && N >= 2)
+            hipLaunchKernelGGL(build_zbounds_kernel, dim3((zb_max_tiles(H, W) + 3) / 4, B), dim3(256), 0, st, depth,
+                               zb, H, W, N, t_table, g_depth == 1 || g_depth == 2 ? g_depth : 4);
         ShadowQuadArgs a;
+        a.zb = (g_zbound && N >= 2) ? zb : nullptr;
         a.depth = depth;
         a.quad = (const float4 *)workspace;
         a.bbox = bbox;

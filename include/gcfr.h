@@ -73,15 +73,18 @@ int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_z, float cl
  *   argmin      (B,L,H,W) i32 out   index of the minimising sample (saved for backward); may be NULL
  *   workspace   device scratch of >= gcfr_shadow_workspace_bytes(B,H,W) bytes, or NULL.
  *               With a workspace the depth maps are first repacked into 2x2-neighbourhood texels
- *               (one 16-byte gather per ray-step instead of four 4-byte gathers); results are
- *               bit-identical to the NULL-workspace path, only faster.  Contents are scratch.
+ *               (one 16-byte gather per ray-step instead of four 4-byte gathers) and a coarse grid of
+ *               depth minima / maxima lets the march skip sample groups that provably cannot lower a
+ *               pixel's running minimum; results are bit-identical to the NULL-workspace path, only
+ *               faster.  Contents are scratch.
  * Supported: 2 <= H,W <= 4096, even; 1 <= N <= 4096.
  */
 size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W);
 
 /* Tuning / A-B knob for experiments (process-wide; not needed in normal use; results never change):
  * key 0 = tile width {8,16,32,64} (default 32), key 1 = samples per skip group {1,2,4} (default 4),
- * key 2 = split each tile's sample range over the 4 waves of its workgroup {0,1,-1 = auto by launch size}. */
+ * key 2 = split each tile's sample range over the 4 waves of its workgroup {0,1,-1 = auto by launch size},
+ * key 3 = depth-bound group skip {0,1} (default 1). */
 int gcfr_tune(int32_t key, int32_t value);
 int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32_t mask_batch,
                     const float *light_pt, int32_t B, int32_t L, int32_t H, int32_t W, int32_t N,

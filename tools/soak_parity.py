@@ -29,6 +29,13 @@ def random_case(rng, H, W):
         depth += (3 * np.sin(c / rng.uniform(3, 9)) * np.cos(r / rng.uniform(3, 9))).astype(np.float32)
     elif kind == 2:
         depth = np.round(depth)                       # plateaus -> exact ties between samples
+    shift = rng.integers(0, 6)                        # depth sign / offset variants (exercise the depth-bound skip)
+    if shift == 1:
+        depth = -depth
+    elif shift == 2:
+        depth = depth - np.float32(0.15 * H)          # straddles zero
+    elif shift == 3:
+        depth = depth + np.float32(rng.choice([-1000.0, 1000.0]))
     mk = rng.integers(0, 4)
     if mk == 0:
         mask = rng.random((H, W)) > rng.uniform(0.05, 0.6)
