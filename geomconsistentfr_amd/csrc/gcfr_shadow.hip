@@ -76,7 +76,74 @@ struct RayConst {
     float x, y, zb;        // pixel B (T8:503)
     float dx, dy;          // end - start (T8:467)
     float BCx, BCy, BCz;   // light - pixel (T8:507)
+    double x64, y64, dx64, dy64, halfW, halfH;
+    int H, W;
 };
+
+__device__ inline float ray_sample(const RayConst &rc, double t, __amdgpu_buffer_rsrc_t zr,
+                                   __amdgpu_buffer_rsrc_t mr, bool &masked)
+{
+    const int W = rc.W, H = rc.H;
+    const double sx = rc.x64 + t * rc.dx64;  // T8:472 / 480 (f64, mul and add rounded separately)
+    const double sy = rc.y64 + t * rc.dy64;
+    // rounded cell -> mask lookup (T8:472-477, 510)
+    const int col_r = (int)(__builtin_rint(sx) + rc.halfW);
+    const int row_r = (int)(rc.halfH - __builtin_rint(sy));
+    // unrounded position (T8:480-487)
+    const double ux = (sx + rc.halfW) - 0.0001;
+    const double uy = (rc.halfH - sy) - 0.0001;
+    const double fxd = __builtin_floor(ux), gxd = __builtin_ceil(ux);
+    const double fyd = __builtin_floor(uy), gyd = __builtin_ceil(uy);
+    int fx = (int)fxd, gx = (int)gxd, fy = (int)fyd, gy = (int)gyd;
+    const double wx0 = gxd - ux, wx1 = ux - fxd;  // T8:492-494 weights
+    const double wy0 = gyd - uy, wy1 = uy - fyd;
+    fx += (fx >> 31) & W;  // index -1 wraps to W-1 / H-1 (T8:488-491)
+    fy += (fy >> 31) & H;
+    const int rowf = fy * W, rowg = gy * W;
+    const double zUL = buf_load_f32(zr, (rowf + fx) << 2);
+    const double zUR = buf_load_f32(zr, (rowf + gx) << 2);
+    const double zLL = buf_load_f32(zr, (rowg + fx) << 2);
+    const double zLR = buf_load_f32(zr, (rowg + gx) << 2);
+    const uint32_t mk = buf_load_u8(mr, row_r * W + col_r);
+    const double up = zUL * wx0 + zUR * wx1;
+    const double low = zLL * wx0 + zLR * wx1;
+    const double zA = up * wy0 + low * wy1;
+    // point A (T8:497-502) and the distance numerator (T8:504-509) in f32
+    const float Ax = (float)(ux - rc.halfW), Ay = (float)(rc.halfH - uy), Az = (float)zA;
+    const float BAx = Ax - rc.x, BAy = Ay - rc.y, BAz = Az - rc.zb;
+    const float Xx = __builtin_fmaf(BAy, rc.BCz, -(BAz * rc.BCy));  // torch.cross uses fma
+    const float Xy = __builtin_fmaf(BAz, rc.BCx, -(BAx * rc.BCz));
+    const float Xz = __builtin_fmaf(BAx, rc.BCy, -(BAy * rc.BCx));
+    masked = (mk == 0);
+    return ((Xx * Xx + Xy * Xy) + Xz * Xz) + kEps4;
+}
+
+// torch.min (T8:514) returns the FIRST index of the minimal DISTANCE d = sqrt(S)/|BC|.  sqrt and the division
+// are monotone, so the minimal distance is the distance of the minimal S, but several slightly larger S (up to
+// about nine consecutive floats) round to the same distance.  Every sample of that tie class that precedes
+// the minimum is a running minimum when it is met, so the class is a suffix of the chain of running minima
+// and the march tracks the chain's last link: if the predecessor does not tie nothing does.  If it does, an
+// even earlier link may tie as well; this re-marches [0, prevk) for the (rare) lanes concerned and returns
+// the first unmasked sample whose distance equals d.  Wave-uniform loop, per-lane predicate.
+__device__ inline int first_tied_sample(const RayConst &rc, const double *t_table, __amdgpu_buffer_rsrc_t zr,
+                                        __amdgpu_buffer_rsrc_t mr, bool tie, int prevk, float den, float d)
+{
+    int first = prevk;
+    int k_hi = tie ? prevk : 0;
+    // wave maximum (6 DPP-free steps are fine here: rare path)
+    for (int off = 32; off > 0; off >>= 1)
+        k_hi = max(k_hi, __shfl_xor(k_hi, off));
+    k_hi = __builtin_amdgcn_readfirstlane(k_hi);
+    bool found = !tie;
+    for (int k = 0; k < k_hi; ++k) {
+        bool masked;
+        const float S = ray_sample(rc, t_table[k], zr, mr, masked);
+        const bool hit = !found && (k < prevk) && !masked && (__builtin_sqrtf(S) / den == d);
+        first = hit ? k : first;
+        found = found || hit;
+    }
+    return first;
+}
 
 template <int TILE_W>
 __global__ __launch_bounds__(256) void shadow_fwd_kernel(ShadowArgs a)
@@ -115,6 +182,10 @@ __global__ __launch_bounds__(256) void shadow_fwd_kernel(ShadowArgs a)
     const double halfW = W / 2.0, halfH = H / 2.0;
 
     RayConst rc;
+    rc.H = H;
+    rc.W = W;
+    rc.halfW = halfW;
+    rc.halfH = halfH;
     rc.x = (float)c - halfWf;  // T8:52
     rc.y = halfHf - (float)r;  // T8:53
     rc.zb = zimg[(size_t)r * W + c];
@@ -126,55 +197,24 @@ __global__ __launch_bounds__(256) void shadow_fwd_kernel(ShadowArgs a)
     rc.BCy = Cy - rc.y;
     rc.BCz = Cz - rc.zb;
     const bool finite_ray = (rc.dx - rc.dx == 0.0f) && (rc.dy - rc.dy == 0.0f);
-    const double x64 = rc.x, y64 = rc.y;
-    const double dx64 = finite_ray ? (double)rc.dx : 0.0, dy64 = finite_ray ? (double)rc.dy : 0.0;
+    rc.x64 = rc.x;
+    rc.y64 = rc.y;
+    rc.dx64 = finite_ray ? (double)rc.dx : 0.0;
+    rc.dy64 = finite_ray ? (double)rc.dy : 0.0;
 
     // sqrt and the division by the per-pixel constant |BC| are monotone, so
     // min_k sqrt(S_k)/den == sqrt(min_k S_k)/den bit for bit: track the minimum of S over the
     // unmasked samples and finish once per pixel.
     float bestS = __builtin_inff();
     int besti = -1;
-    // The running minimum it replaced last.  torch.min returns the first index of the minimal DISTANCE; two
-    // samples whose S differ by a few ulps can round to the same distance, and then the earlier one -- the
-    // predecessor in the chain of running minima -- is the reference's argmin (see the epilogue).
+    // The running minimum it replaced last (distance-tie resolution: see first_tied_sample).
     float prevS = __builtin_inff();
     int prevk = -1;
     bool any_masked = false;
 
     for (int k = 0; k < N; ++k) {
-        const double t = a.t_table[k];  // wave-uniform -> s_load
-        const double sx = x64 + t * dx64;  // T8:472 / 480 (f64, mul and add rounded separately)
-        const double sy = y64 + t * dy64;
-        // rounded cell -> mask lookup (T8:472-477, 510)
-        const int col_r = (int)(__builtin_rint(sx) + halfW);
-        const int row_r = (int)(halfH - __builtin_rint(sy));
-        // unrounded position (T8:480-487)
-        const double ux = (sx + halfW) - 0.0001;
-        const double uy = (halfH - sy) - 0.0001;
-        const double fxd = __builtin_floor(ux), gxd = __builtin_ceil(ux);
-        const double fyd = __builtin_floor(uy), gyd = __builtin_ceil(uy);
-        int fx = (int)fxd, gx = (int)gxd, fy = (int)fyd, gy = (int)gyd;
-        const double wx0 = gxd - ux, wx1 = ux - fxd;  // T8:492-494 weights
-        const double wy0 = gyd - uy, wy1 = uy - fyd;
-        fx += (fx >> 31) & W;  // index -1 wraps to W-1 / H-1 (T8:488-491)
-        fy += (fy >> 31) & H;
-        const int rowf = fy * W, rowg = gy * W;
-        const double zUL = buf_load_f32(zr, (rowf + fx) << 2);
-        const double zUR = buf_load_f32(zr, (rowf + gx) << 2);
-        const double zLL = buf_load_f32(zr, (rowg + fx) << 2);
-        const double zLR = buf_load_f32(zr, (rowg + gx) << 2);
-        const uint32_t mk = buf_load_u8(mr, row_r * W + col_r);
-        const double up = zUL * wx0 + zUR * wx1;
-        const double low = zLL * wx0 + zLR * wx1;
-        const double zA = up * wy0 + low * wy1;
-        // point A (T8:497-502) and the distance numerator (T8:504-509) in f32
-        const float Ax = (float)(ux - halfW), Ay = (float)(halfH - uy), Az = (float)zA;
-        const float BAx = Ax - rc.x, BAy = Ay - rc.y, BAz = Az - rc.zb;
-        const float Xx = __builtin_fmaf(BAy, rc.BCz, -(BAz * rc.BCy));  // torch.cross uses fma
-        const float Xy = __builtin_fmaf(BAz, rc.BCx, -(BAx * rc.BCz));
-        const float Xz = __builtin_fmaf(BAx, rc.BCy, -(BAy * rc.BCx));
-        const float S = ((Xx * Xx + Xy * Xy) + Xz * Xz) + kEps4;
-        const bool masked = (mk == 0);
+        bool masked;
+        const float S = ray_sample(rc, a.t_table[k], zr, mr, masked);  // t wave-uniform -> s_load
         any_masked |= masked;
         const bool take = !masked && (S < bestS);  // strict: first minimum wins (T8:514)
         prevS = take ? bestS : prevS;
@@ -185,8 +225,13 @@ __global__ __launch_bounds__(256) void shadow_fwd_kernel(ShadowArgs a)
 
     const float den = __builtin_sqrtf(((rc.BCx * rc.BCx + rc.BCy * rc.BCy) + rc.BCz * rc.BCz) + kEps4);
     float d = __builtin_sqrtf(bestS) / den;  // +inf when every sample was masked
-    if (__builtin_sqrtf(prevS) / den == d)   // distance tie with the predecessor: the earlier index wins
-        besti = prevk;
+    if (a.argmin) {
+        const bool tie = (prevk >= 0) && (__builtin_sqrtf(prevS) / den == d);
+        if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // wave-uniform branch: the helper shuffles
+            const int first = first_tied_sample(rc, a.t_table, zr, mr, tie, prevk, den, d);
+            besti = tie ? first : besti;
+        }
+    }
     if (any_masked && !(d < kMaskedDistance)) {  // T8:512: masked samples count as 1e6
         d = kMaskedDistance;
         besti = -1;  // no gradient flows through a masked minimum
@@ -741,11 +786,32 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
 
     const float den = __builtin_sqrtf(((BCx * BCx + BCy * BCy) + BCz * BCz) + kEps4);
     float d = __builtin_sqrtf(bestS) / den;
-    // torch.min (T8:514) returns the FIRST index of the minimal distance.  sqrt and the division are monotone,
-    // so the minimal distance is the distance of the minimal S -- but a predecessor in the chain of running
-    // minima whose S is a few ulps larger can round to the same distance, and it comes first.
-    if (WANT_ARGMIN && __builtin_sqrtf(prevS) / den == d)
-        besti = prevk;
+    // torch.min (T8:514) returns the FIRST index of the minimal distance: see first_tied_sample.
+    if (WANT_ARGMIN) {
+        const bool tie = (prevk >= 0) && (__builtin_sqrtf(prevS) / den == d);
+        if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare; wave-uniform branch
+            RayConst rc;
+            rc.H = H;
+            rc.W = W;
+            rc.halfW = halfW;
+            rc.halfH = halfH;
+            rc.x = x;
+            rc.y = y;
+            rc.zb = zb;
+            rc.dx = dxf;
+            rc.dy = dyf;
+            rc.BCx = BCx;
+            rc.BCy = BCy;
+            rc.BCz = BCz;
+            rc.x64 = x64;
+            rc.y64 = y64;
+            rc.dx64 = dx64;
+            rc.dy64 = dy64;
+            const int first = first_tied_sample(rc, a.t_table, make_rsrc(a.depth + (size_t)b * P, (int)(P * 4)), mr,
+                                                tie, prevk, den, d);
+            besti = tie ? first : besti;
+        }
+    }
     if (any_masked && !(d < kMaskedDistance)) {
         d = kMaskedDistance;
         besti = -1;

@@ -59,7 +59,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=240)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--tune", type=str, default="", help="comma list key=value for gcfr_tune")
     a = ap.parse_args()
+    if a.tune:
+        from geomconsistentfr_amd import _lib
+        for kv in a.tune.split(","):
+            k, v = kv.split("=")
+            _lib.check(_lib.load().gcfr_tune(int(k), int(v)), "gcfr_tune")
     rng = np.random.default_rng(a.seed)
     dev = torch.device("cuda:0")
     sizes = [(64, 64, 48), (96, 128, 80), (130, 70, 37), (128, 128, 160), (256, 256, 160)]
