@@ -55,7 +55,7 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = _build.LIB_PATH
+    path = os.environ.get("GCFR_HIP_LIB") or _build.LIB_PATH  # override: A/B builds of the same ABI (tools/ab.sh)
     if not os.path.exists(path):
         try:
             _build.build()

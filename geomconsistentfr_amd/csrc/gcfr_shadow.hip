@@ -316,47 +316,49 @@ __device__ inline float f32_unsortable(int i)
 // reference's wrap-around to the last row / column) lie in [i*s, i*s + 2s) x [j*s, j*s + 2s): tiles
 // overlap by half, so any footprint of at most s+1 cells per axis lies inside the tile that its lowest
 // index selects.  The march uses it to skip sample groups that provably cannot lower a lane's running
-// minimum (see shadow_fwd_quad_kernel); s is the smallest power of two >= 4 that covers the cells one
+// minimum (see shadow_fwd_quad_kernel); s is the smallest power of two >= 8 that covers the cells one
 // group of `group` consecutive samples can touch, derived from the sample table on the device by both
-// kernels.  The host sizes the grid for s = 4.
+// kernels.  The host sizes the grid for s = 8.
 // ----------------------------------------------------------------------------------------------
 __device__ inline int zb_log2_stride(int H, int W, int N, const double *t_table, int group)
 {
     if (N < 2)
-        return 2;
+        return 3;
     const float step = fabsf((float)((t_table[N - 1] - t_table[0]) / (double)(N - 1)));
     const float fd = (float)(group - 1) * step * (float)max(H, W);  // rint(s) moves by <= floor(fd) + 1 cells
     const int need = (int)fminf(fmaxf(fd, 0.0f), 1024.0f) + 3;      // + the cell either side (floor / ceil)
-    int ls = 2;
+    int ls = 3;
     while ((1 << ls) < need && ls < 6)
         ++ls;
     return ls;
 }
 
-__host__ __device__ inline int zb_max_tiles(int H, int W) { return ((H >> 2) + 1) * ((W >> 2) + 1); }
+__host__ __device__ inline int zb_max_tiles(int H, int W) { return ((H >> 3) + 1) * ((W >> 3) + 1); }
 
-__global__ __launch_bounds__(256) void build_zbounds_kernel(const float *__restrict__ depth,
-                                                            float2 *__restrict__ zb, int H, int W, int N,
-                                                            const double *__restrict__ t_table, int group)
+// One wave per tile; `block` counts the 4-wave workgroups assigned to this job (the head of the prepass grid).
+__device__ inline void build_zbounds_block(int block, int b, const float *__restrict__ depth,
+                                           float2 *__restrict__ zb, int H, int W, int N,
+                                           const double *__restrict__ t_table, int group)
 {
     const int ls = zb_log2_stride(H, W, N, t_table, group);
     const int ntw = (W >> ls) + 1, nth = (H >> ls) + 1;
-    const int tile = blockIdx.x * 4 + (int)(threadIdx.x >> 6);  // one wave per tile
+    const int tile = block * 4 + (int)(threadIdx.x >> 6);
     if (tile >= nth * ntw)
         return;
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
     const int ti = tile / ntw, tj = tile - ti * ntw;
     const int side = 2 << ls;
     const float *z = depth + (size_t)b * H * W;
     float lo = __builtin_inff(), hi = -__builtin_inff();
-    for (int e = lane; e < side * side; e += 64) {
+    auto cell = [&](int e) -> float {  // NaN (ignored by fminf / fmaxf) outside the extended grid
         const int er = (ti << ls) + (e >> (ls + 1)), ec = (tj << ls) + (e & (side - 1));
-        if (er <= H && ec <= W) {
-            const int r = er == 0 ? H - 1 : er - 1, c = ec == 0 ? W - 1 : ec - 1;
-            const float v = z[(size_t)r * W + c];
-            lo = fminf(lo, v);  // NaN cells are ignored: a NaN sample never wins the minimum anyway
-            hi = fmaxf(hi, v);
-        }
+        const int r = er == 0 ? H - 1 : er - 1, c = ec == 0 ? W - 1 : ec - 1;
+        return (e < side * side && er <= H && ec <= W) ? z[(size_t)r * W + c] : __builtin_nanf("");
+    };
+    for (int e = lane; e < side * side; e += 256) {  // four independent loads in flight per pass
+        const float v0 = cell(e), v1 = cell(e + 64), v2 = cell(e + 128), v3 = cell(e + 192);
+        lo = fminf(fminf(lo, v0), fminf(fminf(v1, v2), v3));  // NaN cells are ignored: a NaN sample never wins
+        hi = fmaxf(fmaxf(hi, v0), fmaxf(fmaxf(v1, v2), v3));
     }
     const float wlo = f32_unsortable(wave_min_i32(f32_sortable(lo)));
     const float whi = -f32_unsortable(wave_min_i32(f32_sortable(-hi)));
@@ -365,20 +367,49 @@ __global__ __launch_bounds__(256) void build_zbounds_kernel(const float *__restr
 }
 
 // Prepass.  Per image: (a) repack depth into 2x2-neighbourhood texels, (b) optional light preparation,
-// (c) per-block partial bounding boxes of the mask's non-zero cells as four minima
+// (d) the depth-bounds tiles (tail blocks), (c) per-block partial bounding boxes of the mask's non-zero cells as four minima
 // {r_min, c_min, -r_max, -c_max} (kBBoxInit where the block saw no non-zero cell).
 __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict__ depth,
                                                          float4 *__restrict__ quad, int H, int W,
                                                          PrepassLights pl,
                                                          const uint8_t *__restrict__ mask, int mask_batch,
-                                                         int *__restrict__ bbox)
+                                                         int *__restrict__ bbox, int *__restrict__ zrange,
+                                                         float2 *__restrict__ zb, int quad_blocks, int N,
+                                                         const double *__restrict__ t_table, int group)
 {
     const int Wp = W + 1, Hp = H + 1;
     const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // head of the grid: the depth-bounds tiles (same launch; their short dependent-load chains start first and
+    // run alongside the repack blocks)
+    const int zb_blocks = (int)gridDim.x - quad_blocks;
+    if ((int)blockIdx.x < zb_blocks) {
+        build_zbounds_block((int)blockIdx.x, b, depth, zb, H, W, N, t_table, group);
+        return;
+    }
+    const int qb = (int)blockIdx.x - zb_blocks;
+    const int i = qb * blockDim.x + threadIdx.x;
     const int n_partials = (H * W + 255) / 256;
-    if (b < mask_batch && (int)blockIdx.x < n_partials) {  // block-uniform
-        // partial bounding box of the 256 mask cells this block covers -> bbox[b][blockIdx.x] (no atomics,
+    if (zrange && qb < n_partials) {  // block-uniform
+        // partial depth range of the 256 cells this block covers, as two minima {z_min, -z_max} in sortable ints
+        // (contended atomics on one per-image slot cost 0.2 ms here); reduced by the march like the boxes below
+        __shared__ int zpart[4][2];
+        const bool in = i < H * W;
+        const float v = in ? depth[(size_t)b * H * W + i] : 0.0f;
+        const bool ok = in && (v == v);  // NaN cells do not count (a NaN sample never wins the minimum)
+        const int z0 = wave_min_i32(ok ? f32_sortable(v) : 0x7fffffff);
+        const int z1 = wave_min_i32(ok ? f32_sortable(-v) : 0x7fffffff);
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            zpart[wv][0] = z0;
+            zpart[wv][1] = z1;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2)
+            zrange[((size_t)b * n_partials + qb) * 2 + threadIdx.x] =
+                min(min(zpart[0][threadIdx.x], zpart[1][threadIdx.x]), min(zpart[2][threadIdx.x], zpart[3][threadIdx.x]));
+    }
+    if (b < mask_batch && qb < n_partials) {  // block-uniform
+        // partial bounding box of the 256 mask cells this block covers -> bbox[b][qb] (no atomics,
         // nothing to initialise); the march kernel reduces the partials of its image in its prologue
         __shared__ int part[4][4];
         const bool set = (i < H * W) && mask[(size_t)b * H * W + i] != 0;
@@ -394,10 +425,10 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
         }
         __syncthreads();
         if (threadIdx.x < 4)
-            bbox[((size_t)b * n_partials + blockIdx.x) * 4 + threadIdx.x] =
+            bbox[((size_t)b * n_partials + qb) * 4 + threadIdx.x] =
                 min(min(part[0][threadIdx.x], part[1][threadIdx.x]), min(part[2][threadIdx.x], part[3][threadIdx.x]));
     }
-    if (pl.light_raw && blockIdx.x == 0) {
+    if (pl.light_raw && qb == 0) {
         for (int l = threadIdx.x; l < pl.L; l += blockDim.x)
             light_prep_one(pl.light_raw, b * pl.L + l, pl.clamp_z, pl.clamp_min, pl.light_distance,
                            pl.unit_out, pl.light_pt_out);
@@ -420,6 +451,7 @@ struct ShadowQuadArgs {
     const float4 *quad;     // (B,H+1,W+1)  prepass output
     const int *bbox;        // (MB,P/256,4) prepass output: partial mask bounding boxes {r_min, c_min, -r_max, -c_max}
     const float2 *zb;       // (B,zb_max_tiles) prepass output: depth bounds grid, or null (bound skip off)
+    const int *zrange;      // (B,P/256,2) prepass output: partial depth ranges {z_min, -z_max} (sortable ints)
     const uint8_t *mask;    // (MB,H,W)
     const float *light_pt;  // (B,L,3)
     const double *t_table;  // (N)
@@ -455,7 +487,12 @@ __device__ inline int lo32(double v)
 //                 Same total work in 4x finer, more uniform pieces: used for small batches, where a few
 //                 heavy (fully unmasked) tiles otherwise leave the SIMDs idle at the tail of the launch.
 template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool KSPLIT>
-__global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
+#ifndef GCFR_MARCH_WAVES_PER_EU
+#define GCFR_MARCH_ATTR
+#else
+#define GCFR_MARCH_ATTR __attribute__((amdgpu_waves_per_eu(GCFR_MARCH_WAVES_PER_EU, GCFR_MARCH_WAVES_PER_EU)))
+#endif
+__global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(ShadowQuadArgs a)
 {
     constexpr int TILE_H = 64 / TILE_W;
     constexpr int WAVES = KSPLIT ? 1 : 4;  // tiles per workgroup along x
@@ -523,29 +560,44 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
     // rays that have left (or never reach) the face.  Requires the sample table to be monotone and
     // uniformly spaced to within half a step, which gcfr_sample_table guarantees.
     int k_begin = k_lo, k_end = N;  // [k_begin, k_end)
+    const bool use_zb = a.zb != nullptr;
+    int gz_lo_s = 0x7fffffff, gz_nhi_s = 0x7fffffff;  // image depth range {z_min, -z_max} (sortable ints)
     if (a.N >= 2) {
-        // reduce the prepass' partial boxes of this image: 256 threads, one 16-byte partial each per pass
-        __shared__ int sbb[4][4];
+        // reduce the prepass' partial boxes (and depth ranges) of this image: 256 threads, one partial each per pass
+        __shared__ int sbb[4][6];
         {
             const int n_partials = (int)((P + 255) / 256);
             const int4 *pb = (const int4 *)a.bbox + (size_t)(a.mask_batch == 1 ? 0 : b) * n_partials;
+            const int2 *pz = (const int2 *)a.zrange + (size_t)b * n_partials;
             int4 m = make_int4(kBBoxInit, kBBoxInit, kBBoxInit, kBBoxInit);
+            int2 mz = make_int2(0x7fffffff, 0x7fffffff);
             for (int j = threadIdx.x; j < n_partials; j += 256) {
                 const int4 v = pb[j];
                 m.x = min(m.x, v.x);
                 m.y = min(m.y, v.y);
                 m.z = min(m.z, v.z);
                 m.w = min(m.w, v.w);
+                if (use_zb) {
+                    const int2 vz = pz[j];
+                    mz.x = min(mz.x, vz.x);
+                    mz.y = min(mz.y, vz.y);
+                }
             }
             m.x = wave_min_i32(m.x);
             m.y = wave_min_i32(m.y);
             m.z = wave_min_i32(m.z);
             m.w = wave_min_i32(m.w);
+            if (use_zb) {
+                mz.x = wave_min_i32(mz.x);
+                mz.y = wave_min_i32(mz.y);
+            }
             if (lane == 0) {
                 sbb[threadIdx.x >> 6][0] = m.x;
                 sbb[threadIdx.x >> 6][1] = m.y;
                 sbb[threadIdx.x >> 6][2] = m.z;
                 sbb[threadIdx.x >> 6][3] = m.w;
+                sbb[threadIdx.x >> 6][4] = mz.x;
+                sbb[threadIdx.x >> 6][5] = mz.y;
             }
             __syncthreads();
         }
@@ -553,6 +605,8 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
             return __builtin_amdgcn_readfirstlane(min(min(sbb[0][q], sbb[1][q]), min(sbb[2][q], sbb[3][q])));
         };
         const int r_min = red(0), c_min = red(1), r_max = -red(2), c_max = -red(3);
+        gz_lo_s = red(4);
+        gz_nhi_s = red(5);
         int lane_lo = a.N, lane_hi = -1;  // empty
         if (r_min != kBBoxInit) {
             const float X0 = (float)c_min - halfWf - 0.51f, X1 = (float)c_max - halfWf + 0.51f;
@@ -604,12 +658,11 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
     // over one group of samples and z in [zmin, zmax] -- the depth bounds of the cells the group can touch,
     // from the prepass' grid -- |G| is at least `gap` below, evaluated at the group's first and last sample.
     // The reference's bilinear weights are both 0 when a coordinate is integral, which samples z = 0: that
-    // isolated value is tested too (gap0).  K1 + K2 r over-estimates every rounding between G and the f32 S
-    // the body would compute (r bounds |BA|'s components); a lane votes "skip" only if the bound exceeds its
+    // isolated value is tested too (gap0).  Kerr = K1 + K2 r over-estimates every rounding between G and the
+    // f32 S the body would compute (r bounds |BA|'s components over the image); a lane votes "skip" only if the bound exceeds its
     // running minimum by a further 0.1 %, so a skipped sample could not have been taken and the minimum,
     // its index and the tie predecessor are what the full march gives.
-    const bool use_zb = a.zb != nullptr;
-    const int zls = use_zb ? __builtin_amdgcn_readfirstlane(zb_log2_stride(H, W, a.N, a.t_table, DEPTH)) : 2;
+    const int zls = use_zb ? __builtin_amdgcn_readfirstlane(zb_log2_stride(H, W, a.N, a.t_table, DEPTH)) : 3;
     const int zntw = (W >> zls) + 1;
     const __amdgpu_buffer_rsrc_t zr =
         make_rsrc(a.zb + (size_t)b * zb_max_tiles(H, W), zb_max_tiles(H, W) * (int)sizeof(float2));
@@ -617,21 +670,31 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
     const float c1 = BCz * ((dxf * BCx + dyf * BCy) / nrm);
     const float Qz = nrm * zb;
     const float t_abs = fmaxf(fabsf((float)a.t_table[0]), fabsf((float)a.t_table[a.N - 1]));
-    float K1 = 4e-3f * fabsf(BCz) + 1e-6f * fabsf(c1) * t_abs;
-    const float K2 = 1e-6f * nrm + 2e-7f * ((fabsf(BCx) + fabsf(BCy)) + fabsf(BCz));
-    const float R0 = fmaxf(fabsf(zb), (float)max(H, W));
-    if (!(nrm > 0.0f) || !finite_ray || !(K1 - K1 == 0.0f))
-        K1 = __builtin_inff();  // never skips
+    float Kerr = __builtin_inff();  // never skips
+    if (use_zb) {
+        // r: bound on |BA|'s components over the whole image (x, y extent; depth range incl. the sampled 0)
+        const float gz_lo = f32_unsortable(gz_lo_s), gz_hi = -f32_unsortable(gz_nhi_s);  // all-NaN image: +inf, -inf
+        const float rr = fmaxf(fmaxf(fabsf(gz_lo - zb), fabsf(gz_hi - zb)), fmaxf(fabsf(zb), (float)max(H, W)));
+        const float K1 = 4e-3f * fabsf(BCz) + 1e-6f * fabsf(c1) * t_abs;
+        const float K2 = 1e-6f * nrm + 2e-7f * ((fabsf(BCx) + fabsf(BCy)) + fabsf(BCz));
+        const float K = __builtin_fmaf(K2, rr, K1);
+        if ((nrm > 0.0f) && finite_ray && (K - K == 0.0f))
+            Kerr = K;
+    }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     // bounds of the cells a group can touch, given the rounded cells of its first and last sample:
-    // floor(u) and ceil(u) lie in [rint(s) - 1, rint(s) + 1], so the extended indices are [min, max + 2]
-    auto zb_fetch = [&](int ca, int ra, int cb, int rb, bool &covered) -> f32x2 {
+    // floor(u) and ceil(u) lie in [rint(s) - 1, rint(s) + 1], so the extended indices are [min, max + 2].
+    // A footprint the selected tile does not cover gets (-inf, +inf): it never skips.
+    auto zb_fetch = [&](int ca, int ra, int cb, int rb) -> f32x2 {
         const int cmin = min(ca, cb), cmax = max(ca, cb), rmin = min(ra, rb), rmax = max(ra, rb);
         const int tj = cmin >> zls, ti = rmin >> zls;
-        covered = (cmin >= 0) && (rmin >= 0) && (cmax <= W - 1) && (rmax <= H - 1) &&
-                  (cmax + 2 <= ((tj + 2) << zls) - 1) && (rmax + 2 <= ((ti + 2) << zls) - 1);
+        const bool covered = (cmin >= 0) && (rmin >= 0) && (cmax <= W - 1) && (rmax <= H - 1) &&
+                             (cmax + 2 <= ((tj + 2) << zls) - 1) && (rmax + 2 <= ((ti + 2) << zls) - 1);
         const int off = covered ? (__mul24(ti, zntw) + tj) << 3 : 0;
-        return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(zr, off, 0, 0));
+        f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(zr, off, 0, 0));
+        v.x = covered ? v.x : -__builtin_inff();
+        v.y = covered ? v.y : __builtin_inff();
+        return v;
     };
 
     // Two-stage software pipeline.  Stage A (sample k+1): position, rounded cell, issue the mask byte
@@ -662,8 +725,7 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
     // (first) argmin, so the tail needs no branch.
     auto clampk = [&](int k) { return k < k_end ? k : k_end - 1; };
     uint32_t ring[DEPTH];
-    f32x2 ring_z = {0.0f, 0.0f};
-    bool ring_cov = false;
+    f32x2 ring_z = {-__builtin_inff(), __builtin_inff()};
     if (k_begin < k_end) {
         int cj[DEPTH], rj[DEPTH];
 #pragma unroll
@@ -673,14 +735,13 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
             ring[j] = buf_load_u8(mr, mask_offset(px, py, cj[j], rj[j]));
         }
         if (use_zb)
-            ring_z = zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1], ring_cov);
+            ring_z = zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1]);
     }
 
     for (int k0 = k_begin; k0 < k_end; k0 += DEPTH) {
         uint32_t mk[DEPTH];
         bool none = true;
         const f32x2 zbnd = ring_z;
-        const bool zcov = ring_cov;
         {
             int cj[DEPTH], rj[DEPTH];
 #pragma unroll
@@ -693,7 +754,7 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
                 any_masked |= (mk[j] == 0);
             }
             if (use_zb)  // ... and its depth bounds
-                ring_z = zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1], ring_cov);
+                ring_z = zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1]);
         }
         if (__builtin_amdgcn_ballot_w64(!none) == 0ull)
             continue;
@@ -704,9 +765,8 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
             const float Pmin = __builtin_fmaf(nrm, zbnd.x, -Qz), Pmax = __builtin_fmaf(nrm, zbnd.y, -Qz);
             const float gap = fmaxf(Pmin - Thi, Tlo - Pmax);   // > 0 iff the ray clears [zmin, zmax] all along the group
             const float gap0 = fmaxf(-Qz - Thi, Tlo + Qz);     // the same for the isolated value z = 0
-            const float rr = fmaxf(fmaxf(fabsf(zbnd.x - zb), fabsf(zbnd.y - zb)), R0);
-            const float g = fminf(gap, gap0) - __builtin_fmaf(K2, rr, K1);
-            const bool cannot_win = zcov && (g > 0.0f) && (g * g * 0.998f > bestS);
+            const float g = fminf(gap, gap0) - Kerr;
+            const bool cannot_win = (g > 0.0f) && (g * g * 0.998f > bestS);
             if (__builtin_amdgcn_ballot_w64(!none && !cannot_win) == 0ull)
                 continue;
         }
@@ -897,9 +957,9 @@ extern "C" int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_
 
 // Process-wide tuning knobs (experiments / A-B runs only; defaults are the shipped configuration).
 // Measured on MI355X, B=8 x 256^2 x 160 (gpurun_out/ab_r01.txt -> DESIGN.md section 4.1):
-//   tile 2x32 > 4x16 > 8x8 > 1x64;  an XCD-affine block map is 12 % slower;  f64 texels (32-B gathers)
-//   are 25 % slower (vector-memory bound).
-static int g_tile_w = 32;  // pixels per tile row: 8, 16, 32 or 64 (tile = 64/tile_w rows)
+//   tile 2x32 > 4x16 > 8x8 > 1x64 without the depth-bound skip, 8x8 >= 4x16 > 2x32 > 1x64 with it;  an
+//   XCD-affine block map is 12 % slower;  f64 texels (32-B gathers) are 25 % slower (vector-memory bound).
+static int g_tile_w = 0;   // pixels per tile row: 8, 16, 32 or 64 (tile = 64/tile_w rows); 0 = auto (below)
 static int g_depth = 4;    // samples per group (skip granularity / gathers in flight): 1, 2 or 4
 static int g_ksplit = -1;  // sample-range split over the 4 waves of a workgroup: 0 off, 1 on, -1 auto
 static int g_zbound = 1;   // depth-bound group skip (exact): 1 on, 0 off
@@ -908,7 +968,7 @@ extern "C" int gcfr_tune(int32_t key, int32_t value)
 {
     switch (key) {
     case 0:
-        if (value != 8 && value != 16 && value != 32 && value != 64)
+        if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64)
             return GCFR_ERR_INVALID_ARGUMENT;
         g_tile_w = value;
         return GCFR_OK;
@@ -938,7 +998,7 @@ extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
         return 0;
     const size_t n_partials = ((size_t)H * W + 255) / 256;
     return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4) + (size_t)B * n_partials * 4 * sizeof(int) +
-           (size_t)B * (size_t)zb_max_tiles(H, W) * sizeof(float2);
+           (size_t)B * (size_t)zb_max_tiles(H, W) * sizeof(float2) + (size_t)B * n_partials * 2 * sizeof(int);
 }
 
 // Optional profiling hook: events recorded around the dominant (march) kernel of the next launches.
@@ -1032,7 +1092,10 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
     if (workspace && workspace_bytes < gcfr_shadow_workspace_bytes(B, H, W))
         return GCFR_ERR_INVALID_ARGUMENT;
 
-    const int TILE_W = workspace ? g_tile_w : 16, TILE_H = 64 / TILE_W, WAVES = 4;
+    // auto tile shape (measured, gpurun_out/ab logs -> DESIGN.md 4.1): with the depth-bound skip compact tiles win
+    // (the lanes of a wave agree more often): 8x8 up to 256 px wide, 16x4 above; without it 32x2 streams best.
+    const int tile_auto = (g_zbound && N >= 2) ? (W <= 256 ? 8 : 16) : 32;
+    const int TILE_W = workspace ? (g_tile_w ? g_tile_w : tile_auto) : 16, TILE_H = 64 / TILE_W, WAVES = 4;
     const int tiles_x = (W + TILE_W - 1) / TILE_W;
     const int quads_x = (tiles_x + WAVES - 1) / WAVES;
     const int quads_per_image = quads_x * ((H + TILE_H - 1) / TILE_H);
@@ -1049,15 +1112,19 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         // prepass: 2x2 neighbourhood grid (see shadow_fwd_quad_kernel), then the march
         const int texels = (H + 1) * (W + 1);
         int *bbox = (int *)((char *)workspace + (size_t)B * texels * sizeof(float4));
-        hipLaunchKernelGGL(build_quad_kernel, dim3((texels + 255) / 256, B), dim3(256), 0, st, depth,
-                           (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox);
         const size_t n_partials = ((size_t)H * W + 255) / 256;
         float2 *zb = (float2 *)((char *)bbox + (size_t)B * n_partials * 4 * sizeof(int));
-        if (g_zbound && N >= 2)
-            hipLaunchKernelGGL(build_zbounds_kernel, dim3((zb_max_tiles(H, W) + 3) / 4, B), dim3(256), 0, st, depth,
-                               zb, H, W, N, t_table, g_depth == 1 || g_depth == 2 ? g_depth : 4);
+        int *zrange = (int *)(zb + (size_t)B * zb_max_tiles(H, W));  // (B, n_partials, 2)
+        const bool use_zb = g_zbound && N >= 2;
+        const int quad_blocks = (texels + 255) / 256;
+        const int zb_blocks = use_zb ? (zb_max_tiles(H, W) + 3) / 4 : 0;  // sized for the finest stride
+        hipLaunchKernelGGL(build_quad_kernel, dim3(quad_blocks + zb_blocks, B), dim3(256), 0, st, depth,
+                           (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox,
+                           use_zb ? zrange : (int *)nullptr, zb, quad_blocks, N, t_table,
+                           g_depth == 1 || g_depth == 2 ? g_depth : 4);
         ShadowQuadArgs a;
-        a.zb = (g_zbound && N >= 2) ? zb : nullptr;
+        a.zb = use_zb ? zb : nullptr;
+        a.zrange = zrange;
         a.depth = depth;
         a.quad = (const float4 *)workspace;
         a.bbox = bbox;

@@ -82,7 +82,7 @@ int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_z, float cl
 size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W);
 
 /* Tuning / A-B knob for experiments (process-wide; not needed in normal use; results never change):
- * key 0 = tile width {8,16,32,64} (default 32), key 1 = samples per skip group {1,2,4} (default 4),
+ * key 0 = tile width {8,16,32,64, 0 = auto} (default auto), key 1 = samples per skip group {1,2,4} (default 4),
  * key 2 = split each tile's sample range over the 4 waves of its workgroup {0,1,-1 = auto by launch size},
  * key 3 = depth-bound group skip {0,1} (default 1). */
 int gcfr_tune(int32_t key, int32_t value);

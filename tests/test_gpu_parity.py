@@ -360,3 +360,45 @@ def test_maximum_supported_size():
         assert np.array_equal(md.cpu().numpy(), md_o), ws
         lit = md_o < 1e5
         assert np.array_equal(am.cpu().numpy()[lit], am_o[lit]), ws
+
+
+@pytest.mark.parametrize("Hs,Ws,N,dt", [(128, 128, 160, 0.005), (66, 130, 37, 0.02), (256, 256, 96, 0.008)])
+def test_depth_bound_skip_is_exact_for_every_tile_shape(Hs, Ws, N, dt):
+    """The depth-bound group skip (coarse min/max depth grid, include/gcfr.h tune key 3) must not change one bit:
+    min distance and argmin against the C oracle and the direct kernel, for every tile shape and group size,
+    on surfaces that make it fire (smooth bump), that defeat it (noise), that straddle zero and that are
+    offset far from zero (the sampled-zero quirk of integral coordinates, coarse float spacing -> ties)."""
+    import c_oracle
+    from geomconsistentfr_amd import RenderParams, shadow_min_distance, light_prep, _lib
+    L_ = _lib.load()
+    rng = np.random.default_rng(Hs * 7 + N)
+    r, c = np.mgrid[0:Hs, 0:Ws]
+    bump = 0.35 * Hs * np.exp(-(((c - 0.5 * Ws) / (0.25 * Ws)) ** 2 + ((r - 0.5 * Hs) / (0.3 * Hs)) ** 2))
+    depth = np.stack([bump, bump + 3 * rng.random((Hs, Ws)), 30 * rng.random((Hs, Ws)), bump - 0.15 * Hs,
+                      -bump, bump + 1000.0, np.round(bump)]).astype(np.float32)
+    B = depth.shape[0]
+    ell = ((((c - 0.5 * Ws) / (0.4 * Ws)) ** 2 + ((r - 0.5 * Hs) / (0.45 * Hs)) ** 2) < 1)
+    mask = np.stack([ell, ell, np.ones_like(ell), ell, ell, ell, rng.random((Hs, Ws)) > 0.2]).astype(np.uint8)
+    lights = np.array([[[0.75, 0.0, 0.66], [0.1, -0.2, 0.97]]] * B, np.float32)
+    lights[1::2, 0] = [-0.5, 0.47, 0.72]
+    lights[2, 1] = [0.99, 0.05, 0.05]                                  # grazing
+    prm = RenderParams(n_samples=N, t0=0.025, dt=dt)
+    _, pt = light_prep(to_dev(lights), prm)
+    md_o, am_o = c_oracle.shadow_min_distance(depth, mask, c_oracle.light_prep(lights.reshape(-1, 3), clamp_z_min=0.0)[1]
+                                              .reshape(B, 2, 3), c_oracle.sample_table(0.025, dt, N))
+    lit = md_o < 1e5
+    ref_md, ref_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=False)
+    assert np.array_equal(ref_md.cpu().numpy(), md_o)
+    assert np.array_equal(ref_am.cpu().numpy()[lit], am_o[lit])
+    try:
+        for zb in (1, 0):
+            for tw in (8, 16, 32, 64):
+                for grp in ((4, 2, 1) if tw == 8 else (4,)):
+                    assert L_.gcfr_tune(3, zb) == 0 and L_.gcfr_tune(0, tw) == 0 and L_.gcfr_tune(1, grp) == 0
+                    md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True)
+                    assert torch.equal(md, ref_md), (zb, tw, grp)
+                    assert torch.equal(am, ref_am), (zb, tw, grp)
+    finally:
+        L_.gcfr_tune(3, 1)
+        L_.gcfr_tune(0, 0)
+        L_.gcfr_tune(1, 4)

@@ -1,0 +1,7 @@
+#!/bin/bash
+# build an experimental variant of the library: tools/build_variant.sh <name> [-DMACRO=..]...  -> geomconsistentfr_amd/lib/<name>.so
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+NAME=$1; shift
+C=$REPO/geomconsistentfr_amd/csrc
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fno-fast-math -munsafe-fp-atomics -Wall "$@" \
+  $C/gcfr_shadow.hip $C/gcfr_shade.hip $C/gcfr_backward.hip $C/gcfr_normals.hip -o $REPO/geomconsistentfr_amd/lib/$NAME.so
