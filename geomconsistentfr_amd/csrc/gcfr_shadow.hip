@@ -562,6 +562,7 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     int k_begin = k_lo, k_end = N;  // [k_begin, k_end)
     const bool use_zb = a.zb != nullptr;
     int gz_lo_s = 0x7fffffff, gz_nhi_s = 0x7fffffff;  // image depth range {z_min, -z_max} (sortable ints)
+    int lane_last = a.N - 1;  // last sample of this lane that can be unmasked (mask bounding box), see below
     if (a.N >= 2) {
         // reduce the prepass' partial boxes (and depth ranges) of this image: 256 threads, one partial each per pass
         __shared__ int sbb[4][6];
@@ -642,6 +643,7 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
         // readfirstlane: the reductions are wave-uniform by construction, but only an SGPR tells the
         // compiler so -- with VGPR bounds the sample loop turns into a divergent loop (per-lane trip count,
         // vector loads of the sample table, +34 VGPRs: measured 20 % slower).
+        lane_last = lane_hi;
         const int w_lo = __builtin_amdgcn_readfirstlane(wave_min_i32(lane_lo));
         const int w_hi = -__builtin_amdgcn_readfirstlane(wave_min_i32(-lane_hi));
         const int nb = max(k_begin, w_lo), ne = min(k_end, w_hi + 1);
@@ -671,6 +673,14 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     const float Qz = nrm * zb;
     const float t_abs = fmaxf(fabsf((float)a.t_table[0]), fabsf((float)a.t_table[a.N - 1]));
     float Kerr = __builtin_inff();  // never skips
+    // Early termination (exact).  Once the ray is above max(image depth maximum, 0) by more than the running
+    // minimum allows (same bound as above, with the image-wide zmax instead of a tile's) and is still rising
+    // (c1 > 0), no later sample of this lane can be taken.  The lane's `any_masked` no longer matters either if
+    // its distance is certainly below the masked value 1e6 (safeS, wave-uniform).  A lane whose remaining
+    // samples all lie outside the mask's bounding box is finished too (they are masked: any_masked).  When
+    // every lane of the wave is finished the march stops -- it saves the mask gathers of the rest of the ray.
+    float Dcap = __builtin_inff();   // n (zcap - zb) + Kerr; +inf: never finished by the bound
+    float safeS = 0.0f;
     if (use_zb) {
         // r: bound on |BA|'s components over the whole image (x, y extent; depth range incl. the sampled 0)
         const float gz_lo = f32_unsortable(gz_lo_s), gz_hi = -f32_unsortable(gz_nhi_s);  // all-NaN image: +inf, -inf
@@ -678,8 +688,15 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
         const float K1 = 4e-3f * fabsf(BCz) + 1e-6f * fabsf(c1) * t_abs;
         const float K2 = 1e-6f * nrm + 2e-7f * ((fabsf(BCx) + fabsf(BCy)) + fabsf(BCz));
         const float K = __builtin_fmaf(K2, rr, K1);
-        if ((nrm > 0.0f) && finite_ray && (K - K == 0.0f))
+        if ((nrm > 0.0f) && finite_ray && (K - K == 0.0f)) {
             Kerr = K;
+            if (c1 > 0.0f)
+                Dcap = __builtin_fmaf(nrm, fmaxf(gz_hi, 0.0f), -Qz) + K;  // NaN / inf: the test below fails
+        }
+        // d = sqrt(S)/den < 1e6 for certain when S < 0.98e12 den^2; wave minimum -> SGPR
+        const float den2 = (BCx * BCx + BCy * BCy) + BCz * BCz;
+        const float s_lane = (den2 - den2 == 0.0f) ? 0.98e12f * den2 : 0.0f;
+        safeS = f32_unsortable(__builtin_amdgcn_readfirstlane(wave_min_i32(f32_sortable(s_lane))));
     }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     // bounds of the cells a group can touch, given the rounded cells of its first and last sample:
@@ -756,9 +773,8 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
             if (use_zb)  // ... and its depth bounds
                 ring_z = zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1]);
         }
-        if (__builtin_amdgcn_ballot_w64(!none) == 0ull)
-            continue;
-        if (use_zb) {
+        bool run_body = __builtin_amdgcn_ballot_w64(!none) != 0ull;
+        if (run_body && use_zb) {
             const float ta = (float)a.t_table[k0], tb = (float)a.t_table[clampk(k0 + DEPTH - 1)];
             const float Ta = c1 * ta, Tb = c1 * tb;
             const float Tlo = fminf(Ta, Tb), Thi = fmaxf(Ta, Tb);
@@ -767,11 +783,19 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
             const float gap0 = fmaxf(-Qz - Thi, Tlo + Qz);     // the same for the isolated value z = 0
             const float g = fminf(gap, gap0) - Kerr;
             const bool cannot_win = (g > 0.0f) && (g * g * 0.998f > bestS);
-            if (__builtin_amdgcn_ballot_w64(!none && !cannot_win) == 0ull)
-                continue;
+            run_body = __builtin_amdgcn_ballot_w64(!none && !cannot_win) != 0ull;
         }
+        if (run_body) {
         // phase 1: positions and texel gathers for the whole group (all in flight together)
-        double ux[DEPTH], uy[DEPTH], fxd[DEPTH], fyd[DEPTH];
+#ifndef GCFR_FLOOR_MODE
+#define GCFR_FLOOR_MODE 0
+#endif
+        double ux[DEPTH], uy[DEPTH];
+#if GCFR_FLOOR_MODE == 0
+        double fxd[DEPTH], fyd[DEPTH];
+#elif GCFR_FLOOR_MODE == 2
+        int fxi[DEPTH], fyi[DEPTH];
+#endif
         f32x4 qv[DEPTH];
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
@@ -779,9 +803,15 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
             sample_pos(clampk(k0 + j), sx, sy);
             ux[j] = (sx + halfW) - 0.0001;  // unrounded position (T8:480-487)
             uy[j] = (halfH - sy) - 0.0001;
-            fxd[j] = __builtin_floor(ux[j]);
-            fyd[j] = __builtin_floor(uy[j]);
-            const int fx = (int)fxd[j], fy = (int)fyd[j];  // may be -1: the quad grid has that row / column
+            const double fxd_ = __builtin_floor(ux[j]), fyd_ = __builtin_floor(uy[j]);
+            const int fx = (int)fxd_, fy = (int)fyd_;  // may be -1: the quad grid has that row / column
+#if GCFR_FLOOR_MODE == 0
+            fxd[j] = fxd_;
+            fyd[j] = fyd_;
+#elif GCFR_FLOOR_MODE == 2
+            fxi[j] = fx;
+            fyi[j] = fy;
+#endif
             const int texel = __mul24(fy, Wp) + fx;
             // NB: bit-cast the whole vector.  Indexing the builtin's result element-wise makes this
             // hipcc narrow the load to ONE dword (all four corners alias) -- caught in the ISA.
@@ -794,8 +824,15 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
             const int k = clampk(k0 + j);
             const bool masked = (mk[j] == 0);
             const double gxd = __builtin_ceil(ux[j]), gyd = __builtin_ceil(uy[j]);
-            const double wx0 = gxd - ux[j], wx1 = ux[j] - fxd[j];
-            const double wy0 = gyd - uy[j], wy1 = uy[j] - fyd[j];
+#if GCFR_FLOOR_MODE == 0
+            const double fxd_ = fxd[j], fyd_ = fyd[j];
+#elif GCFR_FLOOR_MODE == 1
+            const double fxd_ = __builtin_floor(ux[j]), fyd_ = __builtin_floor(uy[j]);
+#else
+            const double fxd_ = (double)fxi[j], fyd_ = (double)fyi[j];
+#endif
+            const double wx0 = gxd - ux[j], wx1 = ux[j] - fxd_;
+            const double wy0 = gyd - uy[j], wy1 = uy[j] - fyd_;
             const double zUL = qv[j].x, zUR = qv[j].y, zLL = qv[j].z, zLR = qv[j].w;
             const double up = zUL * wx0 + zUR * wx1;
             const double low = zLL * wx0 + zLR * wx1;
@@ -813,6 +850,17 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
                 besti = take ? k : besti;
             }
             bestS = take ? S : bestS;
+        }
+        }  // run_body
+        if (use_zb && k0 + DEPTH < k_end) {  // early termination, see Dcap
+            const float tn = (float)a.t_table[k0 + DEPTH];
+            const float gd = __builtin_fmaf(c1, tn, -Dcap);
+            const bool finished = ((gd > 0.0f) && (gd * gd * 0.998f > bestS) && (bestS < safeS)) ||
+                                  (lane_last < k0 + DEPTH);
+            if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) {
+                any_masked |= (lane_last < k0 + DEPTH);
+                break;
+            }
         }
     }
 
