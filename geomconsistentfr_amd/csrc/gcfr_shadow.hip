@@ -328,12 +328,13 @@ __device__ inline int zb_log2_stride(int H, int W, int N, const double *t_table,
     const float fd = (float)(group - 1) * step * (float)max(H, W);  // rint(s) moves by <= floor(fd) + 1 cells
     const int need = (int)fminf(fmaxf(fd, 0.0f), 1024.0f) + 3;      // + the cell either side (floor / ceil)
     int ls = 3;
-    while ((1 << ls) < need && ls < 6)
+    while ((1 << ls) < need && ls < 5)  // capped at 32: coarser tiles bound nothing (their footprints fail the coverage test)
         ++ls;
     return ls;
 }
 
-__host__ __device__ inline int zb_max_tiles(int H, int W) { return ((H >> 3) + 1) * ((W >> 3) + 1); }
+// records per image: the tiles at the finest stride plus one sentinel (-inf, +inf) that uncovered footprints read
+__host__ __device__ inline int zb_max_tiles(int H, int W) { return ((H >> 3) + 1) * ((W >> 3) + 1) + 1; }
 
 // One wave per tile; `block` counts the 4-wave workgroups assigned to this job (the head of the prepass grid).
 __device__ inline void build_zbounds_block(int block, int b, const float *__restrict__ depth,
@@ -343,6 +344,8 @@ __device__ inline void build_zbounds_block(int block, int b, const float *__rest
     const int ls = zb_log2_stride(H, W, N, t_table, group);
     const int ntw = (W >> ls) + 1, nth = (H >> ls) + 1;
     const int tile = block * 4 + (int)(threadIdx.x >> 6);
+    if (block == 0 && threadIdx.x == 0)
+        zb[(size_t)b * zb_max_tiles(H, W) + zb_max_tiles(H, W) - 1] = make_float2(-__builtin_inff(), __builtin_inff());
     if (tile >= nth * ntw)
         return;
     const int lane = threadIdx.x & 63;
@@ -701,17 +704,16 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     // bounds of the cells a group can touch, given the rounded cells of its first and last sample:
     // floor(u) and ceil(u) lie in [rint(s) - 1, rint(s) + 1], so the extended indices are [min, max + 2].
-    // A footprint the selected tile does not cover gets (-inf, +inf): it never skips.
+    // A footprint the selected tile does not cover reads the sentinel record (-inf, +inf): it never skips.
+    const int zb_sentinel = (zb_max_tiles(H, W) - 1) << 3;
     auto zb_fetch = [&](int ca, int ra, int cb, int rb) -> f32x2 {
         const int cmin = min(ca, cb), cmax = max(ca, cb), rmin = min(ra, rb), rmax = max(ra, rb);
         const int tj = cmin >> zls, ti = rmin >> zls;
         const bool covered = (cmin >= 0) && (rmin >= 0) && (cmax <= W - 1) && (rmax <= H - 1) &&
                              (cmax + 2 <= ((tj + 2) << zls) - 1) && (rmax + 2 <= ((ti + 2) << zls) - 1);
-        const int off = covered ? (__mul24(ti, zntw) + tj) << 3 : 0;
-        f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(zr, off, 0, 0));
-        v.x = covered ? v.x : -__builtin_inff();
-        v.y = covered ? v.y : __builtin_inff();
-        return v;
+        // (no select on the loaded value: it would make the wave wait for the gather right here)
+        const int off = covered ? (__mul24(ti, zntw) + tj) << 3 : zb_sentinel;
+        return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(zr, off, 0, 0));
     };
 
     // Two-stage software pipeline.  Stage A (sample k+1): position, rounded cell, issue the mask byte
@@ -741,44 +743,40 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     // past N-1 are clamped to N-1: re-evaluating the last sample changes neither the minimum nor the
     // (first) argmin, so the tail needs no branch.
     auto clampk = [&](int k) { return k < k_end ? k : k_end - 1; };
-    uint32_t ring[DEPTH];
-    f32x2 ring_z = {-__builtin_inff(), __builtin_inff()};
-    if (k_begin < k_end) {
+    struct Prefetched {  // what is gathered one group ahead: the group's mask bytes and its depth bounds
+        uint32_t m[DEPTH];
+        f32x2 z;
+    };
+    auto prefetch = [&](int kfirst, Prefetched &p) {
         int cj[DEPTH], rj[DEPTH];
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
             double px, py;
-            sample_pos(clampk(k_begin + j), px, py);
-            ring[j] = buf_load_u8(mr, mask_offset(px, py, cj[j], rj[j]));
+            sample_pos(clampk(kfirst + j), px, py);
+            p.m[j] = buf_load_u8(mr, mask_offset(px, py, cj[j], rj[j]));
         }
         if (use_zb)
-            ring_z = zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1]);
-    }
-
-    for (int k0 = k_begin; k0 < k_end; k0 += DEPTH) {
-        uint32_t mk[DEPTH];
+            p.z = zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1]);
+    };
+    // One group: issue the next group's gathers into `nxt`, then consume `cur`.  Returns false when the wave is
+    // finished (early termination).  The loop below alternates two buffers, so that the loaded registers are
+    // consumed in place -- with a single buffer copied at the loop's back edge the compiler waits for the
+    // gathers (s_waitcnt vmcnt(0)) at the END of the iteration that issued them, which exposes their whole
+    // latency on every skipped group.
+    auto group = [&](int k0, const Prefetched &cur, Prefetched &nxt) -> bool {
+        prefetch(k0 + DEPTH, nxt);
         bool none = true;
-        const f32x2 zbnd = ring_z;
-        {
-            int cj[DEPTH], rj[DEPTH];
 #pragma unroll
-            for (int j = 0; j < DEPTH; ++j) {
-                mk[j] = ring[j];
-                double px, py;  // gather the next group's mask bytes
-                sample_pos(clampk(k0 + DEPTH + j), px, py);
-                ring[j] = buf_load_u8(mr, mask_offset(px, py, cj[j], rj[j]));
-                none = none && (mk[j] == 0);
-                any_masked |= (mk[j] == 0);
-            }
-            if (use_zb)  // ... and its depth bounds
-                ring_z = zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1]);
+        for (int j = 0; j < DEPTH; ++j) {
+            none = none && (cur.m[j] == 0);
+            any_masked |= (cur.m[j] == 0);
         }
         bool run_body = __builtin_amdgcn_ballot_w64(!none) != 0ull;
         if (run_body && use_zb) {
             const float ta = (float)a.t_table[k0], tb = (float)a.t_table[clampk(k0 + DEPTH - 1)];
             const float Ta = c1 * ta, Tb = c1 * tb;
             const float Tlo = fminf(Ta, Tb), Thi = fmaxf(Ta, Tb);
-            const float Pmin = __builtin_fmaf(nrm, zbnd.x, -Qz), Pmax = __builtin_fmaf(nrm, zbnd.y, -Qz);
+            const float Pmin = __builtin_fmaf(nrm, cur.z.x, -Qz), Pmax = __builtin_fmaf(nrm, cur.z.y, -Qz);
             const float gap = fmaxf(Pmin - Thi, Tlo - Pmax);   // > 0 iff the ray clears [zmin, zmax] all along the group
             const float gap0 = fmaxf(-Qz - Thi, Tlo + Qz);     // the same for the isolated value z = 0
             const float g = fminf(gap, gap0) - Kerr;
@@ -786,72 +784,51 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
             run_body = __builtin_amdgcn_ballot_w64(!none && !cannot_win) != 0ull;
         }
         if (run_body) {
-        // phase 1: positions and texel gathers for the whole group (all in flight together)
-#ifndef GCFR_FLOOR_MODE
-#define GCFR_FLOOR_MODE 0
-#endif
-        double ux[DEPTH], uy[DEPTH];
-#if GCFR_FLOOR_MODE == 0
-        double fxd[DEPTH], fyd[DEPTH];
-#elif GCFR_FLOOR_MODE == 2
-        int fxi[DEPTH], fyi[DEPTH];
-#endif
-        f32x4 qv[DEPTH];
+            // phase 1: positions and texel gathers for the whole group (all in flight together)
+            double ux[DEPTH], uy[DEPTH], fxd[DEPTH], fyd[DEPTH];
+            f32x4 qv[DEPTH];
 #pragma unroll
-        for (int j = 0; j < DEPTH; ++j) {
-            double sx, sy;
-            sample_pos(clampk(k0 + j), sx, sy);
-            ux[j] = (sx + halfW) - 0.0001;  // unrounded position (T8:480-487)
-            uy[j] = (halfH - sy) - 0.0001;
-            const double fxd_ = __builtin_floor(ux[j]), fyd_ = __builtin_floor(uy[j]);
-            const int fx = (int)fxd_, fy = (int)fyd_;  // may be -1: the quad grid has that row / column
-#if GCFR_FLOOR_MODE == 0
-            fxd[j] = fxd_;
-            fyd[j] = fyd_;
-#elif GCFR_FLOOR_MODE == 2
-            fxi[j] = fx;
-            fyi[j] = fy;
-#endif
-            const int texel = __mul24(fy, Wp) + fx;
-            // NB: bit-cast the whole vector.  Indexing the builtin's result element-wise makes this
-            // hipcc narrow the load to ONE dword (all four corners alias) -- caught in the ISA.
-            qv[j] = __builtin_bit_cast(
-                f32x4, __builtin_amdgcn_raw_buffer_load_b128(qr, (texel << 4) + quad_origin, 0, 0));
-        }
-        // phase 2: bilinear depth, point A, squared distance numerator, running minimum
-#pragma unroll
-        for (int j = 0; j < DEPTH; ++j) {
-            const int k = clampk(k0 + j);
-            const bool masked = (mk[j] == 0);
-            const double gxd = __builtin_ceil(ux[j]), gyd = __builtin_ceil(uy[j]);
-#if GCFR_FLOOR_MODE == 0
-            const double fxd_ = fxd[j], fyd_ = fyd[j];
-#elif GCFR_FLOOR_MODE == 1
-            const double fxd_ = __builtin_floor(ux[j]), fyd_ = __builtin_floor(uy[j]);
-#else
-            const double fxd_ = (double)fxi[j], fyd_ = (double)fyi[j];
-#endif
-            const double wx0 = gxd - ux[j], wx1 = ux[j] - fxd_;
-            const double wy0 = gyd - uy[j], wy1 = uy[j] - fyd_;
-            const double zUL = qv[j].x, zUR = qv[j].y, zLL = qv[j].z, zLR = qv[j].w;
-            const double up = zUL * wx0 + zUR * wx1;
-            const double low = zLL * wx0 + zLR * wx1;
-            const double zA = up * wy0 + low * wy1;
-            const float Ax = (float)(ux[j] - halfW), Ay = (float)(halfH - uy[j]), Az = (float)zA;
-            const float BAx = Ax - x, BAy = Ay - y, BAz = Az - zb;
-            const float Xx = __builtin_fmaf(BAy, BCz, -(BAz * BCy));
-            const float Xy = __builtin_fmaf(BAz, BCx, -(BAx * BCz));
-            const float Xz = __builtin_fmaf(BAx, BCy, -(BAy * BCx));
-            const float S = ((Xx * Xx + Xy * Xy) + Xz * Xz) + kEps4;
-            const bool take = !masked && (S < bestS);
-            if (WANT_ARGMIN) {
-                prevS = take ? bestS : prevS;
-                prevk = take ? besti : prevk;
-                besti = take ? k : besti;
+            for (int j = 0; j < DEPTH; ++j) {
+                double sx, sy;
+                sample_pos(clampk(k0 + j), sx, sy);
+                ux[j] = (sx + halfW) - 0.0001;  // unrounded position (T8:480-487)
+                uy[j] = (halfH - sy) - 0.0001;
+                fxd[j] = __builtin_floor(ux[j]);
+                fyd[j] = __builtin_floor(uy[j]);
+                const int fx = (int)fxd[j], fy = (int)fyd[j];  // may be -1: the quad grid has that row / column
+                const int texel = __mul24(fy, Wp) + fx;
+                // NB: bit-cast the whole vector.  Indexing the builtin's result element-wise makes this
+                // hipcc narrow the load to ONE dword (all four corners alias) -- caught in the ISA.
+                qv[j] = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(qr, (texel << 4) + quad_origin, 0, 0));
             }
-            bestS = take ? S : bestS;
+            // phase 2: bilinear depth, point A, squared distance numerator, running minimum
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                const int k = clampk(k0 + j);
+                const bool masked = (cur.m[j] == 0);
+                const double gxd = __builtin_ceil(ux[j]), gyd = __builtin_ceil(uy[j]);
+                const double wx0 = gxd - ux[j], wx1 = ux[j] - fxd[j];
+                const double wy0 = gyd - uy[j], wy1 = uy[j] - fyd[j];
+                const double zUL = qv[j].x, zUR = qv[j].y, zLL = qv[j].z, zLR = qv[j].w;
+                const double up = zUL * wx0 + zUR * wx1;
+                const double low = zLL * wx0 + zLR * wx1;
+                const double zA = up * wy0 + low * wy1;
+                const float Ax = (float)(ux[j] - halfW), Ay = (float)(halfH - uy[j]), Az = (float)zA;
+                const float BAx = Ax - x, BAy = Ay - y, BAz = Az - zb;
+                const float Xx = __builtin_fmaf(BAy, BCz, -(BAz * BCy));
+                const float Xy = __builtin_fmaf(BAz, BCx, -(BAx * BCz));
+                const float Xz = __builtin_fmaf(BAx, BCy, -(BAy * BCx));
+                const float S = ((Xx * Xx + Xy * Xy) + Xz * Xz) + kEps4;
+                const bool take = !masked && (S < bestS);
+                if (WANT_ARGMIN) {
+                    prevS = take ? bestS : prevS;
+                    prevk = take ? besti : prevk;
+                    besti = take ? k : besti;
+                }
+                bestS = take ? S : bestS;
+            }
         }
-        }  // run_body
         if (use_zb && k0 + DEPTH < k_end) {  // early termination, see Dcap
             const float tn = (float)a.t_table[k0 + DEPTH];
             const float gd = __builtin_fmaf(c1, tn, -Dcap);
@@ -859,9 +836,23 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
                                   (lane_last < k0 + DEPTH);
             if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) {
                 any_masked |= (lane_last < k0 + DEPTH);
-                break;
+                return false;
             }
         }
+        return true;
+    };
+
+    Prefetched bufA, bufB;
+    bufA.z = bufB.z = f32x2{-__builtin_inff(), __builtin_inff()};
+    if (k_begin < k_end)
+        prefetch(k_begin, bufA);
+    for (int k0 = k_begin; k0 < k_end; k0 += 2 * DEPTH) {
+        if (!group(k0, bufA, bufB))
+            break;
+        if (k0 + DEPTH >= k_end)
+            break;
+        if (!group(k0 + DEPTH, bufB, bufA))
+            break;
     }
 
     if (KSPLIT) {  // combine the four sample-range quarters of this tile
@@ -1190,7 +1181,7 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         // small launches: split every tile's sample range over the 4 waves of its workgroup (finer, more
         // uniform work items); large launches keep one tile per wave (less per-pixel prologue work).
         const long long tiles_total = (long long)B * L * tiles_x * ((H + TILE_H - 1) / TILE_H);
-        const bool ksplit = (g_ksplit < 0) ? (tiles_total <= 4096 && N >= 16) : (g_ksplit == 1);  // measured: helps B<=4 at 256^2
+        const bool ksplit = (g_ksplit < 0) ? (tiles_total <= 2048 && N >= 16) : (g_ksplit == 1);  // measured: helps B<=2 at 256^2 (a quarter-range wave starts the depth-bound skip without a running minimum)
         a.ksplit = ksplit ? 1 : 0;
         a.quads_x = ksplit ? tiles_x : quads_x;
         a.quads_y = (H + TILE_H - 1) / TILE_H;

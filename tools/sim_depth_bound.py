@@ -112,6 +112,7 @@ def run(seed=0, tile=(2, 32), depth_group=4, stride=8, H=256, W=256, N=160, t0=0
         assert not bad.any(), (g, int(bad.sum()))
         exec_perf += (Smin < best).reshape(H // th, th, W // tw, tw).any(axis=(1, 3))
         best = np.minimum(best, Smin)
+    run.last = dict(now=exec_now.copy(), new=exec_new.copy(), perf=exec_perf.copy())
     total = n_groups * exec_now.size
     print(f"seed {seed} light {light[0]}  wave-groups: all {total}  mask-skip {exec_now.sum()} "
           f"({exec_now.sum() / total:.3f})  +depth-bound {exec_new.sum()} ({exec_new.sum() / total:.3f})  "
@@ -126,3 +127,11 @@ if __name__ == "__main__":
         a += n0
         b += n1
     print("overall ratio", b / a)
+
+
+def per_wave_histogram(seed=0, tile=(8, 8)):
+    """bodies per wave (min/max bound), to judge load imbalance"""
+    import io, contextlib
+    global _HOOK
+    _HOOK = []
+    run(seed=seed, tile=tile)
