@@ -176,6 +176,12 @@ def main():
     ap.add_argument("--from-depth", action="store_true",
                     help="also compute the normals (T8:353-354) inside the march epilogue instead of reading them "
                          "(SURVEY 8d's 17.4 B/ray-step accounting counts normals as a 12 B/pixel input, the default)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="issue successive steps round-robin on this many HIP streams, one RenderFwdPlan (own outputs "
+                         "and workspace) per stream: independent batches overlap, the next step's prepass and "
+                         "prologue fill the previous march's tail (B=8 is 8192 waves for 256 CUs).  1 = one stream")
+    ap.add_argument("--eager", action="store_true",
+                    help="call render_fwd (allocates its outputs per call, ~60 us of host time) instead of a plan")
     ap.add_argument("--size", type=int, default=256, help="other workloads: image side (config 5: 512)")
     ap.add_argument("--lights", type=int, default=1, help="lights per face (config 5: 18)")
     ap.add_argument("--samples", type=int, default=160, help="march steps (config 5: 320)")
@@ -239,12 +245,23 @@ def main():
         assert hip.hipEventCreate(ctypes.byref(e)) == 0
         return e
 
+    cam = (1570.0 * Hh / 256.0, 1570.0 * Hh / 256.0, Ww / 2.0, Hh / 2.0, 1610.0)
+    plans = None
+    if not (a.eager or a.direct or a.unfused):
+        d_mask_u8 = R.mask_to_u8(d_mask).reshape(-1, Hh, Ww).contiguous()
+        d_light3, d_amb2 = d_light.reshape(B, Ll, 3).contiguous(), d_amb.reshape(B, Ll).contiguous()
+        plans = [R.RenderFwdPlan(B, Ll, Hh, Ww, prm, dev, want_argmin=False, mask_batch=d_mask_u8.shape[0],
+                                 camera=cam if a.from_depth else None) for _ in range(max(1, a.streams))]
+
     def step(timed):
         if timed:
             e0, e1 = new_event(), new_event()
             _lib.check(L_.gcfr_profile_events(e0, e1), "gcfr_profile_events")
             ev_pairs.append((e0, e1))
-        if a.direct or a.unfused:
+        if plans is not None:
+            out = plans[step.i % len(plans)](d_depth, d_mask_u8, d_light3, d_amb2, None if a.from_depth else d_normals,
+                                             d_albedo)
+        elif a.direct or a.unfused:
             _, pt = R.light_prep(d_light, prm)
             md, _ = R.shadow_min_distance(d_depth, d_mask, pt.reshape(B, Ll, 3), prm, want_argmin=False,
                                           use_workspace=not a.direct)
@@ -252,14 +269,22 @@ def main():
         else:
             out = R.render_fwd(d_depth, d_mask, d_light.reshape(B, Ll, 3), d_amb.reshape(B, Ll),
                                None if a.from_depth else d_normals, d_albedo, prm, want_argmin=False,
-                               camera=(1570.0 * Hh / 256.0, 1570.0 * Hh / 256.0, Ww / 2.0, Hh / 2.0, 1610.0)
-                               if a.from_depth else None)
+                               camera=cam if a.from_depth else None)
         if timed:
             _lib.check(L_.gcfr_profile_events(None, None), "gcfr_profile_events")
         return out
 
-    for _ in range(a.warmup):
-        step(False)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(a.streams)] if a.streams > 1 else None
+
+    def run_step(i, timed):
+        step.i = i
+        if streams is None:
+            return step(timed)
+        with torch.cuda.stream(streams[i % len(streams)]):
+            return step(timed)
+
+    for i in range(a.warmup):
+        run_step(i, False)
 
     def fence():
         torch.cuda.synchronize()
@@ -269,14 +294,30 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(True)
+    for i in range(a.steps):
+        run_step(i, True)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    def single_stream_reference(n=100):
+        """the same steps on ONE stream, after the timed region (information only): per-step time and the
+        march's un-overlapped launch duration"""
+        saved = ev_pairs[:]
+        del ev_pairs[:]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n):
+            step.i = 0
+            step(True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        ms = float(np.mean([elapsed_ms(e0, e1) for e0, e1 in ev_pairs]))
+        ev_pairs[:] = saved
+        return {"ms_per_step": 1e3 * dt / n, "ray_steps_per_sec": B * Ll * Hh * Ww * Nn * n / dt, "avg_launch_ms": ms}
 
     ray_steps_per_step = world * B * Ll * Hh * Ww * Nn
     value = ray_steps_per_step * a.steps / elapsed
@@ -303,7 +344,8 @@ def main():
                                    ("non-headline: batch=%d synthetic %dx%d faces per GPU, %d light(s) each, %d march "
                                     "steps, mask=%s, forward-only shadow+shade" % (B, Hh, Ww, Ll, Nn, a.mask)),
                        "faces_per_gpu": B, "H": Hh, "W": Ww, "lights_per_face": Ll, "n_samples": Nn,
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world, "hip_streams": (a.streams if plans is not None or streams else 1),
+                       "host_path": "RenderFwdPlan (preallocated outputs)" if plans is not None else "render_fwd (eager)"},
             "faces_per_sec": world * B * Ll * a.steps / elapsed,
             "ray_steps_per_sec_per_gpu": value / world,
             "roofline": {"bound": "hbm", "note": "north_star's HBM accounting; the gathers are cache-served (traffic << "
@@ -314,6 +356,10 @@ def main():
                          "kernel_ray_steps_per_sec": B * Ll * Hh * Ww * Nn / (shadow_ms * 1e-3),
                          "measured_copy_GBs": measured_copy_bandwidth_gbs(dev)},
         }
+        if streams is not None:
+            out["roofline"]["note"] += ("; avg_launch_ms is measured with %d streams in flight (launches of "
+                                        "successive steps overlap, which lengthens each one)" % a.streams)
+            out["single_stream"] = single_stream_reference()
         if world == 1 and not a.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline_c_openmp"] = cpu_baseline_c()

@@ -317,6 +317,59 @@ def render(depth, albedo, light, ambient, normals, mask, params: RenderParams = 
     )
 
 
+class RenderFwdPlan:
+    """Steady-state forward for fixed shapes: outputs and workspace are allocated once and every call is ONE
+    ctypes call on the current stream (no per-call allocation or argument marshalling: the eager `render_fwd`
+    spends ~60 us of host time per call, which bounds a B=8 step once two streams keep the GPU full).
+    Results are overwritten by the next call on the same plan -- use one plan per stream / per batch in flight.
+    Inputs must already be device tensors of the planned shapes and dtypes (f32, mask u8)."""
+
+    def __init__(self, B, L, H, W, params: RenderParams = RenderParams(), device="cuda", want_argmin=False,
+                 mask_batch=None, camera=None):
+        self.L_ = _lib.load()
+        dev = torch.device(device)
+        self.dev, self.params, self.shape, self.camera = dev, params, (B, L, H, W), camera
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.tt = sample_table(params, dev)
+        o = dict(unit_light_direction=torch.empty((B, L, 3), **f32), light_pt=torch.empty((B, L, 3), **f32),
+                 minimum_distance=torch.empty((B, L, H, W), **f32),
+                 argmin=torch.empty((B, L, H, W), dtype=torch.int32, device=dev) if want_argmin else None,
+                 shadow_mask_weights=torch.empty((B, L, H, W), **f32), full_shading=torch.empty((B, L, H, W), **f32),
+                 final_shading=torch.empty((B, L, H, W), **f32), rendered_images=torch.empty((B, L, 3, H, W), **f32))
+        if camera is not None:
+            o["surface_normals"] = torch.empty((B, 3, H, W), **f32)
+        self.out = o
+        self.ws_bytes = int(self.L_.gcfr_shadow_workspace_bytes(B, H, W))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.box = ctypes_float4(params.bonus_box) if params.bonus_box is not None else None
+        self.mask_batch = B if mask_batch is None else mask_batch
+        self._tail = (B, L, H, W, params.n_samples, self.tt.data_ptr(), float(params.inside_bonus), self.box,
+                      float(params.directional_intensity), o["unit_light_direction"].data_ptr(),
+                      o["light_pt"].data_ptr(), o["minimum_distance"].data_ptr(), _opt_ptr(o["argmin"]))
+        self._outs = (o["shadow_mask_weights"].data_ptr(), o["full_shading"].data_ptr(),
+                      o["final_shading"].data_ptr(), o["rendered_images"].data_ptr(), self.ws.data_ptr(),
+                      self.ws_bytes)
+        self._head = (int(params.clamp_light_z_min is not None), float(params.clamp_light_z_min or 0.0),
+                      float(params.light_distance))
+
+    def __call__(self, depth, mask_u8, light, ambient, normals, albedo):
+        """depth (B,H,W) f32, mask_u8 (B|1,H,W) u8, light (B,L,3) f32, ambient (B,L) f32, albedo (B,3,H,W) f32,
+        normals (B,3,H,W) f32 or None (plan built with camera=...).  All contiguous, on the plan's device."""
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        if self.camera is None:
+            rc = self.L_.gcfr_render_fwd(light.data_ptr(), *self._head, depth.data_ptr(), mask_u8.data_ptr(),
+                                         self.mask_batch, normals.data_ptr(), albedo.data_ptr(), ambient.data_ptr(),
+                                         *self._tail, *self._outs, st)
+        else:
+            fx, fy, cx, cy, z_off = [float(v) for v in self.camera]
+            rc = self.L_.gcfr_render_from_depth_fwd(light.data_ptr(), *self._head, depth.data_ptr(),
+                                                    mask_u8.data_ptr(), self.mask_batch, fx, fy, cx, cy, z_off, 1,
+                                                    albedo.data_ptr(), ambient.data_ptr(), *self._tail,
+                                                    self.out["surface_normals"].data_ptr(), *self._outs, st)
+        _lib.check(rc, "gcfr_render_fwd (plan)")
+        return self.out
+
+
 class GraphedRenderFwd:
     """hipGraph replay of the forward block for fixed shapes.  Captures one `render_fwd` call (two kernels,
     launched through ctypes on the capturing stream) on static buffers; `__call__` copies the new inputs into

@@ -402,3 +402,36 @@ def test_depth_bound_skip_is_exact_for_every_tile_shape(Hs, Ws, N, dt):
         L_.gcfr_tune(3, 1)
         L_.gcfr_tune(0, 0)
         L_.gcfr_tune(1, 4)
+
+
+def test_render_fwd_plan_matches_eager_call_and_overlaps_on_two_streams():
+    """RenderFwdPlan (preallocated outputs, one ctypes call) gives the bits of render_fwd; two plans driven
+    round-robin on two streams (bench.py's default) do not disturb each other."""
+    from geomconsistentfr_amd import RenderParams
+    from geomconsistentfr_amd import block as R
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    B, L, Hs, Ws = 3, 2, 96, 128
+    r, c = np.mgrid[0:Hs, 0:Ws]
+    batches = []
+    for s in range(2):
+        depth = (30 * np.exp(-(((c - 60 - 5 * s) / 30.0) ** 2 + ((r - 50) / 35.0) ** 2)) + rng.random((B, Hs, Ws))).astype(np.float32)
+        mask = (rng.random((B, Hs, Ws)) > 0.2).astype(np.uint8)
+        light = rng.standard_normal((B, L, 3)).astype(np.float32)
+        amb = (0.3 + 0.4 * rng.random((B, L))).astype(np.float32)
+        nrm = rng.standard_normal((B, 3, Hs, Ws)).astype(np.float32)
+        alb = rng.random((B, 3, Hs, Ws)).astype(np.float32)
+        batches.append([torch.from_numpy(t).to(dev) for t in (depth, mask, light, amb, nrm, alb)])
+    prm = RenderParams(n_samples=64, dt=0.0125)
+    ref = [R.render_fwd(*bt, prm, want_argmin=True) for bt in batches]
+    plans = [R.RenderFwdPlan(B, L, Hs, Ws, prm, dev, want_argmin=True) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    for it in range(6):
+        with torch.cuda.stream(streams[it % 2]):
+            plans[it % 2](*batches[it % 2])
+    torch.cuda.synchronize()
+    for s in range(2):
+        for k, v in ref[s].items():
+            if v is not None:
+                assert torch.equal(plans[s].out[k], v), (s, k)
