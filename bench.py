@@ -176,7 +176,7 @@ def main():
     ap.add_argument("--from-depth", action="store_true",
                     help="also compute the normals (T8:353-354) inside the march epilogue instead of reading them "
                          "(SURVEY 8d's 17.4 B/ray-step accounting counts normals as a 12 B/pixel input, the default)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="issue successive steps round-robin on this many HIP streams, one RenderFwdPlan (own outputs "
                          "and workspace) per stream: independent batches overlap, the next step's prepass and "
                          "prologue fill the previous march's tail (B=8 is 8192 waves for 256 CUs).  1 = one stream")

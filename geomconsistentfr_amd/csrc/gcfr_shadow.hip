@@ -336,37 +336,90 @@ __device__ inline int zb_log2_stride(int H, int W, int N, const double *t_table,
 // records per image: the tiles at the finest stride plus one sentinel (-inf, +inf) that uncovered footprints read
 __host__ __device__ inline int zb_max_tiles(int H, int W) { return ((H >> 3) + 1) * ((W >> 3) + 1) + 1; }
 
+// Sum over each 16-lane row of the wave, result in every lane of the row's last lane ... read with readlane(row*16+15).
+__device__ inline float row_sum_f32(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false));
+    return v;  // lane 15 of each row holds the row's sum
+}
+__device__ inline float lane_value(float v, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
 // One wave per tile; `block` counts the 4-wave workgroups assigned to this job (the head of the prepass grid).
+// Record {a, b, c_lo, c_hi}: every cell of the tile satisfies  a X + b Y + c_lo <= z <= a X + b Y + c_hi  with
+// (X, Y) the cell's coordinates in the kernel's frame (X = column - W/2, Y = H/2 - row; the wrap row / column sit
+// at row / column -1).  A bilinear sample is a convex combination of four cells whose weighted mean position is
+// the sample position, so the same band bounds it AT the sample position -- on a smooth surface the band is
+// curvature-sized where a plain min/max is slope-sized.  (a, b) comes from the means of the tile's four
+// quadrants, clamped to +-4; any (a, b) is valid, the residual extrema make it so.
 __device__ inline void build_zbounds_block(int block, int b, const float *__restrict__ depth,
-                                           float2 *__restrict__ zb, int H, int W, int N,
+                                           float4 *__restrict__ zb, int H, int W, int N,
                                            const double *__restrict__ t_table, int group)
 {
     const int ls = zb_log2_stride(H, W, N, t_table, group);
     const int ntw = (W >> ls) + 1, nth = (H >> ls) + 1;
     const int tile = block * 4 + (int)(threadIdx.x >> 6);
     if (block == 0 && threadIdx.x == 0)
-        zb[(size_t)b * zb_max_tiles(H, W) + zb_max_tiles(H, W) - 1] = make_float2(-__builtin_inff(), __builtin_inff());
+        zb[(size_t)b * zb_max_tiles(H, W) + zb_max_tiles(H, W) - 1] =
+            make_float4(0.0f, 0.0f, -__builtin_inff(), __builtin_inff());
     if (tile >= nth * ntw)
         return;
     const int lane = threadIdx.x & 63;
     const int ti = tile / ntw, tj = tile - ti * ntw;
     const int side = 2 << ls;
     const float *z = depth + (size_t)b * H * W;
+    // pass 1: slopes from the means of the tile's four s x s quadrants (finite proper cells only).  Row q of
+    // the wave (16 lanes) owns quadrant q = 2*qy + qx and strides over its cells, so the four sums come out of
+    // DPP row reductions with no cross-row traffic.
+    const int s = 1 << ls;
+    const int q = lane >> 4, ql = lane & 15;
+    const int qy = q >> 1, qx = q & 1;
+    float cnt = 0.0f, sz = 0.0f;
+    for (int e = ql; e < s * s; e += 16) {
+        const int er = (ti << ls) + (qy << ls) + (e >> ls), ec = (tj << ls) + (qx << ls) + (e & (s - 1));
+        if (er >= 1 && ec >= 1 && er <= H && ec <= W) {
+            const float v = z[(size_t)(er - 1) * W + (ec - 1)];
+            if (v - v == 0.0f) {
+                cnt += 1.0f;
+                sz += v;
+            }
+        }
+    }
+    cnt = row_sum_f32(cnt);
+    sz = row_sum_f32(sz);
+    const float n00 = lane_value(cnt, 15), n01 = lane_value(cnt, 31), n10 = lane_value(cnt, 47), n11 = lane_value(cnt, 63);
+    float pa = 0.0f, pb = 0.0f;
+    if (n00 > 0.0f && n01 > 0.0f && n10 > 0.0f && n11 > 0.0f) {  // all four quadrants populated (interior tiles)
+        const float m00 = lane_value(sz, 15) / n00, m01 = lane_value(sz, 31) / n01;
+        const float m10 = lane_value(sz, 47) / n10, m11 = lane_value(sz, 63) / n11;
+        const float inv = 0.5f / (float)s;  // quadrant centres are s apart
+        const float ca = ((m01 + m11) - (m00 + m10)) * inv, cb = ((m10 + m11) - (m00 + m01)) * inv;
+        if (ca - ca == 0.0f)
+            pa = fminf(fmaxf(ca, -4.0f), 4.0f);   // dz/dX: X grows with the column
+        if (cb - cb == 0.0f)
+            pb = -fminf(fmaxf(cb, -4.0f), 4.0f);  // dz/dY: Y falls with the row
+    }
+    // pass 2: residual extrema over every cell of the tile, wrap row / column included
     float lo = __builtin_inff(), hi = -__builtin_inff();
-    auto cell = [&](int e) -> float {  // NaN (ignored by fminf / fmaxf) outside the extended grid
+    for (int e = lane; e < side * side; e += 64) {
         const int er = (ti << ls) + (e >> (ls + 1)), ec = (tj << ls) + (e & (side - 1));
-        const int r = er == 0 ? H - 1 : er - 1, c = ec == 0 ? W - 1 : ec - 1;
-        return (e < side * side && er <= H && ec <= W) ? z[(size_t)r * W + c] : __builtin_nanf("");
-    };
-    for (int e = lane; e < side * side; e += 256) {  // four independent loads in flight per pass
-        const float v0 = cell(e), v1 = cell(e + 64), v2 = cell(e + 128), v3 = cell(e + 192);
-        lo = fminf(fminf(lo, v0), fminf(fminf(v1, v2), v3));  // NaN cells are ignored: a NaN sample never wins
-        hi = fmaxf(fmaxf(hi, v0), fmaxf(fmaxf(v1, v2), v3));
+        if (er <= H && ec <= W) {
+            const int r = er == 0 ? H - 1 : er - 1, c = ec == 0 ? W - 1 : ec - 1;
+            const float X = (float)(ec - 1) - 0.5f * (float)W, Y = 0.5f * (float)H - (float)(er - 1);
+            const float res = z[(size_t)r * W + c] - __builtin_fmaf(pa, X, pb * Y);
+            lo = fminf(lo, res);  // NaN cells are ignored: a NaN sample never wins the minimum
+            hi = fmaxf(hi, res);
+        }
     }
     const float wlo = f32_unsortable(wave_min_i32(f32_sortable(lo)));
     const float whi = -f32_unsortable(wave_min_i32(f32_sortable(-hi)));
     if (lane == 0)
-        zb[(size_t)b * zb_max_tiles(H, W) + tile] = make_float2(wlo, whi);
+        zb[(size_t)b * zb_max_tiles(H, W) + tile] = make_float4(pa, pb, wlo, whi);
 }
 
 // Prepass.  Per image: (a) repack depth into 2x2-neighbourhood texels, (b) optional light preparation,
@@ -377,7 +430,7 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
                                                          PrepassLights pl,
                                                          const uint8_t *__restrict__ mask, int mask_batch,
                                                          int *__restrict__ bbox, int *__restrict__ zrange,
-                                                         float2 *__restrict__ zb, int quad_blocks, int N,
+                                                         float4 *__restrict__ zb, int quad_blocks, int N,
                                                          const double *__restrict__ t_table, int group)
 {
     const int Wp = W + 1, Hp = H + 1;
@@ -453,7 +506,7 @@ struct ShadowQuadArgs {
     const float *depth;     // (B,H,W)      own-pixel depth
     const float4 *quad;     // (B,H+1,W+1)  prepass output
     const int *bbox;        // (MB,P/256,4) prepass output: partial mask bounding boxes {r_min, c_min, -r_max, -c_max}
-    const float2 *zb;       // (B,zb_max_tiles) prepass output: depth bounds grid, or null (bound skip off)
+    const float4 *zb;       // (B,zb_max_tiles) prepass output: depth bounds grid {a, b, c_lo, c_hi}, or null (skip off)
     const int *zrange;      // (B,P/256,2) prepass output: partial depth ranges {z_min, -z_max} (sortable ints)
     const uint8_t *mask;    // (MB,H,W)
     const float *light_pt;  // (B,L,3)
@@ -670,7 +723,7 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     const int zls = use_zb ? __builtin_amdgcn_readfirstlane(zb_log2_stride(H, W, a.N, a.t_table, DEPTH)) : 3;
     const int zntw = (W >> zls) + 1;
     const __amdgpu_buffer_rsrc_t zr =
-        make_rsrc(a.zb + (size_t)b * zb_max_tiles(H, W), zb_max_tiles(H, W) * (int)sizeof(float2));
+        make_rsrc(a.zb + (size_t)b * zb_max_tiles(H, W), zb_max_tiles(H, W) * (int)sizeof(float4));
     const float nrm = __builtin_sqrtf(BCx * BCx + BCy * BCy);
     const float c1 = BCz * ((dxf * BCx + dyf * BCy) / nrm);
     const float Qz = nrm * zb;
@@ -690,7 +743,9 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
         const float rr = fmaxf(fmaxf(fabsf(gz_lo - zb), fabsf(gz_hi - zb)), fmaxf(fabsf(zb), (float)max(H, W)));
         const float K1 = 4e-3f * fabsf(BCz) + 1e-6f * fabsf(c1) * t_abs;
         const float K2 = 1e-6f * nrm + 2e-7f * ((fabsf(BCx) + fabsf(BCy)) + fabsf(BCz));
-        const float K = __builtin_fmaf(K2, rr, K1);
+        // + the plane evaluation: position offsets (1e-4, t d vs the rounded BA_xy) times |a| + |b| <= 8, and the
+        //   f32 roundings of a X + b Y (|.| <= 8 max(H, W)) at build and at test time
+        const float K = __builtin_fmaf(K2, rr, K1) + nrm * (1.2e-2f + 8e-6f * (float)max(H, W));
         if ((nrm > 0.0f) && finite_ray && (K - K == 0.0f)) {
             Kerr = K;
             if (c1 > 0.0f)
@@ -701,19 +756,19 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
         const float s_lane = (den2 - den2 == 0.0f) ? 0.98e12f * den2 : 0.0f;
         safeS = f32_unsortable(__builtin_amdgcn_readfirstlane(wave_min_i32(f32_sortable(s_lane))));
     }
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
+
     // bounds of the cells a group can touch, given the rounded cells of its first and last sample:
     // floor(u) and ceil(u) lie in [rint(s) - 1, rint(s) + 1], so the extended indices are [min, max + 2].
     // A footprint the selected tile does not cover reads the sentinel record (-inf, +inf): it never skips.
-    const int zb_sentinel = (zb_max_tiles(H, W) - 1) << 3;
-    auto zb_fetch = [&](int ca, int ra, int cb, int rb) -> f32x2 {
+    const int zb_sentinel = (zb_max_tiles(H, W) - 1) << 4;
+    auto zb_fetch = [&](int ca, int ra, int cb, int rb) -> f32x4 {
         const int cmin = min(ca, cb), cmax = max(ca, cb), rmin = min(ra, rb), rmax = max(ra, rb);
         const int tj = cmin >> zls, ti = rmin >> zls;
         const bool covered = (cmin >= 0) && (rmin >= 0) && (cmax <= W - 1) && (rmax <= H - 1) &&
                              (cmax + 2 <= ((tj + 2) << zls) - 1) && (rmax + 2 <= ((ti + 2) << zls) - 1);
         // (no select on the loaded value: it would make the wave wait for the gather right here)
-        const int off = covered ? (__mul24(ti, zntw) + tj) << 3 : zb_sentinel;
-        return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(zr, off, 0, 0));
+        const int off = covered ? (__mul24(ti, zntw) + tj) << 4 : zb_sentinel;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, off, 0, 0));
     };
 
     // Two-stage software pipeline.  Stage A (sample k+1): position, rounded cell, issue the mask byte
@@ -745,7 +800,7 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     auto clampk = [&](int k) { return k < k_end ? k : k_end - 1; };
     struct Prefetched {  // what is gathered one group ahead: the group's mask bytes and its depth bounds
         uint32_t m[DEPTH];
-        f32x2 z;
+        f32x4 z;  // {a, b, c_lo, c_hi}
     };
     auto prefetch = [&](int kfirst, Prefetched &p) {
         int cj[DEPTH], rj[DEPTH];
@@ -776,8 +831,13 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
             const float ta = (float)a.t_table[k0], tb = (float)a.t_table[clampk(k0 + DEPTH - 1)];
             const float Ta = c1 * ta, Tb = c1 * tb;
             const float Tlo = fminf(Ta, Tb), Thi = fmaxf(Ta, Tb);
-            const float Pmin = __builtin_fmaf(nrm, cur.z.x, -Qz), Pmax = __builtin_fmaf(nrm, cur.z.y, -Qz);
-            const float gap = fmaxf(Pmin - Thi, Tlo - Pmax);   // > 0 iff the ray clears [zmin, zmax] all along the group
+            // surface band at the sample position s(t) = (x, y) + t d:  z in A0 + t A1 + [c_lo, c_hi], so
+            // G(t) = n (z - zb) - c1 t  lies in  [F_lo + t E, F_hi + t E]: linear in t, extremes at the group's ends
+            const float A0 = __builtin_fmaf(cur.z.x, x, cur.z.y * y), A1 = __builtin_fmaf(cur.z.x, dxf, cur.z.y * dyf);
+            const float E = __builtin_fmaf(nrm, A1, -c1);
+            const float Flo = __builtin_fmaf(nrm, A0 + cur.z.z, -Qz), Fhi = __builtin_fmaf(nrm, A0 + cur.z.w, -Qz);
+            const float eA = ta * E, eB = tb * E;
+            const float gap = fmaxf(Flo + fminf(eA, eB), -(Fhi + fmaxf(eA, eB)));  // > 0 iff the band stays clear of the ray
             const float gap0 = fmaxf(-Qz - Thi, Tlo + Qz);     // the same for the isolated value z = 0
             const float g = fminf(gap, gap0) - Kerr;
             const bool cannot_win = (g > 0.0f) && (g * g * 0.998f > bestS);
@@ -843,7 +903,7 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     };
 
     Prefetched bufA, bufB;
-    bufA.z = bufB.z = f32x2{-__builtin_inff(), __builtin_inff()};
+    bufA.z = bufB.z = f32x4{0.0f, 0.0f, -__builtin_inff(), __builtin_inff()};
     if (k_begin < k_end)
         prefetch(k_begin, bufA);
     for (int k0 = k_begin; k0 < k_end; k0 += 2 * DEPTH) {
@@ -1037,7 +1097,7 @@ extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
         return 0;
     const size_t n_partials = ((size_t)H * W + 255) / 256;
     return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4) + (size_t)B * n_partials * 4 * sizeof(int) +
-           (size_t)B * (size_t)zb_max_tiles(H, W) * sizeof(float2) + (size_t)B * n_partials * 2 * sizeof(int);
+           (size_t)B * (size_t)zb_max_tiles(H, W) * sizeof(float4) + (size_t)B * n_partials * 2 * sizeof(int);
 }
 
 // Optional profiling hook: events recorded around the dominant (march) kernel of the next launches.
@@ -1152,7 +1212,7 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         const int texels = (H + 1) * (W + 1);
         int *bbox = (int *)((char *)workspace + (size_t)B * texels * sizeof(float4));
         const size_t n_partials = ((size_t)H * W + 255) / 256;
-        float2 *zb = (float2 *)((char *)bbox + (size_t)B * n_partials * 4 * sizeof(int));
+        float4 *zb = (float4 *)((char *)bbox + (size_t)B * n_partials * 4 * sizeof(int));
         int *zrange = (int *)(zb + (size_t)B * zb_max_tiles(H, W));  // (B, n_partials, 2)
         const bool use_zb = g_zbound && N >= 2;
         const int quad_blocks = (texels + 255) / 256;
