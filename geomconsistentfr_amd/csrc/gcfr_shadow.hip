@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     // consumed in place -- with a single buffer copied at the loop's back edge the compiler waits for the
     // gathers (s_waitcnt vmcnt(0)) at the END of the iteration that issued them, which exposes their whole
     // latency on every skipped group.
-    auto group = [&](int k0, const Prefetched &cur, Prefetched &nxt) -> bool {
+    auto group = [&](int k0, const Prefetched &cur, Prefetched &nxt, bool check_finished) -> bool {
         prefetch(k0 + DEPTH, nxt);
         bool none = true;
 #pragma unroll
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
                 bestS = take ? S : bestS;
             }
         }
-        if (use_zb && k0 + DEPTH < k_end) {  // early termination, see Dcap
+        if (check_finished && use_zb && k0 + DEPTH < k_end) {  // early termination, see Dcap
             const float tn = (float)a.t_table[k0 + DEPTH];
             const float gd = __builtin_fmaf(c1, tn, -Dcap);
             const bool finished = ((gd > 0.0f) && (gd * gd * 0.998f > bestS) && (bestS < safeS)) ||
@@ -907,11 +907,11 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     if (k_begin < k_end)
         prefetch(k_begin, bufA);
     for (int k0 = k_begin; k0 < k_end; k0 += 2 * DEPTH) {
-        if (!group(k0, bufA, bufB))
+        if (!group(k0, bufA, bufB, false))
             break;
         if (k0 + DEPTH >= k_end)
             break;
-        if (!group(k0 + DEPTH, bufB, bufA))
+        if (!group(k0 + DEPTH, bufB, bufA, true))  // the termination test runs every other group (it costs ~18 VALU)
             break;
     }
 
