@@ -311,8 +311,8 @@ __device__ inline float f32_unsortable(int i)
 }
 
 // ----------------------------------------------------------------------------------------------
-// Depth bounds ("hierarchical z") grid.  Tile (i, j) of stride s = 2^ls holds the minimum and maximum
-// depth over the 2s x 2s cells whose EXTENDED indices (row r+1, column c+1, with r = c = -1 the
+// Depth bounds ("hierarchical z") grid.  Tile (i, j) of stride s = 2^ls bounds the depth (a band around a plane,
+// see build_zbounds_block) over the 2s x 2s cells whose EXTENDED indices (row r+1, column c+1, with r = c = -1 the
 // reference's wrap-around to the last row / column) lie in [i*s, i*s + 2s) x [j*s, j*s + 2s): tiles
 // overlap by half, so any footprint of at most s+1 cells per axis lies inside the tile that its lowest
 // index selects.  The march uses it to skip sample groups that provably cannot lower a lane's running
@@ -712,14 +712,16 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     //     S_k >= Xx^2 + Xy^2 >= G^2,   G = n (z - zb) - BCz (BA_xy . u)/n,   u = BC_xy, n = |u|
     // (Cauchy-Schwarz on the two cross-product components that involve z): n (z - zb) is how far the sampled
     // surface is from the pixel's own depth and the second term how high the ray is there, both scaled by n.
-    // (BA_xy . u)/n is t_k (d . u)/n to within 7e-4 (the 1e-4 offset and the f32 roundings of T8:480-487), so
-    // over one group of samples and z in [zmin, zmax] -- the depth bounds of the cells the group can touch,
-    // from the prepass' grid -- |G| is at least `gap` below, evaluated at the group's first and last sample.
-    // The reference's bilinear weights are both 0 when a coordinate is integral, which samples z = 0: that
-    // isolated value is tested too (gap0).  Kerr = K1 + K2 r over-estimates every rounding between G and the
-    // f32 S the body would compute (r bounds |BA|'s components over the image); a lane votes "skip" only if the bound exceeds its
-    // running minimum by a further 0.1 %, so a skipped sample could not have been taken and the minimum,
-    // its index and the tie predecessor are what the full march gives.
+    // (BA_xy . u)/n is t_k (d . u)/n to within 7e-4 (the 1e-4 offset and the f32 roundings of T8:480-487).  The
+    // prepass' tile record bounds the surface by a band around a plane, z in a X + b Y + [c_lo, c_hi], valid at
+    // the bilinear sample POSITION (see build_zbounds_block), so along one group of samples G is a linear
+    // function of t inside [F_lo + t E, F_hi + t E] and |G| is at least `gap` below, evaluated at the group's
+    // first and last sample.  The reference's bilinear weights are both 0 when a coordinate is integral, which
+    // samples z = 0: that isolated value is tested too (gap0).  Kerr over-estimates every rounding between G
+    // and the f32 S the body would compute (K1 + K2 r, r bounding |BA|'s components over the image, plus the
+    // plane evaluation's terms); a lane votes "skip" only if the bound exceeds its running minimum by a further
+    // 0.2 %, so a skipped sample could not have been taken and the minimum, its index and the tie predecessor
+    // are what the full march gives.
     const int zls = use_zb ? __builtin_amdgcn_readfirstlane(zb_log2_stride(H, W, a.N, a.t_table, DEPTH)) : 3;
     const int zntw = (W >> zls) + 1;
     const __amdgpu_buffer_rsrc_t zr =

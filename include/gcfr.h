@@ -74,7 +74,7 @@ int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_z, float cl
  *   workspace   device scratch of >= gcfr_shadow_workspace_bytes(B,H,W) bytes, or NULL.
  *               With a workspace the depth maps are first repacked into 2x2-neighbourhood texels
  *               (one 16-byte gather per ray-step instead of four 4-byte gathers) and a coarse grid of
- *               depth minima / maxima lets the march skip sample groups that provably cannot lower a
+ *               depth bounds lets the march skip sample groups that provably cannot lower a
  *               pixel's running minimum; results are bit-identical to the NULL-workspace path, only
  *               faster.  Contents are scratch.
  * Supported: 2 <= H,W <= 4096, even; 1 <= N <= 4096.
