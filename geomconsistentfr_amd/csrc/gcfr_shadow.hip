@@ -616,10 +616,13 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     // rays that have left (or never reach) the face.  Requires the sample table to be monotone and
     // uniformly spaced to within half a step, which gcfr_sample_table guarantees.
     int k_begin = k_lo, k_end = N;  // [k_begin, k_end)
-    const bool use_zb = a.zb != nullptr;
+    // the pruning / skipping machinery below reasons about an INCREASING sample table (gcfr_sample_table with
+    // dt > 0, the reference's np.arange); anything else marches every sample, which is always right
+    const bool t_increasing = (a.N >= 2) && (a.t_table[a.N - 1] > a.t_table[0]);
+    const bool use_zb = (a.zb != nullptr) && t_increasing;
     int gz_lo_s = 0x7fffffff, gz_nhi_s = 0x7fffffff;  // image depth range {z_min, -z_max} (sortable ints)
     int lane_last = a.N - 1;  // last sample of this lane that can be unmasked (mask bounding box), see below
-    if (a.N >= 2) {
+    if (t_increasing) {
         // reduce the prepass' partial boxes (and depth ranges) of this image: 256 threads, one partial each per pass
         __shared__ int sbb[4][6];
         {

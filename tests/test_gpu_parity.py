@@ -435,3 +435,26 @@ def test_render_fwd_plan_matches_eager_call_and_overlaps_on_two_streams():
         for k, v in ref[s].items():
             if v is not None:
                 assert torch.equal(plans[s].out[k], v), (s, k)
+
+
+@pytest.mark.parametrize("t0,dt,N", [(0.82, -0.005, 160), (0.4, 0.0, 8), (0.025, 0.005, 1)])
+def test_non_increasing_sample_tables_fall_back_to_the_full_march(t0, dt, N):
+    """The exact pruning / skip tests assume an increasing table; a decreasing or constant one (or N = 1) must
+    still give the direct kernel's and the oracle's bits."""
+    import c_oracle
+    from geomconsistentfr_amd import RenderParams, shadow_min_distance, light_prep
+    rng = np.random.default_rng(N)
+    Hs, Ws = 96, 128
+    r, c = np.mgrid[0:Hs, 0:Ws]
+    depth = (30 * np.exp(-(((c - 60) / 30.0) ** 2 + ((r - 50) / 35.0) ** 2)) + rng.random((2, Hs, Ws))).astype(np.float32)
+    mask = np.stack([(((c - 64) / 50.0) ** 2 + ((r - 48) / 40.0) ** 2) < 1, rng.random((Hs, Ws)) > 0.3]).astype(np.uint8)
+    lights = np.array([[0.6, 0.2, 0.7], [-0.4, -0.5, 0.6]], np.float32)
+    prm = RenderParams(n_samples=N, t0=t0, dt=dt)
+    _, pt = light_prep(to_dev(lights), prm)
+    md_o, am_o = c_oracle.shadow_min_distance(depth, mask, c_oracle.light_prep(lights, clamp_z_min=0.0)[1][:, None, :],
+                                              c_oracle.sample_table(t0, dt, N))
+    lit = md_o < 1e5
+    for ws in (False, True):
+        md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt.reshape(2, 1, 3), prm, use_workspace=ws)
+        assert np.array_equal(md.cpu().numpy(), md_o), ws
+        assert np.array_equal(am.cpu().numpy()[lit], am_o[lit]), ws
