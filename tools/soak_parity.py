@@ -79,11 +79,16 @@ def main():
         depth = np.stack([c[0] for c in cases])
         mask = np.stack([c[1] for c in cases])
         lights = np.stack([c[2] for c in cases])
-        prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
+        # per batch: depth scale (steep / flat surfaces: the plane-fit bounds clamp their slopes at 4) and light
+        # distance (near lights: rays far from parallel, small |BC|)
+        scale = [1.0, 1.0, 0.01, 12.0, 300.0][it % 5] if it % 3 == 0 else 1.0
+        depth = (depth * np.float32(scale)).astype(np.float32)
+        ld = [4013.0, 4013.0, 60.0, 500.0, 1.0e5][(it // 5) % 5]
+        prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N, light_distance=ld)
         _, pt = light_prep(torch.from_numpy(lights).to(dev), prm)
         md, am = shadow_min_distance(torch.from_numpy(depth).to(dev), torch.from_numpy(mask).to(dev),
                                      pt.reshape(B, 1, 3), prm)
-        _, pt_o = c_oracle.light_prep(lights, clamp_z_min=0.0)
+        _, pt_o = c_oracle.light_prep(lights, clamp_z_min=0.0, light_distance=ld)
         md_o, am_o = c_oracle.shadow_min_distance(depth, mask, pt_o[:, None, :], c_oracle.sample_table(0.025, 0.8 / N, N))
         md, am = md.cpu().numpy(), am.cpu().numpy()
         lit_o, lit = md_o < 1e5, md < 1e5
