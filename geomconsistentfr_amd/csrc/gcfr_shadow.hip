@@ -1193,8 +1193,8 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         return GCFR_ERR_INVALID_ARGUMENT;
     if (bonus != 0.0f && !bonus_box)
         return GCFR_ERR_INVALID_ARGUMENT;
-    if (workspace && workspace_bytes < gcfr_shadow_workspace_bytes(B, H, W))
-        return GCFR_ERR_INVALID_ARGUMENT;
+    if (workspace && (workspace_bytes < gcfr_shadow_workspace_bytes(B, H, W) || ((uintptr_t)workspace & 15u)))
+        return GCFR_ERR_INVALID_ARGUMENT;  // (float4 records: 16-byte alignment)
 
     // auto tile shape (measured, gpurun_out/ab logs -> DESIGN.md 4.1): with the depth-bound skip compact tiles win
     // (the lanes of a wave agree more often): 8x8 up to 256 px wide, 16x4 above; without it 32x2 streams best.

@@ -71,7 +71,7 @@ int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_z, float cl
  *               training form: bonus = 0 (bonus_box may be NULL).  bonus_box is a HOST pointer.
  *   min_dist    (B,L,H,W) f32 out   minimum_distance (T8:515)
  *   argmin      (B,L,H,W) i32 out   index of the minimising sample (saved for backward); may be NULL
- *   workspace   device scratch of >= gcfr_shadow_workspace_bytes(B,H,W) bytes, or NULL.
+ *   workspace   device scratch of >= gcfr_shadow_workspace_bytes(B,H,W) bytes, 16-byte aligned, or NULL.
  *               With a workspace the depth maps are first repacked into 2x2-neighbourhood texels
  *               (one 16-byte gather per ray-step instead of four 4-byte gathers) and a coarse grid of
  *               depth bounds lets the march skip sample groups that provably cannot lower a
