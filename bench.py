@@ -185,6 +185,9 @@ def main():
     ap.add_argument("--size", type=int, default=256, help="other workloads: image side (config 5: 512)")
     ap.add_argument("--lights", type=int, default=1, help="lights per face (config 5: 18)")
     ap.add_argument("--samples", type=int, default=160, help="march steps (config 5: 320)")
+    ap.add_argument("--depth-noise", type=float, default=0.0,
+                    help="worst case for the depth-bound skip: add uniform noise of this amplitude to the depth maps "
+                         "(an untrained network's output; the bounds then never separate ray and surface)")
     ap.add_argument("--mask", choices=["ellipse", "ones"], default="ellipse",
                     help="'ones' = worst case: no fully masked wave-step exists, nothing is skipped")
     ap.add_argument("--tune", type=str, default="", help="A/B: comma list key=value for gcfr_tune, e.g. 0=32,2=1")
@@ -215,13 +218,15 @@ def main():
             k, v = kv.split("=")
             _lib.check(_lib.load().gcfr_tune(int(k), int(v)), "gcfr_tune")
     B = a.faces
-    headline = (a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse")
+    headline = (a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse" and a.depth_noise == 0.0)
     if headline:
         prm = RenderParams()
         depth, mask, albedo, normals, light, amb = synth_faces(B, seed0=rank * 1_000_000)
     else:
         prm = RenderParams(n_samples=a.samples, dt=0.8 / a.samples)
         depth, mask, albedo, normals, light, amb = synth_faces_sized(B, rank * 1_000_000, a.size, a.lights, a.mask)
+    if a.depth_noise > 0.0:
+        depth = depth + (a.depth_noise * np.random.default_rng(7).random(depth.shape)).astype(np.float32)
     Hh = Ww = a.size
     Ll, Nn = a.lights, a.samples
     d_depth = torch.from_numpy(depth).to(dev)
@@ -352,7 +357,7 @@ def main():
             "config": {"workload": ("BASELINE configs[1]: batch=%d synthetic 256x256 faces per GPU, 1 light each, "
                                     "160 march steps, forward-only shadow+shade" % B) if headline else
                                    ("non-headline: batch=%d synthetic %dx%d faces per GPU, %d light(s) each, %d march "
-                                    "steps, mask=%s, forward-only shadow+shade" % (B, Hh, Ww, Ll, Nn, a.mask)),
+                                    "steps, mask=%s, depth noise %g, forward-only shadow+shade" % (B, Hh, Ww, Ll, Nn, a.mask, a.depth_noise)),
                        "faces_per_gpu": B, "H": Hh, "W": Ww, "lights_per_face": Ll, "n_samples": Nn,
                        "parallelism": "dp%d" % world, "hip_streams": (a.streams if plans is not None or streams else 1),
                        "host_path": "RenderFwdPlan (preallocated outputs)" if plans is not None else "render_fwd (eager)"},
