@@ -373,6 +373,40 @@ __device__ inline void build_zbounds_block(int block, int b, const float *__rest
     const int ti = tile / ntw, tj = tile - ti * ntw;
     const int side = 2 << ls;
     const float *z = depth + (size_t)b * H * W;
+    if (ls == 3 && ti >= 1 && tj >= 1 && (ti << 3) + 15 <= H && (tj << 3) + 15 <= W) {
+        // Fast path (the common stride, a tile of proper cells only): each lane owns one 2x2 patch of its row's
+        // quadrant, loads it once and uses it for both passes; no bounds tests, no reloads.
+        const int q = lane >> 4, iy = (lane >> 2) & 3, ix = lane & 3;
+        const int er = (ti << 3) + ((q >> 1) << 3) + (iy << 1), ec = (tj << 3) + ((q & 1) << 3) + (ix << 1);
+        const float *p = z + (size_t)(er - 1) * W + (ec - 1);
+        const float v00 = p[0], v01 = p[1], v10 = p[W], v11 = p[W + 1];
+        const bool f00 = v00 - v00 == 0.0f, f01 = v01 - v01 == 0.0f, f10 = v10 - v10 == 0.0f, f11 = v11 - v11 == 0.0f;
+        float cnt = ((f00 ? 1.0f : 0.0f) + (f01 ? 1.0f : 0.0f)) + ((f10 ? 1.0f : 0.0f) + (f11 ? 1.0f : 0.0f));
+        float sz = ((f00 ? v00 : 0.0f) + (f01 ? v01 : 0.0f)) + ((f10 ? v10 : 0.0f) + (f11 ? v11 : 0.0f));
+        cnt = row_sum_f32(cnt);
+        sz = row_sum_f32(sz);
+        const float n00 = lane_value(cnt, 15), n01 = lane_value(cnt, 31), n10 = lane_value(cnt, 47), n11 = lane_value(cnt, 63);
+        float pa = 0.0f, pb = 0.0f;
+        if (n00 > 0.0f && n01 > 0.0f && n10 > 0.0f && n11 > 0.0f) {
+            const float m00 = lane_value(sz, 15) / n00, m01 = lane_value(sz, 31) / n01;
+            const float m10 = lane_value(sz, 47) / n10, m11 = lane_value(sz, 63) / n11;
+            const float ca = ((m01 + m11) - (m00 + m10)) * 0.0625f, cb = ((m10 + m11) - (m00 + m01)) * 0.0625f;
+            if (ca - ca == 0.0f)
+                pa = fminf(fmaxf(ca, -4.0f), 4.0f);
+            if (cb - cb == 0.0f)
+                pb = -fminf(fmaxf(cb, -4.0f), 4.0f);
+        }
+        const float X0 = (float)(ec - 1) - 0.5f * (float)W, Y0 = 0.5f * (float)H - (float)(er - 1);
+        const float base = __builtin_fmaf(pa, X0, pb * Y0);  // the plane at the patch's first cell; +pa per column, -pb per row
+        const float r00 = v00 - base, r01 = v01 - (base + pa), r10 = v10 - (base - pb), r11 = v11 - ((base + pa) - pb);
+        const float lo = fminf(fminf(r00, r01), fminf(r10, r11));  // (fminf / fmaxf drop NaN cells)
+        const float hi = fmaxf(fmaxf(r00, r01), fmaxf(r10, r11));
+        const float wlo = f32_unsortable(wave_min_i32(f32_sortable(lo)));
+        const float whi = -f32_unsortable(wave_min_i32(f32_sortable(-hi)));
+        if (lane == 0)
+            zb[(size_t)b * zb_max_tiles(H, W) + tile] = make_float4(pa, pb, wlo, whi);
+        return;
+    }
     // pass 1: slopes from the means of the tile's four s x s quadrants (finite proper cells only).  Row q of
     // the wave (16 lanes) owns quadrant q = 2*qy + qx and strides over its cells, so the four sums come out of
     // DPP row reductions with no cross-row traffic.
