@@ -164,6 +164,18 @@ def pmc_traffic_bytes():
         return None
 
 
+def pmc_valu_insts():
+    """VALU wave-instructions per shadow_fwd launch from the committed PMC pass (SQ_INSTS_VALU), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        return json.load(open(p)).get("valu_insts_per_launch")
+    except Exception:
+        return None
+
+
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0     # wave-instructions/s: 1024 SIMDs, one wave64 VALU op per 4 cycles at 2.4 GHz
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -371,6 +383,13 @@ def main():
                          "kernel_ray_steps_per_sec": B * Ll * Hh * Ww * Nn / (shadow_ms * 1e-3),
                          "measured_copy_GBs": measured_copy_bandwidth_gbs(dev)},
         }
+        vi = pmc_valu_insts()
+        if vi:   # what actually bounds the kernel: VALU issue, not HBM
+            out["roofline"]["valu"] = {"insts_per_launch": vi, "insts_per_nominal_ray_step": vi / (B * Ll * Hh * Ww * Nn),
+                                       "achieved_insts_per_s": vi / (shadow_ms * 1e-3), "peak_insts_per_s": VALU_ISSUE_PEAK,
+                                       "frac": vi / (shadow_ms * 1e-3) / VALU_ISSUE_PEAK,
+                                       "note": "wave64 VALU instructions (rocprofv3 SQ_INSTS_VALU, headline config) per "
+                                               "un-overlapped launch against 1024 SIMDs x 1 issue / 4 cycles"} if headline else None
         if single is not None:
             out["roofline"]["note"] += ("; avg_launch_ms is the kernel's un-overlapped duration (100 launches on one "
                                         "stream right after the timed region); with %d streams in flight an event "

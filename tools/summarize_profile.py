@@ -44,7 +44,8 @@ def main(tag):
         out = {"tag": tag, "kernel": shadow, "FETCH_SIZE_KiB_raw": fetch_kib, "WRITE_SIZE_KiB_raw": write_kib,
                "correction": "read side x2 on gfx950 (MI355X_MICROARCH.md HBM)",
                "shadow_fwd_hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
-               "avg_launch_ns": summary[shadow].get("_avg_ns")}
+               "avg_launch_ns": summary[shadow].get("_avg_ns"),
+               "valu_insts_per_launch": summary[shadow].get("SQ_INSTS_VALU", {}).get("mean")}
         json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
         print(json.dumps(out, indent=1))
     for k, cs in summary.items():
