@@ -71,3 +71,33 @@ def test_cross_product_distance_never_undercuts_the_bound(W, H, zscale, ld):
     bad = claim & (S.astype(np.float64) < lower)
     assert claim.sum() > n // 10                      # the test must actually exercise the claim
     assert not bad.any(), (int(bad.sum()), float((lower[bad] / S[bad]).max()))
+
+
+@pytest.mark.parametrize("kind", ["smooth", "noisy", "steep"])
+def test_bilinear_samples_stay_inside_the_tiles_plane_band(kind):
+    """The prepass bounds a tile by a band around a plane (slopes from quadrant means, clamped to +-4, band =
+    residual extrema over the tile's cells).  A bilinear sample is a convex combination of four cells whose
+    weighted mean position is the sample position, so it must lie in the same band AT that position."""
+    rng = np.random.default_rng({"smooth": 1, "noisy": 2, "steep": 3}[kind])
+    for _ in range(200):
+        r, c = np.mgrid[0:16, 0:16].astype(np.float64)
+        z = 30 * np.exp(-(((c - rng.uniform(0, 16)) / 9.0) ** 2 + ((r - rng.uniform(0, 16)) / 11.0) ** 2))
+        if kind == "noisy":
+            z = z + 5 * rng.random((16, 16))
+        if kind == "steep":
+            z = z + rng.uniform(-9, 9) * c + rng.uniform(-9, 9) * r        # beyond the +-4 clamp
+        z = z.astype(f32)
+        X0, Y0 = rng.integers(-128, 112), rng.integers(-111, 128)          # frame coordinates of cell (0, 0)
+        X, Y = (X0 + c).astype(f32), (Y0 - r).astype(f32)                  # Y falls with the row
+        m = [z[qy * 8:qy * 8 + 8, qx * 8:qx * 8 + 8].astype(f32).mean(dtype=f32) for qy in (0, 1) for qx in (0, 1)]
+        a = np.clip(((m[1] + m[3]) - (m[0] + m[2])) * f32(0.0625), -4, 4).astype(f32)
+        b = (-np.clip(((m[2] + m[3]) - (m[0] + m[1])) * f32(0.0625), -4, 4)).astype(f32)
+        res = z - (a * X + b * Y)
+        clo, chi = res.min(), res.max()
+        u, v = rng.uniform(0, 15, 500), rng.uniform(0, 15, 500)            # sample positions (column, row)
+        fu, fv = np.floor(u).astype(int), np.floor(v).astype(int)
+        wx, wy = u - fu, v - fv
+        zs = (z[fv, fu] * (1 - wx) + z[fv, fu + 1] * wx) * (1 - wy) + (z[fv + 1, fu] * (1 - wx) + z[fv + 1, fu + 1] * wx) * wy
+        plane = a.astype(np.float64) * (X0 + u) + b.astype(np.float64) * (Y0 - v)
+        tol = 1e-5 * (np.abs(zs) + np.abs(plane) + 1.0)                     # f32 roundings of the residuals
+        assert np.all(zs - plane >= clo - tol) and np.all(zs - plane <= chi + tol)
