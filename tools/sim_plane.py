@@ -5,9 +5,11 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/oracle")
 import bench, c_oracle
 
 
-def run(seed=0, tile=(8, 8), G=4, stride=8, H=256, W=256, N=160, t0=0.025, dt=0.005):
+def run(seed=0, tile=(8, 8), G=4, stride=8, H=256, W=256, N=160, t0=0.025, dt=0.005, light_override=None):
     depth, mask, *_rest = bench.synth_faces(1, seed)
     light = _rest[2]
+    if light_override is not None:
+        light = np.array([light_override], np.float32)
     depth, mask = depth[0].astype(np.float64), mask[0]
     _, pt = c_oracle.light_prep(light, clamp_z_min=0.0)
     Cx, Cy, Cz = [float(v) for v in pt[0]]
@@ -93,5 +95,6 @@ def run(seed=0, tile=(8, 8), G=4, stride=8, H=256, W=256, N=160, t0=0.025, dt=0.
     print(f"seed {seed}: mask {n_mask} minmax {n_mm} plane {n_pl} perfect {n_perf}")
 
 
-for s in range(3):
-    run(seed=s)
+if __name__ == '__main__':
+    for s in range(3):
+        run(seed=s)
