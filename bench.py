@@ -188,10 +188,13 @@ def main():
     ap.add_argument("--from-depth", action="store_true",
                     help="also compute the normals (T8:353-354) inside the march epilogue instead of reading them "
                          "(SURVEY 8d's 17.4 B/ray-step accounting counts normals as a 12 B/pixel input, the default)")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="issue successive steps round-robin on this many HIP streams, one RenderFwdPlan (own outputs "
                          "and workspace) per stream: independent batches overlap, the next step's prepass and "
                          "prologue fill the previous march's tail (B=8 is 8192 waves for 256 CUs).  1 = one stream")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="issue every step as a plan call (two kernel launches + event records, ~55 us of host time) "
+                         "instead of replaying the plan's captured hipGraph (~10 us)")
     ap.add_argument("--eager", action="store_true",
                     help="call render_fwd (allocates its outputs per call, ~60 us of host time) instead of a plan")
     ap.add_argument("--size", type=int, default=256, help="other workloads: image side (config 5: 512)")
@@ -270,7 +273,14 @@ def main():
         plans = [R.RenderFwdPlan(B, Ll, Hh, Ww, prm, dev, want_argmin=False, mask_batch=d_mask_u8.shape[0],
                                  camera=cam if a.from_depth else None) for _ in range(max(1, a.streams))]
 
+    use_graph = plans is not None and not a.no_graph
+    if use_graph:
+        for p_ in plans:
+            p_.capture(d_depth, d_mask_u8, d_light3, d_amb2, None if a.from_depth else d_normals, d_albedo)
+
     def step(timed):
+        if use_graph and step.graph_ok:      # timed region: one hipGraph replay per step (no per-launch events)
+            return plans[step.i % len(plans)].replay()
         if timed:
             e0, e1 = new_event(), new_event()
             _lib.check(L_.gcfr_profile_events(e0, e1), "gcfr_profile_events")
@@ -292,6 +302,8 @@ def main():
         return out
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(a.streams)] if a.streams > 1 else None
+    step.graph_ok = True
+    step.i = 0
 
     def run_step(i, timed):
         step.i = i
@@ -313,6 +325,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         run_step(i, True)
+    host_issue = time.perf_counter() - t0      # host time to enqueue every step (before waiting for the GPU)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -345,6 +358,8 @@ def main():
 
     if a.direct:      # the direct kernel has no event hook: fall back to the whole-step time
         shadow_ms = 1e3 * elapsed / a.steps
+    elif use_graph:   # graph replays carry no per-launch events: measured below, on one stream
+        shadow_ms = None
     else:
         shadow_ms = float(np.mean([elapsed_ms(e0, e1) for e0, e1 in ev_pairs]))
     # With several streams the launches of successive steps overlap: an event pair then brackets a kernel that
@@ -354,8 +369,10 @@ def main():
     # summary of `bench.py --streams 1`, which that number agrees with.  The overlapped mean is kept beside it.
     overlapped_ms = None
     single = None
-    if streams is not None and not a.direct:
+    if (streams is not None or use_graph) and not a.direct:
+        step.graph_ok = False                      # plan calls with the library's event hook, one stream
         single = single_stream_reference()
+        step.graph_ok = True
         overlapped_ms, shadow_ms = shadow_ms, single["avg_launch_ms"]
     algo_bytes = B * Ll * Hh * Ww * Nn * ALGO_BYTES_PER_RAY_STEP          # per launch (one rank)
     achieved = algo_bytes / (shadow_ms * 1e-3) / 1e9
@@ -372,8 +389,10 @@ def main():
                                     "steps, mask=%s, depth noise %g, forward-only shadow+shade" % (B, Hh, Ww, Ll, Nn, a.mask, a.depth_noise)),
                        "faces_per_gpu": B, "H": Hh, "W": Ww, "lights_per_face": Ll, "n_samples": Nn,
                        "parallelism": "dp%d" % world, "hip_streams": (a.streams if plans is not None or streams else 1),
-                       "host_path": "RenderFwdPlan (preallocated outputs)" if plans is not None else "render_fwd (eager)"},
+                       "host_path": ("RenderFwdPlan, hipGraph replay" if use_graph else "RenderFwdPlan (preallocated outputs)")
+                       if plans is not None else "render_fwd (eager)"},
             "faces_per_sec": world * B * Ll * a.steps / elapsed,
+            "host_issue_ms_per_step": 1e3 * host_issue / a.steps,
             "ray_steps_per_sec_per_gpu": value / world,
             "roofline": {"bound": "hbm", "note": "north_star's HBM accounting; the gathers are cache-served (traffic << "
                          "algorithmic bytes, so frac can exceed 1) and the kernel is VALU-issue bound -- DESIGN.md 4.1",
@@ -392,9 +411,10 @@ def main():
                                                "un-overlapped launch against 1024 SIMDs x 1 issue / 4 cycles"} if headline else None
         if single is not None:
             out["roofline"]["note"] += ("; avg_launch_ms is the kernel's un-overlapped duration (100 launches on one "
-                                        "stream right after the timed region); with %d streams in flight an event "
-                                        "pair spans %.4f ms" % (a.streams, overlapped_ms))
-            out["roofline"]["avg_launch_ms_overlapped"] = overlapped_ms
+                                        "stream right after the timed region, HIP events around the kernel)")
+            if overlapped_ms is not None:
+                out["roofline"]["note"] += "; with %d streams in flight an event pair spans %.4f ms" % (a.streams, overlapped_ms)
+                out["roofline"]["avg_launch_ms_overlapped"] = overlapped_ms
             out["single_stream"] = single
         if world == 1 and not a.no_cpu_baseline and headline:
             out["cpu_baseline"] = cpu_baseline()

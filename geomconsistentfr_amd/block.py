@@ -328,6 +328,8 @@ class RenderFwdPlan:
                  mask_batch=None, camera=None):
         self.L_ = _lib.load()
         dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
         self.dev, self.params, self.shape, self.camera = dev, params, (B, L, H, W), camera
         f32 = dict(dtype=torch.float32, device=dev)
         self.tt = sample_table(params, dev)
@@ -351,10 +353,47 @@ class RenderFwdPlan:
                       self.ws_bytes)
         self._head = (int(params.clamp_light_z_min is not None), float(params.clamp_light_z_min or 0.0),
                       float(params.light_distance))
+        self._validated = None
+        self.graph = None
+
+    def _validate(self, depth, mask_u8, light, ambient, normals, albedo):
+        B, L, H, W = self.shape
+        for name, t, dt, n in (("depth", depth, torch.float32, B * H * W), ("mask_u8", mask_u8, torch.uint8, self.mask_batch * H * W),
+                               ("light", light, torch.float32, B * L * 3), ("ambient", ambient, torch.float32, B * L),
+                               ("albedo", albedo, torch.float32, B * 3 * H * W)) + \
+                              ((("normals", normals, torch.float32, B * 3 * H * W),) if self.camera is None else ()):
+            if t is None or t.dtype != dt or t.numel() != n or not t.is_contiguous() or t.device != self.dev:
+                raise _lib.GcfrError("RenderFwdPlan: %s must be a contiguous %s tensor of %d elements on %s"
+                                     % (name, dt, n, self.dev))
+
+    def capture(self, depth, mask_u8, light, ambient, normals, albedo):
+        """Capture one call on these (static) input tensors into a hipGraph; `replay()` then re-runs it on the
+        current stream for ~10 us of host time instead of ~55 (two kernel launches, marshalling 31 arguments).
+        The entry points neither allocate nor synchronise, so they are capture-safe.  New data goes into the same
+        input tensors (copy_) before a replay."""
+        self._static = (depth, mask_u8, light, ambient, normals, albedo)
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):                      # warm-up outside the capture, as torch requires
+            self(*self._static)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self(*self._static)
+        return self
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
 
     def __call__(self, depth, mask_u8, light, ambient, normals, albedo):
         """depth (B,H,W) f32, mask_u8 (B|1,H,W) u8, light (B,L,3) f32, ambient (B,L) f32, albedo (B,3,H,W) f32,
         normals (B,3,H,W) f32 or None (plan built with camera=...).  All contiguous, on the plan's device."""
+        key = (id(depth), id(mask_u8), id(light), id(ambient), id(normals), id(albedo))
+        if key != self._validated:   # (the checks cost ~14 us of host time: once per set of tensors, not per call)
+            self._validate(depth, mask_u8, light, ambient, normals, albedo)
+            self._validated = key
         st = torch.cuda.current_stream(self.dev).cuda_stream
         if self.camera is None:
             rc = self.L_.gcfr_render_fwd(light.data_ptr(), *self._head, depth.data_ptr(), mask_u8.data_ptr(),
@@ -371,12 +410,11 @@ class RenderFwdPlan:
 
 
 class GraphedRenderFwd:
-    """hipGraph replay of the forward block for fixed shapes.  Captures one `render_fwd` call (two kernels,
-    launched through ctypes on the capturing stream) on static buffers; `__call__` copies the new inputs into
-    them and replays.  Forward only (no autograd).  Measured on MI355X (tools/graph_latency.py): replay is
-    bit-identical to the eager call but NOT faster (B=1: 33.6 vs 35.6 us, B=8: 123 vs 120 us) -- with two
-    launches per step there is nothing for a graph to amortise; kept because it shows the entry points are
-    capture-safe (no allocation, no synchronisation inside)."""
+    """hipGraph replay of the eager `render_fwd` for fixed shapes: captures one call on static buffers; `__call__`
+    copies the new inputs into them and replays.  Forward only (no autograd).  On ONE stream a B=8 step is
+    GPU-bound, so the replay is bit-identical but not faster (tools/graph_latency.py: 91 vs 86 us); the host time
+    it saves (56 -> 14 us per step) only matters once several streams keep the GPU full -- `RenderFwdPlan.capture`
+    is the form bench.py uses for that."""
 
     def __init__(self, depth, mask, light, ambient, normals, albedo, params: RenderParams = RenderParams()):
         _require_device(depth, mask, light, ambient, normals, albedo)

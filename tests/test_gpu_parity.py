@@ -435,6 +435,25 @@ def test_render_fwd_plan_matches_eager_call_and_overlaps_on_two_streams():
         for k, v in ref[s].items():
             if v is not None:
                 assert torch.equal(plans[s].out[k], v), (s, k)
+    # hipGraph capture of a plan call: replays give the same bits, also interleaved on two streams, and pick up
+    # new data written into the captured input tensors
+    gplans = [R.RenderFwdPlan(B, L, Hs, Ws, prm, dev, want_argmin=True).capture(*[t.clone() for t in batches[s]])
+              for s in range(2)]
+    for it in range(6):
+        with torch.cuda.stream(streams[it % 2]):
+            gplans[it % 2].replay()
+    torch.cuda.synchronize()
+    for s in range(2):
+        for k, v in ref[s].items():
+            if v is not None:
+                assert torch.equal(gplans[s].out[k], v), (s, k)
+    for dst, src in zip(gplans[0]._static, batches[1]):
+        dst.copy_(src)
+    gplans[0].replay()
+    torch.cuda.synchronize()
+    for k, v in ref[1].items():
+        if v is not None:
+            assert torch.equal(gplans[0].out[k], v), k
 
 
 @pytest.mark.parametrize("t0,dt,N", [(0.82, -0.005, 160), (0.4, 0.0, 8), (0.025, 0.005, 1)])
