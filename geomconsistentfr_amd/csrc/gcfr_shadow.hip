@@ -320,16 +320,22 @@ __device__ inline float f32_unsortable(int i)
 // group of `group` consecutive samples can touch, derived from the sample table on the device by both
 // kernels.  The host sizes the grid for s = 8.
 // ----------------------------------------------------------------------------------------------
-__device__ inline int zb_log2_stride(int H, int W, int N, const double *t_table, int group)
+__device__ inline int zb_log2_stride(int H, int W, int N, const double *t_table, int group, bool *fits = nullptr)
 {
+    if (fits)
+        *fits = false;
     if (N < 2)
         return 3;
     const float step = fabsf((float)((t_table[N - 1] - t_table[0]) / (double)(N - 1)));
-    const float fd = (float)(group - 1) * step * (float)max(H, W);  // rint(s) moves by <= floor(fd) + 1 cells
+    // rint(s) moves by <= floor(fd) + 1 cells over a group (1.002: the table may deviate 0.1 % from uniform, see
+    // the prepass' table check, plus the f32 roundings here)
+    const float fd = (float)(group - 1) * step * (float)max(H, W) * 1.002f;
     const int need = (int)fminf(fmaxf(fd, 0.0f), 1024.0f) + 3;      // + the cell either side (floor / ceil)
     int ls = 3;
     while ((1 << ls) < need && ls < 5)  // capped at 32: coarser tiles bound nothing (their footprints fail the coverage test)
         ++ls;
+    if (fits)
+        *fits = (1 << ls) >= need;  // every group's footprint lies in the tile its lowest cell selects
     return ls;
 }
 
@@ -465,7 +471,8 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
                                                          const uint8_t *__restrict__ mask, int mask_batch,
                                                          int *__restrict__ bbox, int *__restrict__ zrange,
                                                          float4 *__restrict__ zb, int quad_blocks, int N,
-                                                         const double *__restrict__ t_table, int group)
+                                                         const double *__restrict__ t_table, int group,
+                                                         int *__restrict__ tflag)
 {
     const int Wp = W + 1, Hp = H + 1;
     const int b = blockIdx.y;
@@ -518,6 +525,22 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
             bbox[((size_t)b * n_partials + qb) * 4 + threadIdx.x] =
                 min(min(part[0][threadIdx.x], part[1][threadIdx.x]), min(part[2][threadIdx.x], part[3][threadIdx.x]));
     }
+    if (tflag && qb == 0 && b == 0 && threadIdx.x < 64) {
+        // Is the sample table what the march's pruning / skipping reasons about -- increasing, inside [0, 1]
+        // (every sample between the pixel and its end point) and uniform to 0.1 %?  One wave checks, once per launch.
+        bool ok = (N >= 2) && (t_table[0] >= 0.0) && (t_table[N - 1] <= 1.0);
+        if (ok) {
+            const double step = (t_table[N - 1] - t_table[0]) / (double)(N - 1);
+            ok = step > 0.0;
+            for (int k = threadIdx.x; k < N - 1; k += 64) {
+                const double dk = t_table[k + 1] - t_table[k];
+                ok = ok && (dk > 0.0) && (fabs(dk - step) <= 1e-3 * step);
+            }
+        }
+        const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+        if (threadIdx.x == 0)
+            *tflag = all_ok ? 1 : 0;
+    }
     if (pl.light_raw && qb == 0) {
         for (int l = threadIdx.x; l < pl.L; l += blockDim.x)
             light_prep_one(pl.light_raw, b * pl.L + l, pl.clamp_z, pl.clamp_min, pl.light_distance,
@@ -542,6 +565,7 @@ struct ShadowQuadArgs {
     const int *bbox;        // (MB,P/256,4) prepass output: partial mask bounding boxes {r_min, c_min, -r_max, -c_max}
     const float4 *zb;       // (B,zb_max_tiles) prepass output: depth bounds grid {a, b, c_lo, c_hi}, or null (skip off)
     const int *zrange;      // (B,P/256,2) prepass output: partial depth ranges {z_min, -z_max} (sortable ints)
+    const int *tflag;       // (1) prepass output: 1 iff the sample table is increasing, inside [0,1] and uniform
     const uint8_t *mask;    // (MB,H,W)
     const float *light_pt;  // (B,L,3)
     const double *t_table;  // (N)
@@ -650,9 +674,10 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     // rays that have left (or never reach) the face.  Requires the sample table to be monotone and
     // uniformly spaced to within half a step, which gcfr_sample_table guarantees.
     int k_begin = k_lo, k_end = N;  // [k_begin, k_end)
-    // the pruning / skipping machinery below reasons about an INCREASING sample table (gcfr_sample_table with
-    // dt > 0, the reference's np.arange); anything else marches every sample, which is always right
-    const bool t_increasing = (a.N >= 2) && (a.t_table[a.N - 1] > a.t_table[0]);
+    // the pruning / skipping machinery below reasons about an increasing, uniform sample table inside [0, 1]
+    // (gcfr_sample_table with dt > 0, the reference's np.arange); anything else marches every sample, which is
+    // always right
+    const bool t_increasing = (a.N >= 2) && (a.tflag[0] != 0);  // checked by the prepass (see its table check)
     const bool use_zb = (a.zb != nullptr) && t_increasing;
     int gz_lo_s = 0x7fffffff, gz_nhi_s = 0x7fffffff;  // image depth range {z_min, -z_max} (sortable ints)
     int lane_last = a.N - 1;  // last sample of this lane that can be unmasked (mask bounding box), see below
@@ -759,7 +784,11 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     // plane evaluation's terms); a lane votes "skip" only if the bound exceeds its running minimum by a further
     // 0.2 %, so a skipped sample could not have been taken and the minimum, its index and the tie predecessor
     // are what the full march gives.
-    const int zls = use_zb ? __builtin_amdgcn_readfirstlane(zb_log2_stride(H, W, a.N, a.t_table, DEPTH)) : 3;
+    bool zfits = false;
+    const int zls = use_zb ? __builtin_amdgcn_readfirstlane(zb_log2_stride(H, W, a.N, a.t_table, DEPTH, &zfits)) : 3;
+    // With a checked table every sample lies on the segment pixel -> end point, i.e. inside the image, and the
+    // stride was chosen so that a group's footprint fits the tile its lowest cell selects: no per-lane test.
+    const bool zb_trusted = __builtin_amdgcn_readfirstlane((int)zfits) != 0;
     const int zntw = (W >> zls) + 1;
     const __amdgpu_buffer_rsrc_t zr =
         make_rsrc(a.zb + (size_t)b * zb_max_tiles(H, W), zb_max_tiles(H, W) * (int)sizeof(float4));
@@ -803,10 +832,13 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     auto zb_fetch = [&](int ca, int ra, int cb, int rb) -> f32x4 {
         const int cmin = min(ca, cb), cmax = max(ca, cb), rmin = min(ra, rb), rmax = max(ra, rb);
         const int tj = cmin >> zls, ti = rmin >> zls;
-        const bool covered = (cmin >= 0) && (rmin >= 0) && (cmax <= W - 1) && (rmax <= H - 1) &&
-                             (cmax + 2 <= ((tj + 2) << zls) - 1) && (rmax + 2 <= ((ti + 2) << zls) - 1);
-        // (no select on the loaded value: it would make the wave wait for the gather right here)
-        const int off = covered ? (__mul24(ti, zntw) + tj) << 4 : zb_sentinel;
+        int off = (__mul24(ti, zntw) + tj) << 4;
+        if (!zb_trusted) {  // (wave-uniform branch)
+            const bool covered = (cmin >= 0) && (rmin >= 0) && (cmax <= W - 1) && (rmax <= H - 1) &&
+                                 (cmax + 2 <= ((tj + 2) << zls) - 1) && (rmax + 2 <= ((ti + 2) << zls) - 1);
+            // (no select on the loaded value: it would make the wave wait for the gather right here)
+            off = covered ? off : zb_sentinel;
+        }
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, off, 0, 0));
     };
 
@@ -1136,7 +1168,7 @@ extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
         return 0;
     const size_t n_partials = ((size_t)H * W + 255) / 256;
     return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4) + (size_t)B * n_partials * 4 * sizeof(int) +
-           (size_t)B * (size_t)zb_max_tiles(H, W) * sizeof(float4) + (size_t)B * n_partials * 2 * sizeof(int);
+           (size_t)B * (size_t)zb_max_tiles(H, W) * sizeof(float4) + (size_t)B * n_partials * 2 * sizeof(int) + 16;
 }
 
 // Optional profiling hook: events recorded around the dominant (march) kernel of the next launches.
@@ -1253,16 +1285,18 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         const size_t n_partials = ((size_t)H * W + 255) / 256;
         float4 *zb = (float4 *)((char *)bbox + (size_t)B * n_partials * 4 * sizeof(int));
         int *zrange = (int *)(zb + (size_t)B * zb_max_tiles(H, W));  // (B, n_partials, 2)
+        int *tflag = zrange + (size_t)B * n_partials * 2;
         const bool use_zb = g_zbound && N >= 2;
         const int quad_blocks = (texels + 255) / 256;
         const int zb_blocks = use_zb ? (zb_max_tiles(H, W) + 3) / 4 : 0;  // sized for the finest stride
         hipLaunchKernelGGL(build_quad_kernel, dim3(quad_blocks + zb_blocks, B), dim3(256), 0, st, depth,
                            (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox,
                            use_zb ? zrange : (int *)nullptr, zb, quad_blocks, N, t_table,
-                           g_depth == 1 || g_depth == 2 ? g_depth : 4);
+                           g_depth == 1 || g_depth == 2 ? g_depth : 4, tflag);
         ShadowQuadArgs a;
         a.zb = use_zb ? zb : nullptr;
         a.zrange = zrange;
+        a.tflag = tflag;
         a.depth = depth;
         a.quad = (const float4 *)workspace;
         a.bbox = bbox;

@@ -38,7 +38,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     from geomconsistentfr_amd import _lib
     L = _lib.load()
     assert L.gcfr_shadow_fwd(None, None, 1, None, 1, 1, 256, 256, 160, None, 0.0, None, None, None, None, 0, None) == -1
-    assert L.gcfr_shadow_workspace_bytes(8, 256, 256) == 8 * 257 * 257 * 16 + 8 * 256 * 16 + 8 * (33 * 33 + 1) * 16 + 8 * 256 * 8
+    assert L.gcfr_shadow_workspace_bytes(8, 256, 256) == 8 * 257 * 257 * 16 + 8 * 256 * 16 + 8 * (33 * 33 + 1) * 16 + 8 * 256 * 8 + 16
     assert L.gcfr_light_prep(None, 1, 1, 0.0, 4013.0, None, None, None) == -1
     assert L.gcfr_shade_fwd(None, None, None, None, None, None, 1, 1, 8, 8, 0.5, None, None, None, None, None) == -1
 
