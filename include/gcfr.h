@@ -63,9 +63,9 @@ int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_z, float cl
  *   mask_u8     (MB,H,W) u8      1 where the reference's mask != 0; MB = mask_batch = B (T8:510)
  *                                or 1 (one mask shared by all images, S1:488)
  *   light_pt    (B,L,3) f32      from gcfr_light_prep
- *   t_table     (N) f64          from gcfr_sample_table (device copy); the workspace path requires it
- *                                monotone and uniformly spaced to within half a step (it derives a
- *                                conservative index range from t_table[0] and t_table[N-1])
+ *   t_table     (N) f64          from gcfr_sample_table (device copy).  Any table gives the reference's
+ *                                results; the workspace path's pruning / skipping only engages on a table its
+ *                                prepass finds increasing, inside [0, 1] and uniform to 0.1 %
  *   bonus       added to the minimum when the light's (x,y) lies inside bonus_box
  *               = {x_lo, x_hi, y_lo, y_hi} (S1:495-496: box = image, bonus = 5; SLT:503-504);
  *               training form: bonus = 0 (bonus_box may be NULL).  bonus_box is a HOST pointer.
