@@ -601,12 +601,7 @@ __device__ inline int lo32(double v)
 //                 Same total work in 4x finer, more uniform pieces: used for small batches, where a few
 //                 heavy (fully unmasked) tiles otherwise leave the SIMDs idle at the tail of the launch.
 template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool KSPLIT>
-#ifndef GCFR_MARCH_WAVES_PER_EU
-#define GCFR_MARCH_ATTR
-#else
-#define GCFR_MARCH_ATTR __attribute__((amdgpu_waves_per_eu(GCFR_MARCH_WAVES_PER_EU, GCFR_MARCH_WAVES_PER_EU)))
-#endif
-__global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(ShadowQuadArgs a)
+__device__ __forceinline__ void march_tile(ShadowQuadArgs a)
 {
     constexpr int TILE_H = 64 / TILE_W;
     constexpr int WAVES = KSPLIT ? 1 : 4;  // tiles per workgroup along x
@@ -914,12 +909,17 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
             const bool cannot_win = (g > 0.0f) && (g * g * 0.998f > bestS);
             run_body = __builtin_amdgcn_ballot_w64(!none && !cannot_win) != 0ull;
         }
+#ifndef GCFR_BODY_CHUNK
+#define GCFR_BODY_CHUNK 1  // samples of the group evaluated together (texel gathers in flight); see GCFR_MARCH_WAVES_PER_EU
+#endif
         if (run_body) {
+#pragma unroll
+          for (int h0 = 0; h0 < DEPTH; h0 += GCFR_BODY_CHUNK) {
             // phase 1: positions and texel gathers for the whole group (all in flight together)
             double ux[DEPTH], uy[DEPTH], fxd[DEPTH], fyd[DEPTH];
             f32x4 qv[DEPTH];
 #pragma unroll
-            for (int j = 0; j < DEPTH; ++j) {
+            for (int j = h0; j < h0 + GCFR_BODY_CHUNK && j < DEPTH; ++j) {
                 double sx, sy;
                 sample_pos(clampk(k0 + j), sx, sy);
                 ux[j] = (sx + halfW) - 0.0001;  // unrounded position (T8:480-487)
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
             }
             // phase 2: bilinear depth, point A, squared distance numerator, running minimum
 #pragma unroll
-            for (int j = 0; j < DEPTH; ++j) {
+            for (int j = h0; j < h0 + GCFR_BODY_CHUNK && j < DEPTH; ++j) {
                 const int k = clampk(k0 + j);
                 const bool masked = (cur.m[j] == 0);
                 const double gxd = __builtin_ceil(ux[j]), gyd = __builtin_ceil(uy[j]);
@@ -959,6 +959,7 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
                 }
                 bestS = take ? S : bestS;
             }
+          }
         }
         if (check_finished && use_zb && k0 + DEPTH < k_end) {  // early termination, see Dcap
             const float tn = (float)a.t_table[k0 + DEPTH];
@@ -1089,6 +1090,32 @@ __global__ __launch_bounds__(256) GCFR_MARCH_ATTR void shadow_fwd_quad_kernel(Sh
     }
 }
 
+// The two __global__ entry points of the march.  Occupancy is forced (the register allocator would settle at
+// 95-99 VGPRs = 5 waves/SIMD): with the group body evaluated one sample at a time (GCFR_BODY_CHUNK = 1) the
+// inference variant fits 80 VGPRs with ~7 spilled dwords outside the sample loop -> six waves per SIMD, which beats
+// the 119-VGPR / 4-wave build that kept four gathers in flight per body by 8 % at B=8 on four streams and by 11 %
+// at B=64.  The argmin variant carries three more loop registers: six waves cost it 60-68 B of scratch and 35 %,
+// five waves (96 VGPRs, 16 B) are its optimum.  7 or 8 waves: spills of 76 / 104 B, -30 ... -45 %
+// (tools/build_variant.sh + tools/ab.sh, tools/exp_grazing.py).
+#ifndef GCFR_MARCH_WAVES_PER_EU
+#define GCFR_MARCH_WAVES_PER_EU 6
+#endif
+#ifndef GCFR_MARCH_ARGMIN_WAVES_PER_EU
+#define GCFR_MARCH_ARGMIN_WAVES_PER_EU 5
+#endif
+template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE, bool KSPLIT>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(GCFR_MARCH_WAVES_PER_EU, GCFR_MARCH_WAVES_PER_EU))) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
+{
+    march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, KSPLIT>(a);
+}
+template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE, bool KSPLIT>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(GCFR_MARCH_ARGMIN_WAVES_PER_EU, GCFR_MARCH_ARGMIN_WAVES_PER_EU))) void shadow_fwd_quad_argmin_kernel(ShadowQuadArgs a)
+{
+    march_tile<TILE_W, EVEN_HALF, true, DEPTH, FUSE_SHADE, KSPLIT>(a);
+}
+
 }  // namespace gcfr
 
 // ----------------------------------------------------------------------------------------------
@@ -1184,18 +1211,18 @@ extern "C" int gcfr_profile_events(void *start, void *stop)
 template <int TILE_W, int DEPTH, bool FUSE, bool KSPLIT>
 static void launch_quad5(const ShadowQuadArgs &a, bool even_half, bool want_argmin, dim3 grid, hipStream_t st)
 {
-#define GCFR_LAUNCH(E, A) \
-    hipLaunchKernelGGL((shadow_fwd_quad_kernel<TILE_W, E, A, DEPTH, FUSE, KSPLIT>), grid, dim3(256), 0, st, a)
+#define GCFR_LAUNCH(KERNEL, E) \
+    hipLaunchKernelGGL((KERNEL<TILE_W, E, DEPTH, FUSE, KSPLIT>), grid, dim3(256), 0, st, a)
     if (even_half) {
         if (want_argmin)
-            GCFR_LAUNCH(true, true);
+            GCFR_LAUNCH(shadow_fwd_quad_argmin_kernel, true);
         else
-            GCFR_LAUNCH(true, false);
+            GCFR_LAUNCH(shadow_fwd_quad_kernel, true);
     } else {
         if (want_argmin)
-            GCFR_LAUNCH(false, true);
+            GCFR_LAUNCH(shadow_fwd_quad_argmin_kernel, false);
         else
-            GCFR_LAUNCH(false, false);
+            GCFR_LAUNCH(shadow_fwd_quad_kernel, false);
     }
 #undef GCFR_LAUNCH
 }
