@@ -909,9 +909,10 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
             const bool cannot_win = (g > 0.0f) && (g * g * 0.998f > bestS);
             run_body = __builtin_amdgcn_ballot_w64(!none && !cannot_win) != 0ull;
         }
-#ifndef GCFR_BODY_CHUNK
-#define GCFR_BODY_CHUNK 1  // samples of the group evaluated together (texel gathers in flight); see GCFR_MARCH_WAVES_PER_EU
-#endif
+        // samples of the group evaluated together (texel gathers in flight): one at a time in the throughput
+        // variants (fewer live registers -> forced occupancy, see the __global__ wrappers), the whole group in the
+        // k-split variant, whose launches are tiny and latency-bound
+        constexpr int GCFR_BODY_CHUNK = KSPLIT ? DEPTH : 1;
         if (run_body) {
 #pragma unroll
           for (int h0 = 0; h0 < DEPTH; h0 += GCFR_BODY_CHUNK) {
@@ -1103,17 +1104,23 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
 #ifndef GCFR_MARCH_ARGMIN_WAVES_PER_EU
 #define GCFR_MARCH_ARGMIN_WAVES_PER_EU 5
 #endif
-template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE, bool KSPLIT>
+template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(GCFR_MARCH_WAVES_PER_EU, GCFR_MARCH_WAVES_PER_EU))) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
 {
-    march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, KSPLIT>(a);
+    march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, false>(a);
 }
-template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE, bool KSPLIT>
+template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(GCFR_MARCH_ARGMIN_WAVES_PER_EU, GCFR_MARCH_ARGMIN_WAVES_PER_EU))) void shadow_fwd_quad_argmin_kernel(ShadowQuadArgs a)
 {
-    march_tile<TILE_W, EVEN_HALF, true, DEPTH, FUSE_SHADE, KSPLIT>(a);
+    march_tile<TILE_W, EVEN_HALF, true, DEPTH, FUSE_SHADE, false>(a);
+}
+// k-split (tiny launches, one or two images): latency-bound, four gathers in flight per body, occupancy as it falls
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE>
+__global__ __launch_bounds__(256) void shadow_fwd_quad_ksplit_kernel(ShadowQuadArgs a)
+{
+    march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, true>(a);
 }
 
 }  // namespace gcfr
@@ -1211,9 +1218,20 @@ extern "C" int gcfr_profile_events(void *start, void *stop)
 template <int TILE_W, int DEPTH, bool FUSE, bool KSPLIT>
 static void launch_quad5(const ShadowQuadArgs &a, bool even_half, bool want_argmin, dim3 grid, hipStream_t st)
 {
-#define GCFR_LAUNCH(KERNEL, E) \
-    hipLaunchKernelGGL((KERNEL<TILE_W, E, DEPTH, FUSE, KSPLIT>), grid, dim3(256), 0, st, a)
-    if (even_half) {
+#define GCFR_LAUNCH(KERNEL, ...) hipLaunchKernelGGL((KERNEL<TILE_W, __VA_ARGS__, DEPTH, FUSE>), grid, dim3(256), 0, st, a)
+    if (KSPLIT) {
+        if (even_half) {
+            if (want_argmin)
+                GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, true, true);
+            else
+                GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, true, false);
+        } else {
+            if (want_argmin)
+                GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, false, true);
+            else
+                GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, false, false);
+        }
+    } else if (even_half) {
         if (want_argmin)
             GCFR_LAUNCH(shadow_fwd_quad_argmin_kernel, true);
         else
