@@ -274,9 +274,14 @@ def main():
                                  camera=cam if a.from_depth else None) for _ in range(max(1, a.streams))]
 
     use_graph = plans is not None and not a.no_graph
+    graph_error = None
     if use_graph:
-        for p_ in plans:
-            p_.capture(d_depth, d_mask_u8, d_light3, d_amb2, None if a.from_depth else d_normals, d_albedo)
+        try:
+            for p_ in plans:
+                p_.capture(d_depth, d_mask_u8, d_light3, d_amb2, None if a.from_depth else d_normals, d_albedo)
+        except Exception as e:      # a runtime that cannot capture: same kernels, issued call by call
+            graph_error, use_graph = repr(e), False
+            torch.cuda.synchronize()
 
     def step(timed):
         if use_graph and step.graph_ok:      # timed region: one hipGraph replay per step (no per-launch events)
@@ -402,6 +407,8 @@ def main():
                          "kernel_ray_steps_per_sec": B * Ll * Hh * Ww * Nn / (shadow_ms * 1e-3),
                          "measured_copy_GBs": measured_copy_bandwidth_gbs(dev)},
         }
+        if graph_error:
+            out["config"]["graph_capture_failed"] = graph_error
         vi = pmc_valu_insts()
         if vi:   # what actually bounds the kernel: VALU issue, not HBM
             out["roofline"]["valu"] = {"insts_per_launch": vi, "insts_per_nominal_ray_step": vi / (B * Ll * Hh * Ww * Nn),
