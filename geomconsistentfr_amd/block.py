@@ -328,7 +328,9 @@ class RenderFwdPlan:
                  mask_batch=None, camera=None):
         self.L_ = _lib.load()
         dev = torch.device(device)
-        if dev.type == "cuda" and dev.index is None:
+        if dev.type != "cuda":
+            raise _lib.GcfrError("RenderFwdPlan needs a HIP device (there is no CPU path); got %s" % dev)
+        if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
         self.dev, self.params, self.shape, self.camera = dev, params, (B, L, H, W), camera
         f32 = dict(dtype=torch.float32, device=dev)

@@ -52,6 +52,19 @@ def test_product_normals_refuse_host_tensors():
         depth_to_normals(torch.zeros(1, 1, 8, 8), torch.eye(3, dtype=torch.float64)[None])
 
 
+def test_render_plan_and_render_block_refuse_the_host():
+    """No CPU fallback anywhere on the product path: host tensors / host devices raise, they are never routed
+    to the oracle."""
+    from geomconsistentfr_amd._lib import GcfrError
+    from geomconsistentfr_amd import block as R
+    with pytest.raises(GcfrError):
+        R.RenderFwdPlan(1, 1, 8, 8, device="cpu")
+    z = torch.zeros(1, 8, 8)
+    with pytest.raises(GcfrError):
+        R.render_fwd(z, torch.ones(1, 8, 8), torch.ones(1, 1, 3), torch.ones(1, 1), torch.zeros(1, 3, 8, 8),
+                     torch.zeros(1, 3, 8, 8))
+
+
 @needs_ref
 def test_reference_checkpoint_loads_and_network_outputs_match_the_reference():
     """The shipped lighting-transfer checkpoint loads with strict=True, and albedo / depth / light head
