@@ -12,7 +12,7 @@ for round in 1 2 3; do
     if [ "$cfg" = "direct" ]; then extra="--direct";
     elif [[ "$cfg" == lib:* ]]; then export GCFR_HIP_LIB="$REPO/geomconsistentfr_amd/lib/${cfg#lib:}"; extra="";
     else extra="--tune $cfg"; fi
-    python bench.py $AB_EXTRA --no-cpu-baseline --steps 100 $extra 2>/dev/null | tail -1 | python -c "
+    python bench.py $AB_EXTRA --no-cpu-baseline --steps ${AB_STEPS:-100} $extra 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$cfg'.ljust(12), 'step %.1f G/s' % (d['value']/1e9), 'kernel+prepass %.4f ms  %.1f G/s' % (d['roofline']['avg_launch_ms'], d['roofline']['kernel_ray_steps_per_sec']/1e9))"
   done
 done
