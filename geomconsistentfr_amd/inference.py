@@ -10,7 +10,7 @@ The reference's three test scripts are `main()` bodies with hard-coded paths; wh
 The reference runs one image per forward (batch_size = 1 hard-coded); here a whole batch goes through one forward.
 Light directions the reference ships in source (S1:519-562) are exposed as LIGHT_DIRECTIONS.
 """
-from typing import Dict, Optional, Sequence
+from typing import Dict
 
 import numpy as np
 import torch

@@ -128,10 +128,3 @@ if __name__ == "__main__":
         b += n1
     print("overall ratio", b / a)
 
-
-def per_wave_histogram(seed=0, tile=(8, 8)):
-    """bodies per wave (min/max bound), to judge load imbalance"""
-    import io, contextlib
-    global _HOOK
-    _HOOK = []
-    run(seed=seed, tile=tile)
