@@ -13,6 +13,12 @@ Files written:
   slt_*.npz        lighting-transfer form (159 samples from 0.03, I=0.41, f=700, +1410)    SLT:169,514
 Every case stores the light/ambient it used, indices into inputs.npz, and outputs as f32
 (full_shading / final_shading / normals are f64 in the reference; they are stored rounded to f32).
+`minimum_distance` (f32) and `argmin` (u8; N <= 160) are what the reference's own
+`(values, idx) = torch.min(point_to_line_distances, dim=0)` (T8:514, S1:492, SLT:499) returned, captured by
+wrapping torch.min while the reference forward runs (ref_shim.capture_min); the reference never returns them.
+For a masked minimum (value 1e6) `argmin` is torch.min's first masked index, which carries no gradient.
+Re-running this script reproduces every forward array bit for bit; the autograd depth gradients of t8_a / t8_b can
+differ by 1 ulp on <0.1 % of pixels from run to run (torch's multi-threaded index_put accumulation order on CPU).
 """
 import os
 import sys
@@ -91,9 +97,11 @@ def run_t8(model, depth, albedo_target, light4, masks_u8, K, grads=None):
     ref_shim.inject(model, d100, lg, sl)
     masks = torch.from_numpy(masks_u8.astype(np.float64))[..., None]
     ctx = torch.enable_grad() if grads else torch.no_grad()
-    with ctx:
+    with ctx, ref_shim.capture_min() as cap:
         out = model(torch.zeros(3, H, W, 3), 200, K, masks)
-    res = dict(albedo=out[0].detach().numpy(), depth=out[1].detach().numpy()[:, 0],
+    assert len(cap.values) == 3
+    res = dict(minimum_distance=np.stack(cap.values).astype(np.float32), argmin=np.stack(cap.indices).astype(np.uint8),
+               albedo=out[0].detach().numpy(), depth=out[1].detach().numpy()[:, 0],
                shadow_mask_weights=out[2].detach().numpy(), full_shading=out[4].detach().numpy().astype(np.float32),
                rendered_images=out[5].detach().numpy(), unit_light_direction=out[6].detach().numpy().reshape(3, 3),
                ambient_values=out[7].detach().numpy().reshape(3))
@@ -124,12 +132,15 @@ def run_single(model, depth, albedo_target, raw4, target_light, target_amb, mask
     mask = torch.from_numpy(mask_u8.astype(np.float64))[..., None]       # (H,W,1) as S1:580 / SLT:541
     tl = torch.from_numpy(np.asarray(target_light, np.float32)).view(1, 3, 1, 1)
     ta = torch.from_numpy(np.asarray([target_amb], np.float32)).view(1, 1, 1)
-    with torch.no_grad():
+    with torch.no_grad(), ref_shim.capture_min() as cap:
         if variant == "S1":
             out = model(torch.zeros(1, H, W, 3), 200, K, mask, tl, ta, mask[None])
         else:
             out = model(torch.zeros(1, H, W, 3), 200, K, mask, tl, ta)
-    return dict(albedo=out[0].numpy()[0], depth=out[1].numpy()[0, 0], shadow_mask_weights=out[2].numpy()[0],
+    assert len(cap.values) == 1
+    # (values, idx) of torch.min at S1:492 / SLT:499 -- BEFORE the +5 inside-light bonus of S1:495-496
+    return dict(minimum_distance=cap.values[0].astype(np.float32), argmin=cap.indices[0].astype(np.uint8),
+                albedo=out[0].numpy()[0], depth=out[1].numpy()[0, 0], shadow_mask_weights=out[2].numpy()[0],
                 full_shading=out[4].numpy()[0].astype(np.float32), rendered_images=out[5].numpy()[0],
                 unit_light_direction=out[6].numpy().reshape(3), ambient_values=out[7].numpy().reshape(1),
                 final_shading=out[8].numpy()[0].astype(np.float32),

@@ -93,6 +93,33 @@ class Const(torch.nn.Module):
         return self.value
 
 
+class capture_min:
+    """Records what the reference's `(values, idx) = torch.min(point_to_line_distances, dim=0)` returns
+    (T8:514, S1:492, SLT:499) for every image of the forward that runs inside the `with` block: the
+    reference never returns `minimum_distance` or `idx`, so the golden generator wraps torch.min for the
+    duration of the reference forward.  `.values` / `.indices` are lists of (H,W) arrays, one per image, in
+    loop order.  The values are those BEFORE the inference scripts' +5 bonus (S1:495-496)."""
+
+    def __enter__(self):
+        self.values, self.indices = [], []
+        self._orig = torch.min
+
+        def wrapped(*a, **k):
+            out = self._orig(*a, **k)
+            dim = k.get("dim", a[1] if len(a) > 1 and isinstance(a[1], int) else None)
+            if dim == 0 and isinstance(out, tuple) and a[0].dim() == 3:
+                self.values.append(out[0].detach().numpy().copy())
+                self.indices.append(out[1].detach().numpy().copy())
+            return out
+
+        torch.min = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        torch.min = self._orig
+        return False
+
+
 def inject(model, depth_over_100, albedo_logits, light_b114):
     """Replace the three heads so forward() runs the render block on exactly these tensors."""
     model.conv_depth_c2_o = Const(depth_over_100)

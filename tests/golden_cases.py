@@ -4,7 +4,9 @@ Every case is flattened to per-(face, light) records with uniform keys so that o
 GPU parity tests iterate over the same list:
   variant, name, depth (H,W) f32, mask (H,W) u8, albedo (3,H,W) f32, light (3,), ambient (scalar),
   params (dict: n_samples,t0,dt,intensity,clamp_light_z_min,normal_z_offset,focal,bonus,bonus_box),
-  expect: dict of reference outputs for that face.
+  expect: dict of reference outputs for that face.  `minimum_distance` / `argmin` are what the reference's own
+  torch.min returned at T8:514 (S1:492, SLT:499), i.e. BEFORE the inference forms' +5 bonus; where the minimum is a
+  masked sample (value 1e6) `argmin` is torch.min's first masked index (the product reports -1 there).
 """
 import os
 
@@ -52,7 +54,7 @@ def single_cases():
             light=z["target_light"][None].copy(), ambient=np.asarray([amb], np.float32),
             params=S1_PARAMS if s1 else SLT_PARAMS,
             expect={k: z[k][None] for k in ("shadow_mask_weights", "full_shading", "rendered_images",
-                                            "unit_light_direction") if k in z.files})
+                                            "unit_light_direction", "minimum_distance", "argmin") if k in z.files})
 
 
 def all_cases():

@@ -52,6 +52,20 @@ def test_c_oracle_matches_reference_golden(name, case):
     o = c_oracle.shade(nrm, case["depth"], case["albedo"], pt[:, None, :], case["ambient"][:, None], md,
                        intensity=prm["intensity"])
     assert np.abs(o["shadow_w"][:, 0] - exp["shadow_mask_weights"]).max() <= 2e-6
+    # minimum_distance and argmin as the reference's own torch.min returned them (T8:514), before the +5 bonus
+    md_raw, am = c_oracle.shadow_min_distance(case["depth"], case["mask"], pt[:, None, :], tt)
+    md_ref, am_ref = exp["minimum_distance"], exp["argmin"].astype(np.int32)
+    lit = md_ref < 1e5
+    assert np.array_equal(lit, md_raw[:, 0] < 1e5)                       # same pixels end on a masked minimum
+    np.testing.assert_array_equal(md_raw[:, 0][~lit], md_ref[~lit])      # ... with the reference's value 1e6
+    err = np.abs(md_raw[:, 0][lit] - md_ref[lit])
+    assert err.max() <= 1e-5 * max(1.0, float(md_ref[lit].max()))        # residue: torch-CPU's vectorised sqrt (1 ulp)
+    assert (err == 0).mean() >= 0.98
+    # argmin: identical wherever the oracle's distance equals the reference's bit for bit; a 1-ulp sqrt
+    # difference can move the first index inside a run of near-tied samples (never observed to exceed 0.1 %)
+    same_bits = lit & (md_raw[:, 0] == md_ref)
+    assert np.array_equal(am[:, 0][same_bits], am_ref[same_bits])
+    assert (am[:, 0][lit] == am_ref[lit]).mean() >= 0.999
     if "full_shading" in exp:
         assert np.abs(o["full_shading"][:, 0] - exp["full_shading"]).max() <= 1e-6
     if "rendered_images" in exp:
