@@ -94,28 +94,74 @@ def synth_faces(B, seed0):
             np.asarray(amb, np.float32))
 
 
-def cpu_baseline(sample_faces=1, seed0=0):
-    """Time the materialised-torch port (oracle/) on this host: forward, no_grad, like the reference's
-    inference path, all host cores (torch's default, which is what the reference script would get).
-    Checker code used here strictly as the reported CPU baseline; bounded sample: `sample_faces` faces."""
+def cpu_baseline(seed0=0, runs=3, with_backward=True):
+    """The CPU baseline of record: oracle/materialised.py -- the op-for-op torch-CPU port
+    of T8:352-524, bit-equal to the imported reference (tests/test_oracle_vs_reference.py); the reference's own .py
+    cannot travel to the GPU box -- in the reference's training form: a batch of B = 3 faces, normals from depth
+    inside the timed region (T8:353), 256 x 256 x 160.  Forward under no_grad at 8, 32 and all host threads, median
+    of `runs` after a warm-up each, the BEST thread count reported (all 256 hyper-threads of the GPU host are ~10x
+    slower than 8-32 for these memory-bound elementwise ops); then forward+backward (autograd through the port, as
+    loss.backward() replays the reference's graph, T8:655) at that thread count, median of `runs`.
+    Checker code used strictly as the reported baseline; bounded: about 2-3 minutes of host time."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import materialised as M
+    from normals_restatement import depth_to_normals
+    B = 3
     cores = os.cpu_count() or 1
+    depth, mask, albedo, _, light, amb = synth_faces(B, seed0)
+    K = torch.zeros(1, 3, 3, dtype=torch.float64)
+    K[:, 0, 0] = K[:, 1, 1] = 1570.0
+    K[:, 2, 2] = 1.0
+    K[:, 0, 2], K[:, 1, 2] = W / 2.0, H / 2.0
+    t_depth, t_alb, t_light, t_amb, t_mask = (torch.from_numpy(depth)[:, None], torch.from_numpy(albedo),
+                                              torch.from_numpy(light), torch.from_numpy(amb), torch.from_numpy(mask))
+
+    def block(d, al, li, am):
+        n = depth_to_normals(d + 1610.0, K)                                  # T8:353 (kornia restatement, f64)
+        n = torch.cat([n[:, 0:1], -n[:, 1:2], n[:, 2:3]], 1)                 # T8:354
+        return M.render_block(d, al, li, am, n, t_mask)
+
+    def forward():
+        with torch.no_grad():
+            block(t_depth, t_alb, t_light, t_amb)
+
+    def forward_backward():
+        leaves = [t.clone().requires_grad_() for t in (t_depth, t_alb, t_light, t_amb)]
+        o = block(*leaves)
+        (o["rendered_images"].sum() + o["shadow_mask_weights"].sum()).backward()
+
+    def median_time(fn, n):
+        ts = []
+        for _ in range(n):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return float(np.median(ts)), ts
+
+    steps = B * H * W * N_SAMPLES
+    by_threads = {}
+    for th in sorted({min(8, cores), min(32, cores), cores}):
+        torch.set_num_threads(th)
+        forward()                                                            # warm-up (thread pool, allocator)
+        med, ts = median_time(forward, runs)
+        by_threads[th] = {"median_s": med, "runs_s": ts, "ray_steps_per_sec": steps / med}
+    best = max(by_threads, key=lambda th: by_threads[th]["ray_steps_per_sec"])
+    out = {"value": by_threads[best]["ray_steps_per_sec"], "unit": "ray-steps/s", "cores": best, "kind": "port",
+           "host_threads_available": cores, "faces_per_s": B / by_threads[best]["median_s"],
+           "forward_by_threads": {str(k): v for k, v in by_threads.items()},
+           "sample": "T8 form: batch of 3 faces 256x256x160 incl. normals from depth, forward no_grad, "
+                     "oracle/materialised.py (op-for-op torch-CPU port of T8:352-524), median of %d runs after a "
+                     "warm-up at each of %s threads; best = %d threads, %.2f s per batch"
+                     % (runs, sorted(by_threads), best, by_threads[best]["median_s"])}
+    if with_backward:
+        torch.set_num_threads(best)
+        med, ts = median_time(forward_backward, runs)
+        out["forward_backward"] = {"value": steps / med, "unit": "ray-steps/s", "cores": best, "median_s": med,
+                                   "runs_s": ts, "faces_per_s": B / med,
+                                   "sample": "same batch, forward with autograd graph + backward of sum(rendered) + "
+                                             "sum(shadow weights), median of %d runs" % runs}
     torch.set_num_threads(cores)
-    depth, mask, albedo, normals, light, amb = synth_faces(sample_faces, seed0)
-    args = (torch.from_numpy(depth)[:, None], torch.from_numpy(albedo), torch.from_numpy(light),
-            torch.from_numpy(amb), torch.from_numpy(normals).double(), torch.from_numpy(mask))
-    with torch.no_grad():
-        small = M.BlockParams(n_samples=8)
-        M.render_block(args[0][:1, :, :64, :64], args[1][:1, :, :64, :64], args[2][:1], args[3][:1],
-                       args[4][:1, :, :64, :64], args[5][:1, :64, :64], small)       # warm the thread pool
-        t = time.perf_counter()
-        M.render_block(*args)
-        dt = time.perf_counter() - t
-    return {"value": sample_faces * H * W * N_SAMPLES / dt, "unit": "ray-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d face(s) 256x256x160, forward no_grad, oracle/materialised.py (op-for-op torch-CPU port "
-                      "of T8:352-524; the reference .py cannot travel to the GPU box), %.1f s" % (sample_faces, dt),
-            "faces_per_s": sample_faces / dt}
+    return out
 
 
 def cpu_baseline_c(sample_faces=8, seed0=0):
@@ -205,7 +251,9 @@ def main():
                          "(an untrained network's output; the bounds then never separate ray and surface)")
     ap.add_argument("--mask", choices=["ellipse", "ones"], default="ellipse",
                     help="'ones' = worst case: no fully masked wave-step exists, nothing is skipped")
-    ap.add_argument("--tune", type=str, default="", help="A/B: comma list key=value for gcfr_tune, e.g. 0=32,2=1")
+    ap.add_argument("--tune", type=str, default="",
+                    help="A/B: comma list of gcfr_options knobs, e.g. tile_w=32,schedule=0,tile_order=2,ksplit=1,"
+                         "depth_bound_skip=0,group=2 (never changes a result bit)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -227,11 +275,9 @@ def main():
     from geomconsistentfr_amd import RenderParams
     from geomconsistentfr_amd import block as R
 
-    if a.tune:
-        from geomconsistentfr_amd import _lib
-        for kv in a.tune.split(","):
-            k, v = kv.split("=")
-            _lib.check(_lib.load().gcfr_tune(int(k), int(v)), "gcfr_tune")
+    from geomconsistentfr_amd import _lib
+    knobs = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)}
+    base_opt = _lib.options(**knobs) if knobs else None
     B = a.faces
     headline = (a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse" and a.depth_noise == 0.0)
     if headline:
@@ -252,9 +298,8 @@ def main():
     d_amb = torch.from_numpy(amb).to(dev)
 
     # HIP events around the dominant (march) kernel alone, recorded on the launch stream by the library
-    # itself (gcfr_profile_events); created through the same HIP runtime torch loaded.
+    # itself (gcfr_options.event_start / event_stop); created through the same HIP runtime torch loaded.
     import ctypes
-    from geomconsistentfr_amd import _lib
     L_ = _lib.load()
     # the exact file torch loaded (same inode -> the same runtime instance, never a second HIP runtime)
     hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
@@ -271,7 +316,8 @@ def main():
         d_mask_u8 = R.mask_to_u8(d_mask).reshape(-1, Hh, Ww).contiguous()
         d_light3, d_amb2 = d_light.reshape(B, Ll, 3).contiguous(), d_amb.reshape(B, Ll).contiguous()
         plans = [R.RenderFwdPlan(B, Ll, Hh, Ww, prm, dev, want_argmin=False, mask_batch=d_mask_u8.shape[0],
-                                 camera=cam if a.from_depth else None) for _ in range(max(1, a.streams))]
+                                 camera=cam if a.from_depth else None, options=base_opt)
+                 for _ in range(max(1, a.streams))]
 
     use_graph = plans is not None and not a.no_graph
     graph_error = None
@@ -286,24 +332,25 @@ def main():
     def step(timed):
         if use_graph and step.graph_ok:      # timed region: one hipGraph replay per step (no per-launch events)
             return plans[step.i % len(plans)].replay()
-        if timed:
+        opt = base_opt
+        if timed:        # this call's options carry an event pair the library records around the march kernel
             e0, e1 = new_event(), new_event()
-            _lib.check(L_.gcfr_profile_events(e0, e1), "gcfr_profile_events")
-            ev_pairs.append((e0, e1))
+            opt = _lib.options(**knobs, event_start=e0, event_stop=e1)
+            ev_pairs.append((e0, e1, opt))
         if plans is not None:
-            out = plans[step.i % len(plans)](d_depth, d_mask_u8, d_light3, d_amb2, None if a.from_depth else d_normals,
-                                             d_albedo)
+            pl_ = plans[step.i % len(plans)]
+            pl_.options = opt
+            out = pl_(d_depth, d_mask_u8, d_light3, d_amb2, None if a.from_depth else d_normals, d_albedo)
+            pl_.options = base_opt
         elif a.direct or a.unfused:
             _, pt = R.light_prep(d_light, prm)
             md, _ = R.shadow_min_distance(d_depth, d_mask, pt.reshape(B, Ll, 3), prm, want_argmin=False,
-                                          use_workspace=not a.direct)
+                                          use_workspace=not a.direct, options=opt)
             out = R.shade(d_normals, d_depth, d_albedo, pt.reshape(B, Ll, 3), d_amb.reshape(B, Ll), md, prm)
         else:
             out = R.render_fwd(d_depth, d_mask, d_light.reshape(B, Ll, 3), d_amb.reshape(B, Ll),
                                None if a.from_depth else d_normals, d_albedo, prm, want_argmin=False,
-                               camera=cam if a.from_depth else None)
-        if timed:
-            _lib.check(L_.gcfr_profile_events(None, None), "gcfr_profile_events")
+                               camera=cam if a.from_depth else None, options=opt)
         return out
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(a.streams)] if a.streams > 1 else None
@@ -350,7 +397,7 @@ def main():
             step(True)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
-        ms = float(np.mean([elapsed_ms(e0, e1) for e0, e1 in ev_pairs]))
+        ms = float(np.mean([elapsed_ms(e0, e1) for e0, e1, _ in ev_pairs]))
         ev_pairs[:] = saved
         return {"ms_per_step": 1e3 * dt / n, "ray_steps_per_sec": B * Ll * Hh * Ww * Nn * n / dt, "avg_launch_ms": ms}
 
@@ -361,12 +408,10 @@ def main():
         assert hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1) == 0
         return ms.value
 
-    if a.direct:      # the direct kernel has no event hook: fall back to the whole-step time
-        shadow_ms = 1e3 * elapsed / a.steps
-    elif use_graph:   # graph replays carry no per-launch events: measured below, on one stream
+    if use_graph:   # graph replays carry no per-launch events: measured below, on one stream
         shadow_ms = None
     else:
-        shadow_ms = float(np.mean([elapsed_ms(e0, e1) for e0, e1 in ev_pairs]))
+        shadow_ms = float(np.mean([elapsed_ms(e0, e1) for e0, e1, _ in ev_pairs]))
     # With several streams the launches of successive steps overlap: an event pair then brackets a kernel that
     # shares the GPU (and rocprofv3's tracing perturbs that overlap, so its average could not agree).  The
     # roofline therefore uses the kernel's UN-overlapped duration, measured live right after the timed region

@@ -19,20 +19,47 @@ _ERRORS = {-1: "GCFR_ERR_INVALID_ARGUMENT", -2: "GCFR_ERR_LAUNCH"}
 
 _p, _i, _f, _d = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_double
 
+N_COUNTERS = 16      # GCFR_N_COUNTERS
+COUNTER_NAMES = ("tiles", "groups_nominal", "groups_visited", "bound_tests", "bodies", "lane_samples", "early_exits",
+                 "tie_remarches", "samples_in_range", "bounds_given_up")
+
+
+class Options(ctypes.Structure):
+    """include/gcfr.h `gcfr_options`: per-call knobs and hooks of the forward entry points (never change a result
+    bit).  Build one with `options(...)`; pass it as `options=` to the block functions / RenderFwdPlan."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("tile_w", _i), ("group", _i), ("ksplit", _i),
+                ("depth_bound_skip", _i), ("schedule", _i), ("tile_order", _i), ("reserved", _i),
+                ("event_start", _p), ("event_stop", _p), ("counters", _p)]
+
+
+def options(tile_w=0, group=0, ksplit=-1, depth_bound_skip=-1, schedule=-1, tile_order=-1, event_start=None,
+            event_stop=None, counters=None) -> Options:
+    o = Options()
+    load().gcfr_options_default(ctypes.byref(o))
+    o.tile_w, o.group, o.ksplit, o.depth_bound_skip = tile_w, group, ksplit, depth_bound_skip
+    o.schedule, o.tile_order = schedule, tile_order
+    o.event_start, o.event_stop, o.counters = event_start, event_stop, counters
+    return o
+
+
+def opt_ref(o):
+    """ctypes argument for a `const gcfr_options *` parameter (None = library defaults)."""
+    return ctypes.byref(o) if o is not None else None
+
+
 _SIGNATURES = {
     "gcfr_version": (ctypes.c_char_p, []),
     "gcfr_sample_table": (_i, [_d, _d, _i, _p]),
     "gcfr_light_prep": (_i, [_p, _i, _i, _f, _f, _p, _p, _p]),
     "gcfr_shadow_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i]),
-    "gcfr_tune": (_i, [_i, _i]),
-    "gcfr_profile_events": (_i, [_p, _p]),
+    "gcfr_options_default": (None, [_p]),
     "gcfr_render_from_depth_fwd": (_i, [_p, _i, _f, _f, _p, _p, _i, _d, _d, _d, _d, _f, _i, _p, _p, _i, _i, _i, _i, _i, _p,
-                                        _f, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p]),
+                                        _f, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p]),
     "gcfr_normals_fwd": (_i, [_p, _i, _i, _i, _d, _d, _d, _d, _f, _i, _p, _p]),
     "gcfr_normals_bwd": (_i, [_p, _p, _i, _i, _i, _d, _d, _d, _d, _f, _i, _p, _p]),
     "gcfr_render_fwd": (_i, [_p, _i, _f, _f, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p, _f,
-                             _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p]),
-    "gcfr_shadow_fwd": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _f, _p, _p, _p, _p, ctypes.c_size_t, _p]),
+                             _p, _p, _p, _p, _p, _p, _p, _p, _p, ctypes.c_size_t, _p, _p]),
+    "gcfr_shadow_fwd": (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _f, _p, _p, _p, _p, ctypes.c_size_t, _p, _p]),
     "gcfr_shade_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
     "gcfr_shadow_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "gcfr_shade_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -51,17 +78,27 @@ def lib_path() -> str:
 
 
 def load():
-    """Load (building first if the sources are newer and hipcc is available) and type the library."""
+    """Load and type the library.  Without an override the in-tree library is (re)built first whenever it is
+    missing or older than a source under csrc/ or include/gcfr.h and hipcc is available; a stale library on a
+    host without hipcc (the GPU box ships the prebuilt .so) is loaded as it is.  `GCFR_HIP_LIB` selects another
+    build of the same ABI (tools/ab.sh); a missing override is an error, never a silent fall-back."""
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.environ.get("GCFR_HIP_LIB") or _build.LIB_PATH  # override: A/B builds of the same ABI (tools/ab.sh)
-    if not os.path.exists(path):
-        try:
-            _build.build()
-        except Exception as e:  # no hipcc on this host
-            raise GcfrError("libgcfr_hip.so is not built (%s) and there is no CPU fallback: run "
-                            "`python -c 'import __graft_entry__ as g; g.build()'`" % e)
+    override = os.environ.get("GCFR_HIP_LIB")
+    if override:
+        if not os.path.exists(override):
+            raise GcfrError("GCFR_HIP_LIB=%s does not exist" % override)
+        path = override
+    else:
+        path = _build.LIB_PATH
+        if _build.needs_build():
+            try:
+                _build.build()
+            except Exception as e:  # no hipcc on this host
+                if not os.path.exists(path):
+                    raise GcfrError("libgcfr_hip.so is not built (%s) and there is no CPU fallback: run "
+                                    "`python -c 'import __graft_entry__ as g; g.build()'`" % e)
     L = ctypes.CDLL(path)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError here = the library does not export the declared ABI

@@ -97,9 +97,10 @@ def mask_to_u8(mask: torch.Tensor) -> torch.Tensor:
 
 def shadow_min_distance(depth: torch.Tensor, mask: torch.Tensor, light_pt: torch.Tensor,
                         params: RenderParams = RenderParams(), want_argmin: bool = True,
-                        use_workspace: bool = True):
+                        use_workspace: bool = True, options=None):
     """depth (B,H,W) f32, mask (B|1,H,W), light_pt (B,L,3) -> min_dist (B,L,H,W) f32, argmin i32|None.
-    Replaces T8:371-515.  use_workspace=False selects the direct-gather kernel (same bits, slower)."""
+    Replaces T8:371-515.  use_workspace=False selects the direct-gather kernel (same bits, slower).
+    `options`: a `_lib.Options` (kernel / schedule selection and hooks; never changes a result bit)."""
     _require_device(depth, mask, light_pt)
     L_ = _lib.load()
     depth = _f32c(depth)
@@ -118,7 +119,7 @@ def shadow_min_distance(depth: torch.Tensor, mask: torch.Tensor, light_pt: torch
                                       B, L, H, W, params.n_samples, tt.data_ptr(), float(params.inside_bonus),
                                       box, md.data_ptr(), am.data_ptr() if am is not None else None,
                                       ws.data_ptr() if ws is not None else None, ws_bytes,
-                                      _stream_ptr(depth.device)), "gcfr_shadow_fwd")
+                                      _stream_ptr(depth.device), _lib.opt_ref(options)), "gcfr_shadow_fwd")
     return md, am
 
 
@@ -154,7 +155,7 @@ def shade(normals, depth, albedo, light_pt, ambient, min_dist, params: RenderPar
 
 
 def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParams = RenderParams(),
-               want_argmin: bool = True, camera=None):
+               want_argmin: bool = True, camera=None, options=None):
     """One enqueue for the whole forward block (gcfr_render_fwd): light prep, depth repack, ray march with
     the shading fused into its epilogue.  depth (B,H,W), mask (B|1,H,W), light (B,L,3) raw/target,
     ambient (B,L), normals/albedo (B,3,H,W).  Returns a dict of f32 tensors (B,L,...).
@@ -199,7 +200,7 @@ def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParam
                 ambient.data_ptr(), B, L, H, W, params.n_samples, tt.data_ptr(), float(params.inside_bonus), box,
                 float(params.directional_intensity), unit.data_ptr(), pt.data_ptr(), md.data_ptr(), _opt_ptr(am),
                 w.data_ptr(), full.data_ptr(), fin.data_ptr(), ren.data_ptr(), ws.data_ptr(), ws_bytes,
-                _stream_ptr(dev)), "gcfr_render_fwd")
+                _stream_ptr(dev), _lib.opt_ref(options)), "gcfr_render_fwd")
         else:
             fx, fy, cx, cy, z_off = [float(v) for v in camera]
             nout = torch.empty((B, 3, H, W), **f32)
@@ -209,7 +210,7 @@ def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParam
                 ambient.data_ptr(), B, L, H, W, params.n_samples, tt.data_ptr(), float(params.inside_bonus), box,
                 float(params.directional_intensity), unit.data_ptr(), pt.data_ptr(), md.data_ptr(), _opt_ptr(am),
                 nout.data_ptr(), w.data_ptr(), full.data_ptr(), fin.data_ptr(), ren.data_ptr(), ws.data_ptr(),
-                ws_bytes, _stream_ptr(dev)), "gcfr_render_from_depth_fwd")
+                ws_bytes, _stream_ptr(dev), _lib.opt_ref(options)), "gcfr_render_from_depth_fwd")
             out["surface_normals"] = nout
     return out
 
@@ -325,8 +326,9 @@ class RenderFwdPlan:
     Inputs must already be device tensors of the planned shapes and dtypes (f32, mask u8)."""
 
     def __init__(self, B, L, H, W, params: RenderParams = RenderParams(), device="cuda", want_argmin=False,
-                 mask_batch=None, camera=None):
+                 mask_batch=None, camera=None, options=None):
         self.L_ = _lib.load()
+        self.options = options          # _lib.Options or None; kept alive here, read by the library at every call
         dev = torch.device(device)
         if dev.type != "cuda":
             raise _lib.GcfrError("RenderFwdPlan needs a HIP device (there is no CPU path); got %s" % dev)
@@ -392,53 +394,27 @@ class RenderFwdPlan:
     def __call__(self, depth, mask_u8, light, ambient, normals, albedo):
         """depth (B,H,W) f32, mask_u8 (B|1,H,W) u8, light (B,L,3) f32, ambient (B,L) f32, albedo (B,3,H,W) f32,
         normals (B,3,H,W) f32 or None (plan built with camera=...).  All contiguous, on the plan's device."""
-        key = (id(depth), id(mask_u8), id(light), id(ambient), id(normals), id(albedo))
-        if key != self._validated:   # (the checks cost ~14 us of host time: once per set of tensors, not per call)
+        # (the checks cost ~14 us of host time: once per set of buffers, not per call.  The key is what the kernels
+        # actually consume -- address, shape, dtype, device -- so a new tensor that happens to reuse a Python id,
+        # or a tensor whose storage was reassigned, is validated again.)
+        key = tuple(None if t is None else (t.data_ptr(), tuple(t.shape), t.dtype, t.device, t.is_contiguous())
+                    for t in (depth, mask_u8, light, ambient, normals, albedo))
+        if key != self._validated:
             self._validate(depth, mask_u8, light, ambient, normals, albedo)
             self._validated = key
         st = torch.cuda.current_stream(self.dev).cuda_stream
         if self.camera is None:
             rc = self.L_.gcfr_render_fwd(light.data_ptr(), *self._head, depth.data_ptr(), mask_u8.data_ptr(),
                                          self.mask_batch, normals.data_ptr(), albedo.data_ptr(), ambient.data_ptr(),
-                                         *self._tail, *self._outs, st)
+                                         *self._tail, *self._outs, st, _lib.opt_ref(self.options))
         else:
             fx, fy, cx, cy, z_off = [float(v) for v in self.camera]
             rc = self.L_.gcfr_render_from_depth_fwd(light.data_ptr(), *self._head, depth.data_ptr(),
                                                     mask_u8.data_ptr(), self.mask_batch, fx, fy, cx, cy, z_off, 1,
                                                     albedo.data_ptr(), ambient.data_ptr(), *self._tail,
-                                                    self.out["surface_normals"].data_ptr(), *self._outs, st)
+                                                    self.out["surface_normals"].data_ptr(), *self._outs, st,
+                                                    _lib.opt_ref(self.options))
         _lib.check(rc, "gcfr_render_fwd (plan)")
-        return self.out
-
-
-class GraphedRenderFwd:
-    """hipGraph replay of the eager `render_fwd` for fixed shapes: captures one call on static buffers; `__call__`
-    copies the new inputs into them and replays.  Forward only (no autograd).  On ONE stream a B=8 step is
-    GPU-bound, so the replay is bit-identical but not faster (tools/graph_latency.py: 91 vs 86 us); the host time
-    it saves (56 -> 14 us per step) only matters once several streams keep the GPU full -- `RenderFwdPlan.capture`
-    is the form bench.py uses for that."""
-
-    def __init__(self, depth, mask, light, ambient, normals, albedo, params: RenderParams = RenderParams()):
-        _require_device(depth, mask, light, ambient, normals, albedo)
-        self.params = params
-        self.static = [t.detach().clone().contiguous() for t in (depth, mask, light, ambient, normals, albedo)]
-        self.static[1] = mask_to_u8(self.static[1])
-        sample_table(params, depth.device)                       # materialise the table outside the capture
-        s = torch.cuda.Stream(device=depth.device)
-        s.wait_stream(torch.cuda.current_stream(depth.device))
-        with torch.cuda.stream(s):                               # warm-up on the side stream, as torch requires
-            for _ in range(2):
-                render_fwd(*self.static, params, want_argmin=False)
-        torch.cuda.current_stream(depth.device).wait_stream(s)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = render_fwd(*self.static, params, want_argmin=False)
-
-    def __call__(self, depth, mask, light, ambient, normals, albedo):
-        for dst, src in zip(self.static, (depth, mask, light, ambient, normals, albedo)):
-            if src is not dst:
-                dst.copy_(src if dst.dtype == src.dtype else src.to(dst.dtype))
-        self.graph.replay()
         return self.out
 
 
@@ -497,6 +473,36 @@ class _RenderFromDepthFunction(torch.autograd.Function):
         return (grad_depth.reshape(B, 1, H, W), grad_albedo, grad_light, grad_amb.reshape(B).float(), None, None, None)
 
 
+_CAMERA_CACHE = {}      # id(tensor) -> (weakref to the tensor, its in-place version, scalars)
+
+
+def camera_scalars(camera_matrix: torch.Tensor):
+    """(fx, fy, cx, cy) of a (1|B,3,3) camera matrix as host floats, or None if the B matrices differ.
+    The reference builds K on the host and passes `intrinsic_matrix.cuda()` to every forward (T8:571-577, 618).
+    A host tensor is simply read.  A DEVICE tensor has to be copied back -- a device-to-host sync -- so its scalars
+    are cached per tensor OBJECT: the entry holds a weak reference and the tensor's in-place version counter, and is
+    only trusted while that very object is alive and unmodified (an address- or id-keyed cache would hand a freed
+    tensor's scalars to whatever is allocated in its place).  Callers that keep one K on the device (Trainer does)
+    therefore synchronise once; callers that upload a fresh K every step should pass the host tensor instead."""
+    import weakref
+
+    def read(K):
+        K = K.detach().to("cpu", torch.float64)
+        same = K.shape[0] == 1 or bool((K == K[:1]).all())
+        return (float(K[0, 0, 0]), float(K[0, 1, 1]), float(K[0, 0, 2]), float(K[0, 1, 2])) if same else None
+
+    if camera_matrix.device.type == "cpu":
+        return read(camera_matrix)
+    key = id(camera_matrix)
+    ent = _CAMERA_CACHE.get(key)
+    if ent is not None and ent[0]() is camera_matrix and ent[1] == camera_matrix._version:
+        return ent[2]
+    scalars = read(camera_matrix)                                   # the only sync: first use of this tensor object
+    _CAMERA_CACHE[key] = (weakref.ref(camera_matrix, lambda _r, k=key: _CAMERA_CACHE.pop(k, None)),
+                          camera_matrix._version, scalars)
+    return scalars
+
+
 def render_from_depth(depth, albedo, light, ambient, camera_matrix, z_offset, mask,
                       params: RenderParams = RenderParams()):
     """The whole T8:353-522 seam for one light per image: normals from depth, shading, ray march, composite.
@@ -506,14 +512,13 @@ def render_from_depth(depth, albedo, light, ambient, camera_matrix, z_offset, ma
     from .normals import depth_to_normals
     B, _, H, W = depth.shape
     needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (depth, albedo, light, ambient))
-    K = camera_matrix.detach().to("cpu", torch.float64)
-    per_image_K = K.shape[0] != 1 and not bool((K == K[:1]).all())
-    if per_image_K:  # per-image camera matrices: the three-stage path handles them
+    k4 = camera_scalars(camera_matrix)
+    if k4 is None:  # per-image camera matrices: the three-stage path handles them
         normals = depth_to_normals(depth, camera_matrix, z_offset=z_offset)
         r = render(depth, albedo, light, ambient, normals, mask, params)
         r["surface_normals"] = normals
         return r
-    cam = (float(K[0, 0, 0]), float(K[0, 1, 1]), float(K[0, 0, 2]), float(K[0, 1, 2]), float(z_offset))
+    cam = k4 + (float(z_offset),)
     if needs_grad:
         _require_device(depth, albedo, light, ambient, mask)
         mask_u8 = mask_to_u8(mask).reshape(-1, H, W)

@@ -23,12 +23,28 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: libgcfr_hip.so cannot be built")
 
 
+HASH_PATH = os.path.join(LIB_DIR, "libgcfr_hip.srchash")
+
+
+def source_hash() -> str:
+    """sha256 over the flags and every file the library is compiled from (csrc/*, include/gcfr.h)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(PKG, "..", "include", "gcfr.h")]
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+    """True when the library is missing or was built from other sources (content hash recorded beside the .so --
+    not mtimes, which a snapshot copy to the GPU box does not preserve)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG, "..", "include", "gcfr.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(HASH_PATH) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -39,6 +55,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(HASH_PATH, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB_PATH
 
 

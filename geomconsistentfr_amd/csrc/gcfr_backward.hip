@@ -17,6 +17,10 @@
 
 #include "../../include/gcfr.h"
 
+#ifndef GCFR_BWD_INLINE
+#define GCFR_BWD_INLINE inline
+#endif
+
 namespace gcfr {
 
 __device__ inline double wave_sum(double v)
@@ -65,7 +69,7 @@ struct ShadowBwdArgs {
 // Backward of the ray march for ONE pixel and light: re-evaluates the argmin sample k and applies the chain
 // rule (see the file header).  g32 = dLoss/d minimum_distance.  Scatters the depth gradients (five f32 atomics
 // into gz, the image's grad_depth plane) and returns the light-point gradient in gC.
-__device__ inline void shadow_bwd_pixel(const float *zimg, float *gz, const double *t_table, int H, int W,
+__device__ GCFR_BWD_INLINE void shadow_bwd_pixel(const float *zimg, float *gz, const double *t_table, int H, int W,
                                         int r, int c, float Cx, float Cy, float Cz, int k, float g32,
                                         double (&gC)[3])
 {

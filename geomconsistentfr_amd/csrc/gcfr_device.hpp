@@ -194,7 +194,10 @@ __device__ inline void unit_normal(const NormalsArgs &a, const float *z, int r, 
 
 // Backward of unit_normal() for one pixel: (g0,g1,g2) = dLoss/d(unit normal output, y already negated);
 // scatters dLoss/d depth to the eight stencil neighbours (f32 atomics into gz, the image's grad_depth plane).
-__device__ inline void normals_bwd_pixel(const NormalsArgs &a, const float *z, float *gz, int r, int c,
+#ifndef GCFR_NBWD_INLINE
+#define GCFR_NBWD_INLINE inline
+#endif
+__device__ GCFR_NBWD_INLINE void normals_bwd_pixel(const NormalsArgs &a, const float *z, float *gz, int r, int c,
                                          double g0, double g1_in, double g2)
 {
     const Grad3 g = point_gradients(a, z, r, c);

@@ -22,6 +22,9 @@
 
 #include "../../include/gcfr.h"
 
+#include <atomic>
+#include <cstddef>
+
 namespace gcfr {
 
 // ----------------------------------------------------------------------------------------------
@@ -320,7 +323,8 @@ __device__ inline float f32_unsortable(int i)
 // group of `group` consecutive samples can touch, derived from the sample table on the device by both
 // kernels.  The host sizes the grid for s = 8.
 // ----------------------------------------------------------------------------------------------
-__device__ inline int zb_log2_stride(int H, int W, int N, const double *t_table, int group, bool *fits = nullptr)
+template <class TablePtrT>
+__device__ inline int zb_log2_stride(int H, int W, int N, TablePtrT t_table, int group, bool *fits = nullptr)
 {
     if (fits)
         *fits = false;
@@ -462,70 +466,139 @@ __device__ inline void build_zbounds_block(int block, int b, const float *__rest
         zb[(size_t)b * zb_max_tiles(H, W) + tile] = make_float4(pa, pb, wlo, whi);
 }
 
-// Prepass.  Per image: (a) repack depth into 2x2-neighbourhood texels, (b) optional light preparation,
-// (d) the depth-bounds tiles (tail blocks), (c) per-block partial bounding boxes of the mask's non-zero cells as four minima
-// {r_min, c_min, -r_max, -c_max} (kBBoxInit where the block saw no non-zero cell).
+// Per-image statistics the march needs before it starts: the bounding box of the mask's non-zero cells and the
+// depth range.  One 256-thread block per chunk of kStatChunk pixels writes ONE partial record (four + two minima:
+// {r_min, c_min, -r_max, -c_max}, {z_min, -z_max} as sortable ints; kBBoxInit / INT_MAX where the chunk has
+// nothing to report), so an image has only P/16384 partials (4 at 256x256) and every march wave reduces them
+// itself with one load and six DPP minima -- no atomics to initialise, no workgroup barrier in the march (round 1
+// kept 256 partials per image and reduced them through LDS in every march workgroup's prologue).
+// The tile queue of the persistent schedule lives 256 B after the sample-table flag: every tile start reads the flag
+// with a scalar load, and a line that is being hammered by device-scope atomics answers reads slowly.
+constexpr int kQueueSlot = 64;
+constexpr int kStatChunk = 16384;
+__host__ __device__ inline int n_stat_chunks(int H, int W) { return (H * W + kStatChunk - 1) / kStatChunk; }
+
+__device__ inline void stat_mask_dword(uint32_t d, int r, int c, int &rmin, int &cmin, int &nrmax, int &ncmax)
+{
+    const uint32_t nz = (d | ((d & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;  // bit 7 of every non-zero byte
+    if (nz) {
+        const int first = __builtin_ctz(nz) >> 3, last = (31 - __builtin_clz(nz)) >> 3;
+        rmin = min(rmin, r);
+        nrmax = min(nrmax, -r);
+        cmin = min(cmin, c + first);
+        ncmax = min(ncmax, -(c + last));
+    }
+}
+
+__device__ inline void build_stats_block(int chunk, int b, const float *__restrict__ depth,
+                                         const uint8_t *__restrict__ mask, int mask_batch, int H, int W,
+                                         int *__restrict__ bbox, int *__restrict__ zrange, bool want_z, bool vec_ok)
+{
+    const int P = H * W;
+    const int p0 = chunk * kStatChunk;
+    const bool want_box = b < mask_batch;
+    int rmin = kBBoxInit, cmin = kBBoxInit, nrmax = kBBoxInit, ncmax = kBBoxInit;
+    float zlo = __builtin_inff(), zhi = -__builtin_inff();  // fminf / fmaxf drop NaN cells (a NaN sample never wins)
+    const float *z = depth + (size_t)b * P;
+    const uint8_t *m = mask + (size_t)b * P;  // only dereferenced when want_box
+    if (vec_ok) {  // W % 16 == 0 and 16-byte aligned planes: 16 pixels of one row per lane and step
+#pragma unroll
+        for (int it = 0; it < kStatChunk / 4096; ++it) {
+            const int i = p0 + it * 4096 + (int)threadIdx.x * 16;
+            if (i < P) {
+                if (want_z) {
+                    const float4 *zp = (const float4 *)(z + i);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = zp[q];
+                        zlo = fminf(fminf(zlo, v.x), fminf(fminf(v.y, v.z), v.w));
+                        zhi = fmaxf(fmaxf(zhi, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+                    }
+                }
+                if (want_box) {
+                    const uint4 mv = *(const uint4 *)(m + i);
+                    const int r = i / W, c = i - r * W;
+                    stat_mask_dword(mv.x, r, c, rmin, cmin, nrmax, ncmax);
+                    stat_mask_dword(mv.y, r, c + 4, rmin, cmin, nrmax, ncmax);
+                    stat_mask_dword(mv.z, r, c + 8, rmin, cmin, nrmax, ncmax);
+                    stat_mask_dword(mv.w, r, c + 12, rmin, cmin, nrmax, ncmax);
+                }
+            }
+        }
+    } else {  // any width / alignment: one pixel per lane and step
+        for (int e = threadIdx.x; e < kStatChunk; e += 256) {
+            const int i = p0 + e;
+            if (i >= P)
+                break;
+            if (want_z) {
+                const float v = z[i];
+                zlo = fminf(zlo, v);
+                zhi = fmaxf(zhi, v);
+            }
+            if (want_box && m[i] != 0) {
+                const int r = i / W, c = i - r * W;
+                rmin = min(rmin, r);
+                cmin = min(cmin, c);
+                nrmax = min(nrmax, -r);
+                ncmax = min(ncmax, -c);
+            }
+        }
+    }
+    __shared__ int part[4][6];
+    const int wv = threadIdx.x >> 6;
+    const int v0 = wave_min_i32(rmin), v1 = wave_min_i32(cmin), v2 = wave_min_i32(nrmax), v3 = wave_min_i32(ncmax);
+    const int v4 = wave_min_i32(f32_sortable(zlo)), v5 = wave_min_i32(f32_sortable(-zhi));
+    if ((threadIdx.x & 63) == 0) {
+        part[wv][0] = v0;
+        part[wv][1] = v1;
+        part[wv][2] = v2;
+        part[wv][3] = v3;
+        part[wv][4] = v4;
+        part[wv][5] = v5;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int q = threadIdx.x;
+        const int v = min(min(part[0][q], part[1][q]), min(part[2][q], part[3][q]));
+        const size_t rec = (size_t)b * n_stat_chunks(H, W) + chunk;
+        if (q < 4) {
+            if (want_box)
+                bbox[rec * 4 + q] = v;
+        } else if (want_z) {
+            zrange[rec * 2 + (q - 4)] = v;
+        }
+    }
+}
+
+// Prepass, one launch.  Grid x = [depth-bounds tiles | statistics chunks | repack blocks], y = image:
+//   (d) the depth-bounds tiles (head of the grid: their short dependent-load chains start first),
+//   (c) per-chunk partial mask bounding boxes and depth ranges (build_stats_block),
+//   (a) the repack of depth into 2x2-neighbourhood texels; its first block also runs (b) the optional light
+//       preparation, (e) the sample-table check and zeroes the persistent march's tile queue.
 __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict__ depth,
                                                          float4 *__restrict__ quad, int H, int W,
                                                          PrepassLights pl,
                                                          const uint8_t *__restrict__ mask, int mask_batch,
                                                          int *__restrict__ bbox, int *__restrict__ zrange,
-                                                         float4 *__restrict__ zb, int quad_blocks, int N,
+                                                         float4 *__restrict__ zb, int zb_blocks, int stat_blocks,
+                                                         int want_z, int vec_ok, int N,
                                                          const double *__restrict__ t_table, int group,
                                                          int *__restrict__ tflag)
 {
     const int Wp = W + 1, Hp = H + 1;
     const int b = blockIdx.y;
-    // head of the grid: the depth-bounds tiles (same launch; their short dependent-load chains start first and
-    // run alongside the repack blocks)
-    const int zb_blocks = (int)gridDim.x - quad_blocks;
     if ((int)blockIdx.x < zb_blocks) {
         build_zbounds_block((int)blockIdx.x, b, depth, zb, H, W, N, t_table, group);
         return;
     }
-    const int qb = (int)blockIdx.x - zb_blocks;
+    if ((int)blockIdx.x < zb_blocks + stat_blocks) {
+        build_stats_block((int)blockIdx.x - zb_blocks, b, depth, mask, mask_batch, H, W, bbox, zrange, want_z != 0,
+                          vec_ok != 0);
+        return;
+    }
+    const int qb = (int)blockIdx.x - zb_blocks - stat_blocks;
     const int i = qb * blockDim.x + threadIdx.x;
-    const int n_partials = (H * W + 255) / 256;
-    if (zrange && qb < n_partials) {  // block-uniform
-        // partial depth range of the 256 cells this block covers, as two minima {z_min, -z_max} in sortable ints
-        // (contended atomics on one per-image slot cost 0.2 ms here); reduced by the march like the boxes below
-        __shared__ int zpart[4][2];
-        const bool in = i < H * W;
-        const float v = in ? depth[(size_t)b * H * W + i] : 0.0f;
-        const bool ok = in && (v == v);  // NaN cells do not count (a NaN sample never wins the minimum)
-        const int z0 = wave_min_i32(ok ? f32_sortable(v) : 0x7fffffff);
-        const int z1 = wave_min_i32(ok ? f32_sortable(-v) : 0x7fffffff);
-        const int wv = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) {
-            zpart[wv][0] = z0;
-            zpart[wv][1] = z1;
-        }
-        __syncthreads();
-        if (threadIdx.x < 2)
-            zrange[((size_t)b * n_partials + qb) * 2 + threadIdx.x] =
-                min(min(zpart[0][threadIdx.x], zpart[1][threadIdx.x]), min(zpart[2][threadIdx.x], zpart[3][threadIdx.x]));
-    }
-    if (b < mask_batch && qb < n_partials) {  // block-uniform
-        // partial bounding box of the 256 mask cells this block covers -> bbox[b][qb] (no atomics,
-        // nothing to initialise); the march kernel reduces the partials of its image in its prologue
-        __shared__ int part[4][4];
-        const bool set = (i < H * W) && mask[(size_t)b * H * W + i] != 0;
-        const int r = i / W, c = i - r * W;
-        const int v0 = wave_min_i32(set ? r : kBBoxInit), v1 = wave_min_i32(set ? c : kBBoxInit);
-        const int v2 = wave_min_i32(set ? -r : kBBoxInit), v3 = wave_min_i32(set ? -c : kBBoxInit);
-        const int wv = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) {
-            part[wv][0] = v0;
-            part[wv][1] = v1;
-            part[wv][2] = v2;
-            part[wv][3] = v3;
-        }
-        __syncthreads();
-        if (threadIdx.x < 4)
-            bbox[((size_t)b * n_partials + qb) * 4 + threadIdx.x] =
-                min(min(part[0][threadIdx.x], part[1][threadIdx.x]), min(part[2][threadIdx.x], part[3][threadIdx.x]));
-    }
-    if (tflag && qb == 0 && b == 0 && threadIdx.x < 64) {
+    if (qb == 0 && b == 0 && threadIdx.x < 64) {
         // Is the sample table what the march's pruning / skipping reasons about -- increasing, inside [0, 1]
         // (every sample between the pixel and its end point) and uniform to 0.1 %?  One wave checks, once per launch.
         bool ok = (N >= 2) && (t_table[0] >= 0.0) && (t_table[N - 1] <= 1.0);
@@ -538,8 +611,10 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
             }
         }
         const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
-        if (threadIdx.x == 0)
-            *tflag = all_ok ? 1 : 0;
+        if (threadIdx.x == 0) {
+            tflag[0] = all_ok ? 1 : 0;
+            tflag[kQueueSlot] = 0;  // the persistent march's tile queue (an atomic counter), reset for this call
+        }
     }
     if (pl.light_raw && qb == 0) {
         for (int l = threadIdx.x; l < pl.L; l += blockDim.x)
@@ -559,33 +634,64 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
     quad[o] = make_float4(zUL, zUR, zLL, zLR);
 }
 
-struct ShadowQuadArgs {
-    const float *depth;     // (B,H,W)      own-pixel depth
-    const float4 *quad;     // (B,H+1,W+1)  prepass output
-    const int *bbox;        // (MB,P/256,4) prepass output: partial mask bounding boxes {r_min, c_min, -r_max, -c_max}
-    const float4 *zb;       // (B,zb_max_tiles) prepass output: depth bounds grid {a, b, c_lo, c_hi}, or null (skip off)
-    const int *zrange;      // (B,P/256,2) prepass output: partial depth ranges {z_min, -z_max} (sortable ints)
-    const int *tflag;       // (1) prepass output: 1 iff the sample table is increasing, inside [0,1] and uniform
-    const uint8_t *mask;    // (MB,H,W)
-    const float *light_pt;  // (B,L,3)
-    const double *t_table;  // (N)
+// Operands of the per-pixel epilogue (distance finish, optional fused shading).  They live in the kernel-argument
+// segment like the rest of ShadowQuadArgs, but the march reads them through an opaque pointer AFTER the sample loop
+// (epilogue_args()): referenced through the by-value struct the compiler loads every pointer at kernel entry and
+// keeps ~40 SGPRs live across the loop, which pushed the loop's wave-uniform f64 constants into VGPRs (round 1:
+// 106 SGPRs, 28 B/lane of scratch at the forced occupancy).
+struct MarchEpilogueArgs {
     float *min_dist;        // (B,L,H,W)
     int32_t *argmin;        // (B,L,H,W) or null
-    int32_t mask_batch, B, L, H, W, N;
-    int32_t quads_x, quads_y;  // grid x / y: 4-tile (or, k-split, 1-tile) block columns and tile rows
-    int32_t bl_offset;         // first (image, light) index of this launch (grid z is limited to 65535)
     float bonus, bx_lo, bx_hi, by_lo, by_hi;
     // fused shading epilogue (FUSE_SHADE): T8:364-369, 517-522 on the pixel the lane just marched
-    const float *normals;   // (B,3,H,W)
+    const float *normals;   // (B,3,H,W); nullptr: the epilogue computes the normal from the depth stencil (T8:353-354)
     const float *albedo;    // (B,3,H,W)
     const float *ambient;   // (B,L)
     float *shadow_w, *full, *final_shading, *rendered;
     float intensity;
-    int32_t ksplit;  // host-side choice, see shadow_fwd_quad_kernel
-    // normals == nullptr: the epilogue computes the normal from the depth stencil itself (T8:353-354 fused)
     NormalsArgs nrm;
-    float *normals_out;  // (B,3,H,W) or null
+    float *normals_out;     // (B,3,H,W) or null
 };
+
+struct ShadowQuadArgs {
+    const float *depth;     // (B,H,W)      own-pixel depth
+    const float4 *quad;     // (B,H+1,W+1)  prepass output
+    const int *bbox;        // (MB,n_stat,4) prepass output: partial mask bounding boxes {r_min, c_min, -r_max, -c_max}
+    const float4 *zb;       // (B,zb_max_tiles) prepass output: depth bounds grid {a, b, c_lo, c_hi}, or null (skip off)
+    const int *zrange;      // (B,n_stat,2) prepass output: partial depth ranges {z_min, -z_max} (sortable ints)
+    int *tflag;             // [0] prepass output: 1 iff the sample table is increasing, inside [0,1] and uniform;
+                            // [kQueueSlot] the persistent schedule's tile queue (zeroed by the prepass)
+    const uint8_t *mask;    // (MB,H,W)
+    const float *light_pt;  // (B,L,3)
+    const double *t_table;  // (N)
+    unsigned long long *counters;  // GCFR_COUNTERS builds: work counts, see gcfr_options
+    int32_t mask_batch, B, L, H, W, N;
+    int32_t tiles_x, tiles_y;  // tiles per image row / column
+    int32_t total_tiles;       // B * L * tiles_x * tiles_y (persistent schedule)
+    int32_t tile_order;        // persistent schedule: see gcfr_options
+    int32_t bl_offset;         // grid schedule: first (image, light) index of this launch (grid z is limited to 65535)
+    MarchEpilogueArgs epi;
+};
+
+// The march kernels take ShadowQuadArgs by value as their only argument and read it IN PLACE from the
+// kernel-argument segment through this pointer (scalar loads), not through the by-value copy: referenced by value
+// the compiler loads every field at kernel entry and keeps it in SGPRs for the kernel's lifetime -- ~40 SGPRs of
+// epilogue pointers live across the sample loop, and in the persistent schedule everything live across the tile loop
+// (round 1: 106 SGPRs, the loop's wave-uniform f64 constants pushed into VGPRs, 28 B/lane of scratch).  An opaque
+// redefinition of the pointer (`launder`) at the top of each tile and before the epilogue makes the loads after
+// it un-hoistable, so each phase keeps only its own operands.
+typedef const __attribute__((address_space(4))) ShadowQuadArgs *ArgPtr;
+typedef const __attribute__((address_space(4))) MarchEpilogueArgs *EpiPtr;
+__device__ __forceinline__ ArgPtr kernel_args()
+{
+    return (ArgPtr)__builtin_amdgcn_kernarg_segment_ptr();  // the struct starts the segment
+}
+template <class T>
+__device__ __forceinline__ T launder(T p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
 
 constexpr double kRintMagic = 6755399441055744.0;  // 2^52 + 2^51
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -595,34 +701,89 @@ __device__ inline int lo32(double v)
     return (int)(unsigned)(__builtin_bit_cast(unsigned long long, v) & 0xffffffffull);
 }
 
-// KSPLIT = false: the 4 waves of a workgroup march 4 horizontally adjacent tiles, all N samples each.
+// Work counters of the counting build (-DGCFR_COUNTERS; tools/count_work.py): wave-uniform tallies, added to
+// gcfr_options.counters once per tile.  Compiled out of the product build.
+enum { kCntTiles, kCntGroupsNominal, kCntGroupsVisited, kCntBoundTests, kCntBodies, kCntLaneSamples, kCntEarlyExit,
+       kCntTieRemarch, kCntSamplesInRange, kCntBoundsGivenUp, kCntUsed };
+#ifdef GCFR_COUNTERS
+#define GCFR_COUNT(i, n) (cnt[i] += (unsigned)(n))
+#else
+#define GCFR_COUNT(i, n) ((void)0)
+#endif
+
+// Per-image statistics, wave-uniform: the reduction of the prepass' partial records (build_stats_block).
+struct ImageStats {
+    int r_min, c_min, r_max, c_max;  // bounding box of the mask's non-zero cells (r_min == kBBoxInit: none)
+    int gz_lo_s, gz_nhi_s;           // depth range {z_min, -z_max} as sortable ints
+};
+__device__ inline ImageStats reduce_image_stats(ArgPtr a, int b, int lane, bool want_z)
+{
+    const int n = n_stat_chunks(a->H, a->W);
+    const int4 *pb = (const int4 *)a->bbox + (size_t)(a->mask_batch == 1 ? 0 : b) * n;
+    const int2 *pz = (const int2 *)a->zrange + (size_t)b * n;
+    int4 m = make_int4(kBBoxInit, kBBoxInit, kBBoxInit, kBBoxInit);
+    int2 mz = make_int2(0x7fffffff, 0x7fffffff);
+    for (int j = lane; j < n; j += 64) {
+        const int4 v = pb[j];
+        m.x = min(m.x, v.x);
+        m.y = min(m.y, v.y);
+        m.z = min(m.z, v.z);
+        m.w = min(m.w, v.w);
+        if (want_z) {
+            const int2 vz = pz[j];
+            mz.x = min(mz.x, vz.x);
+            mz.y = min(mz.y, vz.y);
+        }
+    }
+    ImageStats st;
+    st.r_min = wave_min_i32(m.x);
+    st.c_min = wave_min_i32(m.y);
+    st.r_max = -wave_min_i32(m.z);
+    st.c_max = -wave_min_i32(m.w);
+    st.gz_lo_s = want_z ? wave_min_i32(mz.x) : 0x7fffffff;
+    st.gz_nhi_s = want_z ? wave_min_i32(mz.y) : 0x7fffffff;
+    return st;
+}
+
+// One tile of one (image, light) pair: 64 lanes = 64 pixels, all N samples (KSPLIT: this wave's quarter of them).
+// KSPLIT = false: the waves of a workgroup march different tiles and never synchronise.
 // KSPLIT = true : the 4 waves march the SAME tile, a contiguous quarter of the sample range each, and
 //                 combine their partial minima through LDS (earliest index wins ties, as torch.min).
-//                 Same total work in 4x finer, more uniform pieces: used for small batches, where a few
+//                 Same total work in 4x finer, more uniform pieces: used for tiny launches, where a few
 //                 heavy (fully unmasked) tiles otherwise leave the SIMDs idle at the tail of the launch.
+#ifndef GCFR_TILE_INLINE
+#define GCFR_TILE_INLINE __forceinline__
+#endif
 template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool KSPLIT>
-__device__ __forceinline__ void march_tile(ShadowQuadArgs a)
+__device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy, const int tx,
+                                           const ImageStats &st)
 {
     constexpr int TILE_H = 64 / TILE_W;
-    constexpr int WAVES = KSPLIT ? 1 : 4;  // tiles per workgroup along x
-    const int H = a.H, W = a.W, L = a.L;
+    const int H = a->H, W = a->W, L = a->L;
+    // Wave-uniform read-only inputs are read through the CONSTANT address space: in the persistent schedule the
+    // previous tile's stores and the queue atomic precede these loads in program order, so through a plain global
+    // pointer the compiler can no longer prove the memory unclobbered and turns every sample-table read of the
+    // sample loop into a VECTOR load (measured: the persistent march 3.5x slower, 0.257 vs 0.073 ms); constant-
+    // address-space loads of a uniform address are scalar loads by construction.  The data is written before the
+    // launch (host upload, prepass) and never during it.
+    typedef const __attribute__((address_space(4))) double *TablePtr;
+    typedef const __attribute__((address_space(4))) float *ConstF32Ptr;
+    typedef const __attribute__((address_space(4))) int *ConstI32Ptr;
+    const TablePtr tt = (TablePtr)(unsigned long long)a->t_table;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // sample range of this wave
-    const int chunk = KSPLIT ? (a.N + 3) >> 2 : a.N;
+    const int chunk = KSPLIT ? (a->N + 3) >> 2 : a->N;
     const int k_lo = KSPLIT ? wave * chunk : 0;
-    const int N = KSPLIT ? min(a.N, k_lo + chunk) : a.N;  // exclusive upper bound ("N" below)
+    const int N = KSPLIT ? min(a->N, k_lo + chunk) : a->N;  // exclusive upper bound ("N" below)
+#ifdef GCFR_COUNTERS
+    unsigned cnt[kCntUsed] = {};
+#endif
 
-    // 3-D grid: x = tile-quad column, y = tile row, z = (image, light) -- no integer divisions in the prologue,
-    // and the dispatch order (x fastest, z slowest) is image-major with row-major tiles.  An XCD-affine remap
-    // (all blocks of an image on one XCD) was measured 12 % SLOWER at B=8 -- one image per XCD makes the
-    // slowest image set the kernel time, and the CU L1 already serves the gathers -- so blocks stay round-robin.
-    const int qx = blockIdx.x, qy = blockIdx.y;
-    const int bl = a.bl_offset + (int)blockIdx.z;
     const int b = bl / L;
     const int l = bl - b * L;
     int r = qy * TILE_H + lane / TILE_W;
-    int c = (qx * WAVES + (KSPLIT ? 0 : wave)) * TILE_W + (lane % TILE_W);
+    int c = tx * TILE_W + (lane % TILE_W);
     const bool valid = (r < H) && (c < W);
     r = valid ? r : H - 1;
     c = valid ? c : W - 1;
@@ -630,11 +791,12 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
     const size_t P = (size_t)H * W;
     const int Wp = W + 1;
     const size_t Pq = (size_t)(H + 1) * Wp;
-    const __amdgpu_buffer_rsrc_t qr = make_rsrc(a.quad + (size_t)b * Pq, (int)(Pq * 16));
+    const __amdgpu_buffer_rsrc_t qr = make_rsrc(a->quad + (size_t)b * Pq, (int)(Pq * 16));
     const __amdgpu_buffer_rsrc_t mr =
-        make_rsrc(a.mask + (size_t)(a.mask_batch == 1 ? 0 : b) * P, (int)P);
+        make_rsrc(a->mask + (size_t)(a->mask_batch == 1 ? 0 : b) * P, (int)P);
 
-    const float Cx = a.light_pt[3 * bl + 0], Cy = a.light_pt[3 * bl + 1], Cz = a.light_pt[3 * bl + 2];
+    const ConstF32Ptr lp = (ConstF32Ptr)(unsigned long long)a->light_pt;
+    const float Cx = lp[3 * bl + 0], Cy = lp[3 * bl + 1], Cz = lp[3 * bl + 2];
     const Box box = image_box(H, W);
     const LightCase lc = classify_light(Cx, Cy, box);
     const float halfWf = W / 2.0f, halfHf = H / 2.0f;
@@ -642,7 +804,7 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
     const int halfWi = W / 2, halfHi = H / 2;
 
     const float x = (float)c - halfWf, y = halfHf - (float)r;
-    const float zb = a.depth[(size_t)b * P + (size_t)r * W + c];
+    const float zb = a->depth[(size_t)b * P + (size_t)r * W + c];
     float Ex, Ey;
     end_point(x, y, Cx, Cy, box, lc, Ex, Ey);
     const float dxf = Ex - x, dyf = Ey - y;
@@ -672,56 +834,13 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
     // the pruning / skipping machinery below reasons about an increasing, uniform sample table inside [0, 1]
     // (gcfr_sample_table with dt > 0, the reference's np.arange); anything else marches every sample, which is
     // always right
-    const bool t_increasing = (a.N >= 2) && (a.tflag[0] != 0);  // checked by the prepass (see its table check)
-    const bool use_zb = (a.zb != nullptr) && t_increasing;
-    int gz_lo_s = 0x7fffffff, gz_nhi_s = 0x7fffffff;  // image depth range {z_min, -z_max} (sortable ints)
-    int lane_last = a.N - 1;  // last sample of this lane that can be unmasked (mask bounding box), see below
+    const bool t_increasing = (a->N >= 2) && (((ConstI32Ptr)(unsigned long long)a->tflag)[0] != 0);  // checked by the prepass (see its table check)
+    const bool use_zb = (a->zb != nullptr) && t_increasing;
+    const int gz_lo_s = st.gz_lo_s, gz_nhi_s = st.gz_nhi_s;  // image depth range {z_min, -z_max} (sortable ints)
+    int lane_last = a->N - 1;  // last sample of this lane that can be unmasked (mask bounding box), see below
     if (t_increasing) {
-        // reduce the prepass' partial boxes (and depth ranges) of this image: 256 threads, one partial each per pass
-        __shared__ int sbb[4][6];
-        {
-            const int n_partials = (int)((P + 255) / 256);
-            const int4 *pb = (const int4 *)a.bbox + (size_t)(a.mask_batch == 1 ? 0 : b) * n_partials;
-            const int2 *pz = (const int2 *)a.zrange + (size_t)b * n_partials;
-            int4 m = make_int4(kBBoxInit, kBBoxInit, kBBoxInit, kBBoxInit);
-            int2 mz = make_int2(0x7fffffff, 0x7fffffff);
-            for (int j = threadIdx.x; j < n_partials; j += 256) {
-                const int4 v = pb[j];
-                m.x = min(m.x, v.x);
-                m.y = min(m.y, v.y);
-                m.z = min(m.z, v.z);
-                m.w = min(m.w, v.w);
-                if (use_zb) {
-                    const int2 vz = pz[j];
-                    mz.x = min(mz.x, vz.x);
-                    mz.y = min(mz.y, vz.y);
-                }
-            }
-            m.x = wave_min_i32(m.x);
-            m.y = wave_min_i32(m.y);
-            m.z = wave_min_i32(m.z);
-            m.w = wave_min_i32(m.w);
-            if (use_zb) {
-                mz.x = wave_min_i32(mz.x);
-                mz.y = wave_min_i32(mz.y);
-            }
-            if (lane == 0) {
-                sbb[threadIdx.x >> 6][0] = m.x;
-                sbb[threadIdx.x >> 6][1] = m.y;
-                sbb[threadIdx.x >> 6][2] = m.z;
-                sbb[threadIdx.x >> 6][3] = m.w;
-                sbb[threadIdx.x >> 6][4] = mz.x;
-                sbb[threadIdx.x >> 6][5] = mz.y;
-            }
-            __syncthreads();
-        }
-        auto red = [&](int q) {
-            return __builtin_amdgcn_readfirstlane(min(min(sbb[0][q], sbb[1][q]), min(sbb[2][q], sbb[3][q])));
-        };
-        const int r_min = red(0), c_min = red(1), r_max = -red(2), c_max = -red(3);
-        gz_lo_s = red(4);
-        gz_nhi_s = red(5);
-        int lane_lo = a.N, lane_hi = -1;  // empty
+        const int r_min = st.r_min, c_min = st.c_min, r_max = st.r_max, c_max = st.c_max;
+        int lane_lo = a->N, lane_hi = -1;  // empty
         if (r_min != kBBoxInit) {
             const float X0 = (float)c_min - halfWf - 0.51f, X1 = (float)c_max - halfWf + 0.51f;
             const float Y0 = halfHf - (float)r_max - 0.51f, Y1 = halfHf - (float)r_min + 0.51f;
@@ -745,12 +864,12 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
                 empty = empty || (y < Y0) || (y > Y1);
             }
             if (!empty && ta <= tb) {
-                const float t_first = (float)a.t_table[0];
-                const float inv_dt = (float)(a.N - 1) * __builtin_amdgcn_rcpf((float)a.t_table[a.N - 1] - t_first);
+                const float t_first = (float)tt[0];
+                const float inv_dt = (float)(a->N - 1) * __builtin_amdgcn_rcpf((float)tt[a->N - 1] - t_first);
                 const float ka = (ta - t_first) * inv_dt, kb = (tb - t_first) * inv_dt;
                 // clamp in float first: ta / tb may be +-3e38
-                lane_lo = (int)fminf(fmaxf(floorf(ka) - 1.0f, 0.0f), (float)a.N);
-                lane_hi = (int)fmaxf(fminf(ceilf(kb) + 1.0f, (float)(a.N - 1)), -1.0f);
+                lane_lo = (int)fminf(fmaxf(floorf(ka) - 1.0f, 0.0f), (float)a->N);
+                lane_hi = (int)fmaxf(fminf(ceilf(kb) + 1.0f, (float)(a->N - 1)), -1.0f);
             }
         }
         // readfirstlane: the reductions are wave-uniform by construction, but only an SGPR tells the
@@ -764,6 +883,9 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
         k_begin = nb;
         k_end = ne;
     }
+    GCFR_COUNT(kCntTiles, 1);
+    GCFR_COUNT(kCntGroupsNominal, (N - k_lo + DEPTH - 1) / DEPTH);
+    GCFR_COUNT(kCntSamplesInRange, k_end > k_begin ? k_end - k_begin : 0);
 
     // Depth-bound skip (exact).  For the sample point A = (s_k, z) of this ray,
     //     S_k >= Xx^2 + Xy^2 >= G^2,   G = n (z - zb) - BCz (BA_xy . u)/n,   u = BC_xy, n = |u|
@@ -780,17 +902,17 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
     // 0.2 %, so a skipped sample could not have been taken and the minimum, its index and the tie predecessor
     // are what the full march gives.
     bool zfits = false;
-    const int zls = use_zb ? __builtin_amdgcn_readfirstlane(zb_log2_stride(H, W, a.N, a.t_table, DEPTH, &zfits)) : 3;
+    const int zls = use_zb ? __builtin_amdgcn_readfirstlane(zb_log2_stride(H, W, a->N, tt, DEPTH, &zfits)) : 3;
     // With a checked table every sample lies on the segment pixel -> end point, i.e. inside the image, and the
     // stride was chosen so that a group's footprint fits the tile its lowest cell selects: no per-lane test.
     const bool zb_trusted = __builtin_amdgcn_readfirstlane((int)zfits) != 0;
     const int zntw = (W >> zls) + 1;
     const __amdgpu_buffer_rsrc_t zr =
-        make_rsrc(a.zb + (size_t)b * zb_max_tiles(H, W), zb_max_tiles(H, W) * (int)sizeof(float4));
+        make_rsrc(a->zb + (size_t)b * zb_max_tiles(H, W), zb_max_tiles(H, W) * (int)sizeof(float4));
     const float nrm = __builtin_sqrtf(BCx * BCx + BCy * BCy);
     const float c1 = BCz * ((dxf * BCx + dyf * BCy) / nrm);
     const float Qz = nrm * zb;
-    const float t_abs = fmaxf(fabsf((float)a.t_table[0]), fabsf((float)a.t_table[a.N - 1]));
+    const float t_abs = fmaxf(fabsf((float)tt[0]), fabsf((float)tt[a->N - 1]));
     float Kerr = __builtin_inff();  // never skips
     // Early termination (exact).  Once the ray is above max(image depth maximum, 0) by more than the running
     // minimum allows (same bound as above, with the image-wide zmax instead of a tile's) and is still rising
@@ -843,7 +965,7 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
     // records.  The skip is wave-uniform (ballot -> scalar branch) and exact; on face-shaped masks more
     // than half of all wave-steps take it (rays that have left the face, background tiles).
     auto sample_pos = [&](int k, double &sx, double &sy) {
-        const double t = a.t_table[k];  // wave-uniform -> s_load
+        const double t = tt[k];  // wave-uniform -> s_load
         sx = x64 + t * dx64;            // T8:472 / 480 (f64, mul and add rounded separately)
         sy = y64 + t * dy64;
     };
@@ -886,6 +1008,7 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
     // latency on every skipped group.
     auto group = [&](int k0, const Prefetched &cur, Prefetched &nxt, bool check_finished) -> bool {
         prefetch(k0 + DEPTH, nxt);
+        GCFR_COUNT(kCntGroupsVisited, 1);
         bool none = true;
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
@@ -894,7 +1017,8 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
         }
         bool run_body = __builtin_amdgcn_ballot_w64(!none) != 0ull;
         if (run_body && use_zb) {
-            const float ta = (float)a.t_table[k0], tb = (float)a.t_table[clampk(k0 + DEPTH - 1)];
+            GCFR_COUNT(kCntBoundTests, 1);
+            const float ta = (float)tt[k0], tb = (float)tt[clampk(k0 + DEPTH - 1)];
             const float Ta = c1 * ta, Tb = c1 * tb;
             const float Tlo = fminf(Ta, Tb), Thi = fmaxf(Ta, Tb);
             // surface band at the sample position s(t) = (x, y) + t d:  z in A0 + t A1 + [c_lo, c_hi], so
@@ -914,6 +1038,12 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
         // k-split variant, whose launches are tiny and latency-bound
         constexpr int GCFR_BODY_CHUNK = KSPLIT ? DEPTH : 1;
         if (run_body) {
+          GCFR_COUNT(kCntBodies, 1);
+#ifdef GCFR_COUNTERS
+#pragma unroll
+          for (int j = 0; j < DEPTH; ++j)
+              cnt[kCntLaneSamples] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(cur.m[j] != 0));
+#endif
 #pragma unroll
           for (int h0 = 0; h0 < DEPTH; h0 += GCFR_BODY_CHUNK) {
             // phase 1: positions and texel gathers for the whole group (all in flight together)
@@ -963,12 +1093,13 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
           }
         }
         if (check_finished && use_zb && k0 + DEPTH < k_end) {  // early termination, see Dcap
-            const float tn = (float)a.t_table[k0 + DEPTH];
+            const float tn = (float)tt[k0 + DEPTH];
             const float gd = __builtin_fmaf(c1, tn, -Dcap);
             const bool finished = ((gd > 0.0f) && (gd * gd * 0.998f > bestS) && (bestS < safeS)) ||
                                   (lane_last < k0 + DEPTH);
             if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) {
                 any_masked |= (lane_last < k0 + DEPTH);
+                GCFR_COUNT(kCntEarlyExit, 1);
                 return false;
             }
         }
@@ -1022,6 +1153,7 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
     if (WANT_ARGMIN) {
         const bool tie = (prevk >= 0) && (__builtin_sqrtf(prevS) / den == d);
         if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare; wave-uniform branch
+            GCFR_COUNT(kCntTieRemarch, 1);
             RayConst rc;
             rc.H = H;
             rc.W = W;
@@ -1039,7 +1171,7 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
             rc.y64 = y64;
             rc.dx64 = dx64;
             rc.dy64 = dy64;
-            const int first = first_tied_sample(rc, a.t_table, make_rsrc(a.depth + (size_t)b * P, (int)(P * 4)), mr,
+            const int first = first_tied_sample(rc, a->t_table, make_rsrc(a->depth + (size_t)b * P, (int)(P * 4)), mr,
                                                 tie, prevk, den, d);
             besti = tie ? first : besti;
         }
@@ -1050,53 +1182,71 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
     }
     if (!finite_ray)
         d = __builtin_nanf("");
-    const bool inside = (Cx >= a.bx_lo) && (Cx <= a.bx_hi) && (Cy >= a.by_lo) && (Cy <= a.by_hi);
+    const EpiPtr ep = launder((EpiPtr)&a->epi);
+    const bool inside = (Cx >= ep->bx_lo) && (Cx <= ep->bx_hi) && (Cy >= ep->by_lo) && (Cy <= ep->by_hi);
     if (inside)
-        d = d + a.bonus;
+        d = d + ep->bonus;
     if (valid) {
         const size_t pix = (size_t)r * W + c;
         const size_t o = (size_t)bl * P + pix;
-        a.min_dist[o] = d;
+        ep->min_dist[o] = d;
         if (WANT_ARGMIN)
-            a.argmin[o] = besti;
+            ep->argmin[o] = besti;
         if (FUSE_SHADE) {
             float n[3];
-            if (a.normals) {
-                const float *nrm = a.normals + (size_t)b * 3 * P + pix;
+            const float *normals = ep->normals;
+            if (normals) {
+                const float *nrm = normals + (size_t)b * 3 * P + pix;
                 n[0] = nrm[0];
                 n[1] = nrm[P];
                 n[2] = nrm[2 * P];
             } else {  // normals fused: 3x3 depth stencil, same device function as normals_fwd_kernel
-                unit_normal(a.nrm, a.depth + (size_t)b * P, r, c, n);
-                if (a.normals_out && l == 0) {
-                    float *no = a.normals_out + (size_t)b * 3 * P + pix;
+                NormalsArgs na = {};  // (field by field: the source lives in the constant address space)
+                na.H = H;
+                na.W = W;
+                na.fx = ep->nrm.fx;
+                na.fy = ep->nrm.fy;
+                na.cx = ep->nrm.cx;
+                na.cy = ep->nrm.cy;
+                na.z_offset = ep->nrm.z_offset;
+                na.negate_y = ep->nrm.negate_y;
+                unit_normal(na, a->depth + (size_t)b * P, r, c, n);
+                float *normals_out = ep->normals_out;
+                if (normals_out && l == 0) {
+                    float *no = normals_out + (size_t)b * 3 * P + pix;
                     no[0] = n[0];
                     no[P] = n[1];
                     no[2 * P] = n[2];
                 }
             }
-            const Shaded sh = shade_pixel(x, y, zb, n[0], n[1], n[2], Cx, Cy, Cz, a.ambient[bl], a.intensity, d);
-            if (a.shadow_w)
-                a.shadow_w[o] = sh.w;
-            if (a.full)
-                a.full[o] = sh.full;
-            if (a.final_shading)
-                a.final_shading[o] = sh.fin;
-            const float *alb = a.albedo + (size_t)b * 3 * P + pix;
-            float *ren = a.rendered + (size_t)bl * 3 * P + pix;
+            const Shaded sh = shade_pixel(x, y, zb, n[0], n[1], n[2], Cx, Cy, Cz, ep->ambient[bl], ep->intensity, d);
+            float *shadow_w = ep->shadow_w, *full = ep->full, *final_shading = ep->final_shading;
+            if (shadow_w)
+                shadow_w[o] = sh.w;
+            if (full)
+                full[o] = sh.full;
+            if (final_shading)
+                final_shading[o] = sh.fin;
+            const float *alb = ep->albedo + (size_t)b * 3 * P + pix;
+            float *ren = ep->rendered + (size_t)bl * 3 * P + pix;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch)  // T8:519-522
                 ren[ch * P] = alb[ch * P] * sh.fin;
         }
     }
+#ifdef GCFR_COUNTERS
+    if (a->counters && lane == 0)
+#pragma unroll
+        for (int i = 0; i < kCntUsed; ++i)
+            atomicAdd(a->counters + i, (unsigned long long)cnt[i]);
+#endif
 }
 
-// The two __global__ entry points of the march.  Occupancy is forced (the register allocator would settle at
+// The __global__ entry points of the march.  Occupancy is forced (the register allocator would settle at
 // 95-99 VGPRs = 5 waves/SIMD): with the group body evaluated one sample at a time (GCFR_BODY_CHUNK = 1) the
-// inference variant fits 80 VGPRs with ~7 spilled dwords outside the sample loop -> six waves per SIMD, which beats
-// the 119-VGPR / 4-wave build that kept four gathers in flight per body by 8 % at B=8 on four streams and by 11 %
-// at B=64.  The argmin variant carries three more loop registers: six waves cost it 60-68 B of scratch and 35 %,
-// five waves (96 VGPRs, 16 B) are its optimum.  7 or 8 waves: spills of 76 / 104 B, -30 ... -45 %
+// inference variant fits six waves per SIMD, which beats the 119-VGPR / 4-wave build that kept four gathers in
+// flight per body by 8 % at B=8 on four streams and by 11 % at B=64.  The argmin variant carries three more loop
+// registers and is best at five waves.  7 or 8 waves spill 76 / 104 B and lose 30 ... 45 %
 // (tools/build_variant.sh + tools/ab.sh, tools/exp_grazing.py).
 #ifndef GCFR_MARCH_WAVES_PER_EU
 #define GCFR_MARCH_WAVES_PER_EU 6
@@ -1104,23 +1254,154 @@ __device__ __forceinline__ void march_tile(ShadowQuadArgs a)
 #ifndef GCFR_MARCH_ARGMIN_WAVES_PER_EU
 #define GCFR_MARCH_ARGMIN_WAVES_PER_EU 5
 #endif
-template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
-__global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(GCFR_MARCH_WAVES_PER_EU, GCFR_MARCH_WAVES_PER_EU))) void shadow_fwd_quad_kernel(ShadowQuadArgs a)
-{
-    march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, false>(a);
-}
-template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
-__global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(GCFR_MARCH_ARGMIN_WAVES_PER_EU, GCFR_MARCH_ARGMIN_WAVES_PER_EU))) void shadow_fwd_quad_argmin_kernel(ShadowQuadArgs a)
-{
-    march_tile<TILE_W, EVEN_HALF, true, DEPTH, FUSE_SHADE, false>(a);
-}
-// k-split (tiny launches, one or two images): latency-bound, four gathers in flight per body, occupancy as it falls
+
+// Grid schedule: one workgroup = four horizontally adjacent tiles (one per wave), 3-D grid x = tile-quad column,
+// y = tile row, z = (image, light) -- no integer divisions, dispatch order image-major with row-major tiles.
 template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE>
-__global__ __launch_bounds__(256) void shadow_fwd_quad_ksplit_kernel(ShadowQuadArgs a)
+__device__ __forceinline__ void march_grid(ArgPtr a)
 {
-    march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, true>(a);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tx = (int)blockIdx.x * 4 + wave;
+    if (tx >= a->tiles_x)
+        return;  // (the waves of a workgroup never synchronise)
+    const int bl = a->bl_offset + (int)blockIdx.z;
+    const bool want_z = (a->zb != nullptr);
+    const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, want_z);
+    march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, false>(a, bl, (int)blockIdx.y, tx, st);
+}
+
+// Queue order of the persistent / strided schedules: tile index t -> (image-light pair, tile row, tile column).
+//   tile_order 0: image-major, row-major -- consecutive indices are horizontal neighbours;
+//   tile_order 1: the same with each image's tile rows centre-first;
+//   tile_order 2: centre rows first across ALL images: the heavy face-centre tiles of every image start first and
+//                 the nearly free border rows (their rays are pruned by the mask's bounding box) fill the tail;
+//   tile_order 3: image-major, row-major, but image i's tiles are rotated by i * 0.38 of an image.  The dispatcher
+//                 places consecutive workgroups on consecutive CUs, so with order 0 a CU's resident workgroups are
+//                 the SAME tile position of six different images -- six heavy face-centre waves on one SIMD, six
+//                 nearly free border waves on another.  The rotation gives every SIMD a mix of positions.
+__device__ __forceinline__ void decode_tile(ArgPtr a, int t, int &bl, int &qy, int &tx)
+{
+    const int tiles_x = a->tiles_x, tiles_y = a->tiles_y;
+    int k;
+    if (a->tile_order == 2) {  // t = (k * BL + bl) * tiles_x + tx
+        const int BL = a->B * a->L;
+        const int row = t / tiles_x;
+        tx = t - row * tiles_x;
+        k = row / BL;
+        bl = row - k * BL;
+    } else {                   // t = (bl * tiles_y + k) * tiles_x + tx
+        const int per_image = tiles_x * tiles_y;
+        bl = t / per_image;
+        const int rem = t - bl * per_image;
+        k = rem / tiles_x;
+        tx = rem - k * tiles_x;
+    }
+    if (a->tile_order == 3) {  // rotate each image's tiles by a different amount (whole 4-tile groups)
+        const int per_image = tiles_x * tiles_y;
+        const int rot = ((int)((unsigned)per_image * 25033u >> 16) & ~3) | 4;  // ~0.382 of the image, a multiple of 4
+        int p = k * tiles_x + tx + (int)(((long long)bl * rot) % per_image);
+        p = p >= per_image ? p - per_image : p;
+        k = p / tiles_x;
+        tx = p - k * tiles_x;
+    }
+    qy = k;
+    if (a->tile_order == 1 || a->tile_order == 2) {  // centre rows first: mid-1, mid, mid-2, mid+1, ...
+        const int mid = (tiles_y + 1) >> 1, j = k >> 1;
+        qy = (k & 1) ? mid + j : mid - 1 - j;
+    }
+}
+
+// Persistent schedules: the launch is exactly as many waves as the chip holds at the forced occupancy and every
+// wave marches several tiles, so one launch keeps every SIMD busy to the end -- round 1's grid of 8192 one-tile
+// waves for 6144 slots ran 1.33 rounds with a one-third-full tail and needed three more launches in flight on other
+// streams to fill it.  Two ways to hand out the tiles:
+//   DYNAMIC = false  strided: wave g marches tiles g, g + G, g + 2G, ... (G = waves in the launch).  In a
+//                    heavy-first queue order every SIMD gets one tile from each band of the cost distribution, which
+//                    balances the SIMDs statically, with no atomics;
+//   DYNAMIC = true   tile queue: the first tile is the wave's own index, every further one comes from an atomic
+//                    counter (started at G by the prepass... see shadow_fwd_impl).  Same-address device-scope
+//                    atomics complete at ~9 ns each on MI355X (measured: 8192 + 6144 of them cost the march
+//                    0.12 ms when every wave fetched its FIRST tile that way), so the counter is only touched for
+//                    the second and later tiles and polled with a plain load first (no atomic to learn "empty").
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool DYNAMIC>
+__device__ __forceinline__ void march_persistent(ArgPtr a)
+{
+    const int lane = threadIdx.x & 63;
+    const int gwave = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n_waves = (int)gridDim.x * 4;
+    int t = gwave;
+    for (;;) {
+        a = launder(a);  // nothing loaded from the arguments stays live across tiles
+        if (t >= a->total_tiles)
+            break;
+        int bl, qy, tx;
+        decode_tile(a, t, bl, qy, tx);
+        const ImageStats st = reduce_image_stats(a, bl / a->L, lane, a->zb != nullptr);
+        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, false>(a, bl, qy, tx, st);
+        if (DYNAMIC) {
+            int *queue = a->tflag + kQueueSlot;  // counts tiles handed out beyond the first n_waves
+            int nxt = a->total_tiles;
+            if (lane == 0) {
+                if (__hip_atomic_load(queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + n_waves < a->total_tiles)
+                    nxt = atomicAdd(queue, 1) + n_waves;
+            }
+            t = __builtin_amdgcn_readfirstlane(nxt);
+        } else {
+            t += n_waves;
+        }
+    }
+}
+
+// 1-D grid in queue order: one workgroup = four consecutive tiles of the queue, handed to the CUs by the hardware
+// dispatcher as slots free up (dynamic balancing for free, heavy tiles first with tile_order 2).
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE>
+__device__ __forceinline__ void march_grid_ordered(ArgPtr a)
+{
+    const int t = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (t >= a->total_tiles)
+        return;
+    int bl, qy, tx;
+    decode_tile(a, t, bl, qy, tx);
+    const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, a->zb != nullptr);
+    march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, false>(a, bl, qy, tx, st);
+}
+
+enum { kSchedGrid = 0, kSchedQueue = 1, kSchedStrided = 2, kSchedGridOrdered = 3 };
+
+template <int SCHED, int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE>
+__device__ __forceinline__ void march_dispatch()
+{
+    if (SCHED == kSchedQueue)
+        march_persistent<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, true>(kernel_args());
+    else if (SCHED == kSchedStrided)
+        march_persistent<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, false>(kernel_args());
+    else if (SCHED == kSchedGridOrdered)
+        march_grid_ordered<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE>(kernel_args());
+    else
+        march_grid<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE>(kernel_args());
+}
+
+template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE, int SCHED>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(GCFR_MARCH_WAVES_PER_EU, GCFR_MARCH_WAVES_PER_EU))) void shadow_fwd_quad_kernel(ShadowQuadArgs)
+{
+    march_dispatch<SCHED, TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE>();
+}
+template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE, int SCHED>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(GCFR_MARCH_ARGMIN_WAVES_PER_EU, GCFR_MARCH_ARGMIN_WAVES_PER_EU))) void shadow_fwd_quad_argmin_kernel(ShadowQuadArgs)
+{
+    march_dispatch<SCHED, TILE_W, EVEN_HALF, true, DEPTH, FUSE_SHADE>();
+}
+// k-split (tiny launches, one or two images): latency-bound, four gathers in flight per body, occupancy as it falls;
+// grid x = tile column, y = tile row, z = (image, light)
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE>
+__global__ __launch_bounds__(256) void shadow_fwd_quad_ksplit_kernel(ShadowQuadArgs)
+{
+    const ArgPtr a = kernel_args();
+    const int bl = a->bl_offset + (int)blockIdx.z;
+    const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, a->zb != nullptr);
+    march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, true>(a, bl, (int)blockIdx.y, (int)blockIdx.x, st);
 }
 
 }  // namespace gcfr
@@ -1135,7 +1416,14 @@ static inline int launch_status()
     return hipGetLastError() == hipSuccess ? GCFR_OK : GCFR_ERR_LAUNCH;
 }
 
-extern "C" const char *gcfr_version(void) { return "gcfr-hip 0.1.0 gfx950"; }
+extern "C" const char *gcfr_version(void)
+{
+#ifdef GCFR_COUNTERS
+    return "gcfr-hip 0.2.0 gfx950 +counters";
+#else
+    return "gcfr-hip 0.2.0 gfx950";
+#endif
+}
 
 extern "C" int gcfr_sample_table(double t0, double dt, int32_t n, double *out_host)
 {
@@ -1159,127 +1447,167 @@ extern "C" int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_
     return launch_status();
 }
 
-// Process-wide tuning knobs (experiments / A-B runs only; defaults are the shipped configuration).
-// Measured on MI355X, B=8 x 256^2 x 160 (gpurun_out/ab_r01.txt -> DESIGN.md section 4.1):
-//   tile 2x32 > 4x16 > 8x8 > 1x64 without the depth-bound skip, 8x8 >= 4x16 > 2x32 > 1x64 with it;  an
-//   XCD-affine block map is 12 % slower;  f64 texels (32-B gathers) are 25 % slower (vector-memory bound).
-static int g_tile_w = 0;   // pixels per tile row: 8, 16, 32 or 64 (tile = 64/tile_w rows); 0 = auto (below)
-static int g_depth = 4;    // samples per group (skip granularity / gathers in flight): 1, 2 or 4
-static int g_ksplit = -1;  // sample-range split over the 4 waves of a workgroup: 0 off, 1 on, -1 auto
-static int g_zbound = 1;   // depth-bound group skip (exact): 1 on, 0 off
+// Per-call knobs, resolved from gcfr_options (NULL = defaults).  Measured on MI355X, B=8 x 256^2 x 160
+// (profiles/): tile 2x32 > 4x16 > 8x8 > 1x64 without the depth-bound skip,
+// 8x8 >= 4x16 > 2x32 > 1x64 with it; an XCD-affine block map is 12 % slower; f64 texels (32-B gathers) 25 % slower.
+struct Knobs {
+    int tile_w = 0;      // pixels per tile row: 8, 16, 32 or 64 (tile = 64/tile_w rows); 0 = auto
+    int group = 4;       // samples per group (skip granularity / gathers in flight): 1, 2 or 4
+    int ksplit = -1;     // sample-range split over the 4 waves of a workgroup: 0 off, 1 on, -1 auto
+    int zbound = 1;      // depth-bound group skip (exact): 1 on, 0 off
+    int schedule = -1;   // 0 grid, 1 persistent tile queue, -1 auto
+    int tile_order = -1; // persistent schedule: 0, 1, 2, -1 auto
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    unsigned long long *counters = nullptr;
+};
 
-extern "C" int gcfr_tune(int32_t key, int32_t value)
+static int resolve_options(const gcfr_options *opt, Knobs &k)
 {
-    switch (key) {
-    case 0:
-        if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64)
-            return GCFR_ERR_INVALID_ARGUMENT;
-        g_tile_w = value;
+    if (!opt)
         return GCFR_OK;
-    case 1:
-        if (value != 1 && value != 2 && value != 4)
-            return GCFR_ERR_INVALID_ARGUMENT;
-        g_depth = value;
-        return GCFR_OK;
-    case 2:
-        if (value < -1 || value > 1)
-            return GCFR_ERR_INVALID_ARGUMENT;
-        g_ksplit = value;
-        return GCFR_OK;
-    case 3:
-        if (value != 0 && value != 1)
-            return GCFR_ERR_INVALID_ARGUMENT;
-        g_zbound = value;
-        return GCFR_OK;
-    default:
+    if (opt->struct_size != sizeof(gcfr_options))
         return GCFR_ERR_INVALID_ARGUMENT;
-    }
+    const int tw = opt->tile_w, g = opt->group;
+    if ((tw != 0 && tw != 8 && tw != 16 && tw != 32 && tw != 64) || (g != 0 && g != 1 && g != 2 && g != 4) ||
+        opt->ksplit < -1 || opt->ksplit > 1 || opt->depth_bound_skip < -1 || opt->depth_bound_skip > 1 ||
+        opt->schedule < -1 || opt->schedule > 3 || opt->tile_order < -1 || opt->tile_order > 3)
+        return GCFR_ERR_INVALID_ARGUMENT;
+    k.tile_w = tw;
+    k.group = g ? g : 4;
+    k.ksplit = opt->ksplit;
+    k.zbound = opt->depth_bound_skip < 0 ? 1 : opt->depth_bound_skip;
+    k.schedule = opt->schedule;
+    k.tile_order = opt->tile_order;
+    k.ev_start = (hipEvent_t)opt->event_start;
+    k.ev_stop = (hipEvent_t)opt->event_stop;
+    k.counters = (unsigned long long *)opt->counters;
+    return GCFR_OK;
 }
 
+extern "C" void gcfr_options_default(gcfr_options *opt)
+{
+    if (!opt)
+        return;
+    *opt = gcfr_options{};
+    opt->struct_size = (uint32_t)sizeof(gcfr_options);
+    opt->ksplit = opt->depth_bound_skip = opt->schedule = opt->tile_order = -1;
+}
+
+// workspace layout: [quad texels | partial boxes | depth-bounds records | partial depth ranges | tflag, queue]
 extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
 {
     if (B <= 0 || H <= 0 || W <= 0)
         return 0;
-    const size_t n_partials = ((size_t)H * W + 255) / 256;
-    return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4) + (size_t)B * n_partials * 4 * sizeof(int) +
-           (size_t)B * (size_t)zb_max_tiles(H, W) * sizeof(float4) + (size_t)B * n_partials * 2 * sizeof(int) + 16;
+    const size_t n_stat = (size_t)n_stat_chunks(H, W);
+    return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4) + (size_t)B * n_stat * 4 * sizeof(int) +
+           (size_t)B * (size_t)zb_max_tiles(H, W) * sizeof(float4) + (size_t)B * n_stat * 2 * sizeof(int) +
+           (kQueueSlot + 1) * sizeof(int) + 12;
 }
 
-// Optional profiling hook: events recorded around the dominant (march) kernel of the next launches.
-static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-
-extern "C" int gcfr_profile_events(void *start, void *stop)
+// Number of compute units of the current device (immutable hardware fact; queried once per device and process).
+static int device_cu_count()
 {
-    g_ev_start = (hipEvent_t)start;
-    g_ev_stop = (hipEvent_t)stop;
-    return GCFR_OK;
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 
-template <int TILE_W, int DEPTH, bool FUSE, bool KSPLIT>
-static void launch_quad5(const ShadowQuadArgs &a, bool even_half, bool want_argmin, dim3 grid, hipStream_t st)
+enum Schedule { kGrid = kSchedGrid, kQueue = kSchedQueue, kStrided = kSchedStrided, kGridOrdered = kSchedGridOrdered, kKSplit };
+
+template <int TILE_W, int DEPTH, bool FUSE>
+static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argmin, Schedule sch, dim3 grid,
+                         hipStream_t st)
 {
-#define GCFR_LAUNCH(KERNEL, ...) hipLaunchKernelGGL((KERNEL<TILE_W, __VA_ARGS__, DEPTH, FUSE>), grid, dim3(256), 0, st, a)
-    if (KSPLIT) {
+#define GCFR_LAUNCH(KERNEL, ...) hipLaunchKernelGGL((KERNEL<TILE_W, __VA_ARGS__>), grid, dim3(256), 0, st, a)
+#define GCFR_LAUNCH_SCHED(SCHED)                                                    \
+    do {                                                                            \
+        if (even_half) {                                                            \
+            if (want_argmin)                                                        \
+                GCFR_LAUNCH(shadow_fwd_quad_argmin_kernel, true, DEPTH, FUSE, SCHED);  \
+            else                                                                    \
+                GCFR_LAUNCH(shadow_fwd_quad_kernel, true, DEPTH, FUSE, SCHED);      \
+        } else {                                                                    \
+            if (want_argmin)                                                        \
+                GCFR_LAUNCH(shadow_fwd_quad_argmin_kernel, false, DEPTH, FUSE, SCHED); \
+            else                                                                    \
+                GCFR_LAUNCH(shadow_fwd_quad_kernel, false, DEPTH, FUSE, SCHED);     \
+        }                                                                           \
+    } while (0)
+    if (sch == kKSplit) {
         if (even_half) {
             if (want_argmin)
-                GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, true, true);
+                GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, true, true, DEPTH, FUSE);
             else
-                GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, true, false);
+                GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, true, false, DEPTH, FUSE);
         } else {
             if (want_argmin)
-                GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, false, true);
+                GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, false, true, DEPTH, FUSE);
             else
-                GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, false, false);
+                GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, false, false, DEPTH, FUSE);
         }
-    } else if (even_half) {
-        if (want_argmin)
-            GCFR_LAUNCH(shadow_fwd_quad_argmin_kernel, true);
-        else
-            GCFR_LAUNCH(shadow_fwd_quad_kernel, true);
+    } else if (sch == kQueue) {
+        GCFR_LAUNCH_SCHED(kSchedQueue);
+    } else if (sch == kStrided) {
+        GCFR_LAUNCH_SCHED(kSchedStrided);
+    } else if (sch == kGridOrdered) {
+        GCFR_LAUNCH_SCHED(kSchedGridOrdered);
     } else {
-        if (want_argmin)
-            GCFR_LAUNCH(shadow_fwd_quad_argmin_kernel, false);
-        else
-            GCFR_LAUNCH(shadow_fwd_quad_kernel, false);
+        GCFR_LAUNCH_SCHED(kSchedGrid);
     }
+#undef GCFR_LAUNCH_SCHED
 #undef GCFR_LAUNCH
 }
 
-template <int TILE_W, int DEPTH, bool FUSE>
-static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argmin, dim3 grid, hipStream_t st)
-{
-    if (a.ksplit)
-        launch_quad5<TILE_W, DEPTH, FUSE, true>(a, even_half, want_argmin, grid, st);
-    else
-        launch_quad5<TILE_W, DEPTH, FUSE, false>(a, even_half, want_argmin, grid, st);
-}
-
 template <int TILE_W, int DEPTH>
-static void launch_quad3(const ShadowQuadArgs &a, bool even_half, bool want_argmin, dim3 grid, hipStream_t st)
+static void launch_quad3(const ShadowQuadArgs &a, bool even_half, bool want_argmin, Schedule sch, dim3 grid,
+                         hipStream_t st)
 {
-    if (a.rendered)
-        launch_quad4<TILE_W, DEPTH, true>(a, even_half, want_argmin, grid, st);
+    if (a.epi.rendered)
+        launch_quad4<TILE_W, DEPTH, true>(a, even_half, want_argmin, sch, grid, st);
     else
-        launch_quad4<TILE_W, DEPTH, false>(a, even_half, want_argmin, grid, st);
+        launch_quad4<TILE_W, DEPTH, false>(a, even_half, want_argmin, sch, grid, st);
 }
 
 template <int TILE_W>
-static void launch_quad(ShadowQuadArgs a, bool even_half, bool want_argmin, int total_bl, hipStream_t st)
+static void launch_quad(ShadowQuadArgs a, bool even_half, bool want_argmin, int total_bl, Schedule sch,
+                        const Knobs &kn, hipStream_t st)
 {
-    if (g_ev_start)
-        (void)hipEventRecord(g_ev_start, st);
-    for (int z0 = 0; z0 < total_bl; z0 += 65535) {  // grid z is limited to 65535 (image, light) pairs per launch
-        a.bl_offset = z0;
-        const dim3 grid((unsigned)a.quads_x, (unsigned)a.quads_y, (unsigned)((total_bl - z0) < 65535 ? (total_bl - z0) : 65535));
-        if (g_depth == 1)
-            launch_quad3<TILE_W, 1>(a, even_half, want_argmin, grid, st);
-        else if (g_depth == 2)
-            launch_quad3<TILE_W, 2>(a, even_half, want_argmin, grid, st);
+    if (kn.ev_start)
+        (void)hipEventRecord(kn.ev_start, st);
+    auto one = [&](dim3 grid) {
+        if (kn.group == 1)
+            launch_quad3<TILE_W, 1>(a, even_half, want_argmin, sch, grid, st);
+        else if (kn.group == 2)
+            launch_quad3<TILE_W, 2>(a, even_half, want_argmin, sch, grid, st);
         else
-            launch_quad3<TILE_W, 4>(a, even_half, want_argmin, grid, st);
+            launch_quad3<TILE_W, 4>(a, even_half, want_argmin, sch, grid, st);
+    };
+    if (sch == kQueue || sch == kStrided) {
+        // exactly the waves the chip holds at the kernels' forced occupancy (one 4-wave workgroup = one wave per SIMD
+        // of a CU), fewer if there are fewer tiles
+        const int occ = want_argmin ? GCFR_MARCH_ARGMIN_WAVES_PER_EU : GCFR_MARCH_WAVES_PER_EU;
+        const long long resident = (long long)device_cu_count() * occ;
+        const long long need = ((long long)a.total_tiles + 3) / 4;
+        one(dim3((unsigned)(need < resident ? need : resident)));
+    } else if (sch == kGridOrdered) {
+        one(dim3((unsigned)(((long long)a.total_tiles + 3) / 4)));
+    } else {
+        const unsigned gx = sch == kKSplit ? (unsigned)a.tiles_x : (unsigned)((a.tiles_x + 3) / 4);
+        for (int z0 = 0; z0 < total_bl; z0 += 65535) {  // grid z is limited to 65535 (image, light) pairs per launch
+            a.bl_offset = z0;
+            one(dim3(gx, (unsigned)a.tiles_y, (unsigned)((total_bl - z0) < 65535 ? (total_bl - z0) : 65535)));
+        }
     }
-    if (g_ev_stop)
-        (void)hipEventRecord(g_ev_stop, st);
+    if (kn.ev_stop)
+        (void)hipEventRecord(kn.ev_stop, st);
 }
 
 struct FusedShade {  // operands of the fused shading epilogue; rendered == nullptr: march only
@@ -1295,7 +1623,7 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
                            const float *light_pt, int32_t B, int32_t L, int32_t H, int32_t W, int32_t N,
                            const double *t_table, float bonus, const float *bonus_box, float *min_dist,
                            int32_t *argmin, void *workspace, size_t workspace_bytes, void *stream,
-                           const FusedShade &fs)
+                           const FusedShade &fs, const gcfr_options *opt)
 {
     if (!depth || !mask_u8 || !light_pt || !t_table || !min_dist)
         return GCFR_ERR_INVALID_ARGUMENT;
@@ -1306,16 +1634,20 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         return GCFR_ERR_INVALID_ARGUMENT;
     if (workspace && (workspace_bytes < gcfr_shadow_workspace_bytes(B, H, W) || ((uintptr_t)workspace & 15u)))
         return GCFR_ERR_INVALID_ARGUMENT;  // (float4 records: 16-byte alignment)
+    Knobs kn;
+    if (resolve_options(opt, kn) != GCFR_OK)
+        return GCFR_ERR_INVALID_ARGUMENT;
 
-    // auto tile shape (measured, gpurun_out/ab logs -> DESIGN.md 4.1): with the depth-bound skip compact tiles win
+    // auto tile shape (measured): with the depth-bound skip compact tiles win
     // (the lanes of a wave agree more often): 8x8 up to 256 px wide, 16x4 above; without it 32x2 streams best.
-    const int tile_auto = (g_zbound && N >= 2) ? (W <= 256 ? 8 : 16) : 32;
-    const int TILE_W = workspace ? (g_tile_w ? g_tile_w : tile_auto) : 16, TILE_H = 64 / TILE_W, WAVES = 4;
-    const int tiles_x = (W + TILE_W - 1) / TILE_W;
+    const int tile_auto = (kn.zbound && N >= 2) ? (W <= 256 ? 8 : 16) : 32;
+    const int TILE_W = workspace ? (kn.tile_w ? kn.tile_w : tile_auto) : 16, TILE_H = 64 / TILE_W, WAVES = 4;
+    const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
     const int quads_x = (tiles_x + WAVES - 1) / WAVES;
-    const int quads_per_image = quads_x * ((H + TILE_H - 1) / TILE_H);
+    const int quads_per_image = quads_x * tiles_y;
     const long long blocks = (long long)B * L * quads_per_image;
-    if (blocks > 0x7fffffffLL)
+    const long long tiles_total = (long long)B * L * tiles_x * tiles_y;
+    if (blocks > 0x7fffffffLL || tiles_total > 0x7fffffffLL || (long long)B * L > 0x7fffffffLL / 4)
         return GCFR_ERR_INVALID_ARGUMENT;
     float bx[4] = {0.0f, -1.0f, 0.0f, -1.0f};
     if (bonus_box)
@@ -1324,21 +1656,21 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
     hipStream_t st = (hipStream_t)stream;
 
     if (workspace) {
-        // prepass: 2x2 neighbourhood grid (see shadow_fwd_quad_kernel), then the march
+        // prepass (2x2 neighbourhood grid, statistics, depth bounds: see build_quad_kernel), then the march
         const int texels = (H + 1) * (W + 1);
+        const size_t n_stat = (size_t)n_stat_chunks(H, W);
         int *bbox = (int *)((char *)workspace + (size_t)B * texels * sizeof(float4));
-        const size_t n_partials = ((size_t)H * W + 255) / 256;
-        float4 *zb = (float4 *)((char *)bbox + (size_t)B * n_partials * 4 * sizeof(int));
-        int *zrange = (int *)(zb + (size_t)B * zb_max_tiles(H, W));  // (B, n_partials, 2)
-        int *tflag = zrange + (size_t)B * n_partials * 2;
-        const bool use_zb = g_zbound && N >= 2;
+        float4 *zb = (float4 *)((char *)bbox + (size_t)B * n_stat * 4 * sizeof(int));
+        int *zrange = (int *)(zb + (size_t)B * zb_max_tiles(H, W));  // (B, n_stat, 2)
+        int *tflag = zrange + (size_t)B * n_stat * 2;                 // [0] table flag, [1] tile queue
+        const bool use_zb = kn.zbound && N >= 2;
         const int quad_blocks = (texels + 255) / 256;
         const int zb_blocks = use_zb ? (zb_max_tiles(H, W) + 3) / 4 : 0;  // sized for the finest stride
-        hipLaunchKernelGGL(build_quad_kernel, dim3(quad_blocks + zb_blocks, B), dim3(256), 0, st, depth,
-                           (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox,
-                           use_zb ? zrange : (int *)nullptr, zb, quad_blocks, N, t_table,
-                           g_depth == 1 || g_depth == 2 ? g_depth : 4, tflag);
-        ShadowQuadArgs a;
+        const int vec_ok = ((W & 15) == 0) && (((uintptr_t)depth & 15u) == 0) && (((uintptr_t)mask_u8 & 15u) == 0);
+        hipLaunchKernelGGL(build_quad_kernel, dim3(zb_blocks + (int)n_stat + quad_blocks, B), dim3(256), 0, st, depth,
+                           (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox, zrange, zb, zb_blocks,
+                           (int)n_stat, use_zb ? 1 : 0, vec_ok, N, t_table, kn.group, tflag);
+        ShadowQuadArgs a = {};
         a.zb = use_zb ? zb : nullptr;
         a.zrange = zrange;
         a.tflag = tflag;
@@ -1348,56 +1680,57 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         a.mask = mask_u8;
         a.light_pt = light_pt;
         a.t_table = t_table;
-        a.min_dist = min_dist;
-        a.argmin = argmin;
+        a.counters = kn.counters;
         a.mask_batch = mask_batch;
         a.B = B;
         a.L = L;
         a.H = H;
         a.W = W;
         a.N = N;
-        // small launches: split every tile's sample range over the 4 waves of its workgroup (finer, more
-        // uniform work items); large launches keep one tile per wave (less per-pixel prologue work).
-        const long long tiles_total = (long long)B * L * tiles_x * ((H + TILE_H - 1) / TILE_H);
-        const bool ksplit = (g_ksplit < 0) ? (tiles_total <= 2048 && N >= 16) : (g_ksplit == 1);  // measured: helps B<=2 at 256^2 (a quarter-range wave starts the depth-bound skip without a running minimum)
-        a.ksplit = ksplit ? 1 : 0;
-        a.quads_x = ksplit ? tiles_x : quads_x;
-        a.quads_y = (H + TILE_H - 1) / TILE_H;
+        a.tiles_x = tiles_x;
+        a.tiles_y = tiles_y;
+        a.total_tiles = (int)tiles_total;
         a.bl_offset = 0;
-        if ((long long)B * L > 0x7fffffffLL / 4)
-            return GCFR_ERR_INVALID_ARGUMENT;
-        a.bonus = bonus;
-        a.bx_lo = bx[0];
-        a.bx_hi = bx[1];
-        a.by_lo = bx[2];
-        a.by_hi = bx[3];
-        a.normals = fs.normals;
-        a.albedo = fs.albedo;
-        a.ambient = fs.ambient;
-        a.shadow_w = fs.shadow_w;
-        a.full = fs.full;
-        a.final_shading = fs.final_shading;
-        a.rendered = fs.rendered;
-        a.intensity = fs.intensity;
-        a.nrm = fs.nrm;
-        a.nrm.depth = depth;
-        a.nrm.H = H;
-        a.nrm.W = W;
-        a.normals_out = fs.normals_out;
+        // Schedule.  Tiny launches (<= 2048 tiles, B <= 2 at 256^2): split every tile's sample range over the 4
+        // waves of its workgroup (finer, more uniform pieces; a quarter-range wave starts the depth-bound skip
+        // without a running minimum, so it loses from B = 4 up).  Otherwise the persistent tile queue.
+        const bool ksplit = (kn.ksplit < 0) ? (tiles_total <= 2048 && N >= 16) : (kn.ksplit == 1);
+        const Schedule sch = ksplit ? kKSplit : (Schedule)(kn.schedule < 0 ? kSchedGrid : kn.schedule);
+        a.tile_order = kn.tile_order < 0 ? 0 : kn.tile_order;
+        a.epi.min_dist = min_dist;
+        a.epi.argmin = argmin;
+        a.epi.bonus = bonus;
+        a.epi.bx_lo = bx[0];
+        a.epi.bx_hi = bx[1];
+        a.epi.by_lo = bx[2];
+        a.epi.by_hi = bx[3];
+        a.epi.normals = fs.normals;
+        a.epi.albedo = fs.albedo;
+        a.epi.ambient = fs.ambient;
+        a.epi.shadow_w = fs.shadow_w;
+        a.epi.full = fs.full;
+        a.epi.final_shading = fs.final_shading;
+        a.epi.rendered = fs.rendered;
+        a.epi.intensity = fs.intensity;
+        a.epi.nrm = fs.nrm;
+        a.epi.nrm.depth = depth;
+        a.epi.nrm.H = H;
+        a.epi.nrm.W = W;
+        a.epi.normals_out = fs.normals_out;
         const bool even_half = (((W / 2) & 1) == 0) && (((H / 2) & 1) == 0);
         const bool want = argmin != nullptr;
         switch (TILE_W) {
         case 8:
-            launch_quad<8>(a, even_half, want, B * L, st);
+            launch_quad<8>(a, even_half, want, B * L, sch, kn, st);
             break;
         case 32:
-            launch_quad<32>(a, even_half, want, B * L, st);
+            launch_quad<32>(a, even_half, want, B * L, sch, kn, st);
             break;
         case 64:
-            launch_quad<64>(a, even_half, want, B * L, st);
+            launch_quad<64>(a, even_half, want, B * L, sch, kn, st);
             break;
         default:
-            launch_quad<16>(a, even_half, want, B * L, st);
+            launch_quad<16>(a, even_half, want, B * L, sch, kn, st);
             break;
         }
         return launch_status();
@@ -1424,7 +1757,11 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
     a.bx_hi = bx[1];
     a.by_lo = bx[2];
     a.by_hi = bx[3];
+    if (kn.ev_start)
+        (void)hipEventRecord(kn.ev_start, st);
     hipLaunchKernelGGL(shadow_fwd_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (kn.ev_stop)
+        (void)hipEventRecord(kn.ev_stop, st);
     return launch_status();
 }
 
@@ -1432,10 +1769,11 @@ extern "C" int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32
                                const float *light_pt, int32_t B, int32_t L, int32_t H, int32_t W,
                                int32_t N, const double *t_table, float bonus,
                                const float *bonus_box, float *min_dist, int32_t *argmin,
-                               void *workspace, size_t workspace_bytes, void *stream)
+                               void *workspace, size_t workspace_bytes, void *stream,
+                               const gcfr_options *opt)
 {
     return shadow_fwd_impl(depth, mask_u8, mask_batch, light_pt, B, L, H, W, N, t_table, bonus, bonus_box,
-                           min_dist, argmin, workspace, workspace_bytes, stream, FusedShade{});
+                           min_dist, argmin, workspace, workspace_bytes, stream, FusedShade{}, opt);
 }
 
 extern "C" int gcfr_render_fwd(const float *light_raw, int32_t clamp_z, float clamp_min,
@@ -1445,7 +1783,8 @@ extern "C" int gcfr_render_fwd(const float *light_raw, int32_t clamp_z, float cl
                                int32_t N, const double *t_table, float bonus, const float *bonus_box,
                                float intensity, float *unit_out, float *light_pt_out, float *min_dist,
                                int32_t *argmin, float *shadow_w, float *full, float *final_shading,
-                               float *rendered, void *workspace, size_t workspace_bytes, void *stream)
+                               float *rendered, void *workspace, size_t workspace_bytes, void *stream,
+                               const gcfr_options *opt)
 {
     if (!light_raw || !normals || !albedo || !ambient || !unit_out || !light_pt_out || !rendered ||
         !workspace)
@@ -1469,7 +1808,7 @@ extern "C" int gcfr_render_fwd(const float *light_raw, int32_t clamp_z, float cl
     fs.rendered = rendered;
     fs.intensity = intensity;
     return shadow_fwd_impl(depth, mask_u8, mask_batch, light_pt_out, B, L, H, W, N, t_table, bonus,
-                           bonus_box, min_dist, argmin, workspace, workspace_bytes, stream, fs);
+                           bonus_box, min_dist, argmin, workspace, workspace_bytes, stream, fs, opt);
 }
 
 extern "C" int gcfr_render_from_depth_fwd(const float *light_raw, int32_t clamp_z, float clamp_min,
@@ -1482,7 +1821,7 @@ extern "C" int gcfr_render_from_depth_fwd(const float *light_raw, int32_t clamp_
                                           float *unit_out, float *light_pt_out, float *min_dist,
                                           int32_t *argmin, float *normals_out, float *shadow_w, float *full,
                                           float *final_shading, float *rendered, void *workspace,
-                                          size_t workspace_bytes, void *stream)
+                                          size_t workspace_bytes, void *stream, const gcfr_options *opt)
 {
     if (!light_raw || !albedo || !ambient || !unit_out || !light_pt_out || !rendered || !workspace ||
         B <= 0 || L <= 0 || fx == 0.0 || fy == 0.0)
@@ -1511,5 +1850,5 @@ extern "C" int gcfr_render_from_depth_fwd(const float *light_raw, int32_t clamp_
     fs.rendered = rendered;
     fs.intensity = intensity;
     return shadow_fwd_impl(depth, mask_u8, mask_batch, light_pt_out, B, L, H, W, N, t_table, bonus,
-                           bonus_box, min_dist, argmin, workspace, workspace_bytes, stream, fs);
+                           bonus_box, min_dist, argmin, workspace, workspace_bytes, stream, fs, opt);
 }

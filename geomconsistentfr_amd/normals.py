@@ -56,9 +56,10 @@ def depth_to_normals(depth: torch.Tensor, camera_matrix: torch.Tensor, negate_y:
     if not depth.is_cuda:
         raise _lib.GcfrError("geomconsistentfr_amd has no CPU path: depth must be on a ROCm device "
                              "(oracle/normals_restatement.py is the host-side specification used by the tests)")
-    K = camera_matrix.detach().to("cpu", torch.float64)          # tiny; the reference builds it on the host (T8:571)
-    if K.shape[0] != 1 and not bool((K == K[:1]).all()):
+    from .block import camera_scalars                            # host scalars, read once per tensor (no per-call sync)
+    k4 = camera_scalars(camera_matrix)
+    if k4 is None:
         return torch.cat([depth_to_normals(depth[i:i + 1], camera_matrix[i:i + 1], negate_y, z_offset)
                           for i in range(depth.shape[0])])
-    fx, fy, cx, cy = (float(K[0, 0, 0]), float(K[0, 1, 1]), float(K[0, 0, 2]), float(K[0, 1, 2]))
+    fx, fy, cx, cy = k4
     return _NormalsFunction.apply(depth, fx, fy, cx, cy, z_offset, negate_y)

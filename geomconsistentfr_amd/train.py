@@ -154,6 +154,22 @@ class TrainConfig:
     miopen_find: bool = True    # torch.backends.cudnn.benchmark: MIOpen picks the fastest conv algorithm (+9 % step rate)
 
 
+def ddp_kwargs(cfg: "TrainConfig", device: torch.device, generator: bool) -> dict:
+    """DistributedDataParallel arguments of the two models.
+    broadcast_buffers=False: BatchNorm running statistics stay per GPU (module docstring), and the discriminator
+    runs two forwards (fake, real) before one backward -- DDP's per-forward buffer broadcast would overwrite BN
+    buffers in place between them and break autograd's version check.
+    find_unused_parameters=True for the generator: its skip convolutions are epoch-gated (relightnet._decode,
+    T8:245, 258, 271, 283: added only when epoch > 8 / 10 / 12 / 14).  The reference trains from epoch 0 (T8:592),
+    where those branches run in forward but never reach the loss; without the flag DDP's reducer waits for their
+    gradients for ever and the SECOND step raises "Expected to have finished reduction in the prior iteration"."""
+    kw = dict(device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=cfg.bucket_cap_mb,
+              gradient_as_bucket_view=True, broadcast_buffers=False)
+    if generator:
+        kw["find_unused_parameters"] = True
+    return kw
+
+
 class Trainer:
     """One process per GPU.  `step(batch, epoch, j)` = T8:617-656 for one batch of any size."""
 
@@ -167,14 +183,8 @@ class Trainer:
         self.net, self.disc = self.model, self.patchgan
         if distributed:
             from torch.nn.parallel import DistributedDataParallel as DDP
-            ids = [self.device.index] if self.device.type == "cuda" else None
-            # broadcast_buffers=False: BatchNorm running statistics stay per GPU (module docstring), and the
-            # discriminator runs two forwards (fake, real) before one backward -- DDP's per-forward buffer
-            # broadcast would overwrite BN buffers in place between them and break autograd's version check.
-            kw = dict(device_ids=ids, bucket_cap_mb=cfg.bucket_cap_mb, gradient_as_bucket_view=True,
-                      broadcast_buffers=False)
-            self.net = DDP(self.model, **kw)
-            self.disc = DDP(self.patchgan, **kw)
+            self.net = DDP(self.model, **ddp_kwargs(cfg, self.device, generator=True))
+            self.disc = DDP(self.patchgan, **ddp_kwargs(cfg, self.device, generator=False))
         self.opt = torch.optim.Adam(self.model.parameters(), lr=cfg.lr)                  # T8:589
         self.opt_d = torch.optim.Adam(self.patchgan.parameters(), lr=cfg.lr)             # T8:590
         K = torch.zeros(1, 3, 3, dtype=torch.float64)

@@ -14,7 +14,9 @@
  *   - every pointer is a DEVICE pointer owned by the caller (hipMalloc / torch tensor storage),
  *     contiguous, planes in NCHW order; nothing is allocated, freed or synchronised inside;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue work;
- *   - re-entrant, no global state; return value: GCFR_OK or a negative gcfr_status;
+ *   - re-entrant and thread-safe: the library keeps NO process-wide mutable state -- every knob and hook is
+ *     an argument (`gcfr_options`), so two host threads may launch on two streams with different options;
+ *     return value: GCFR_OK or a negative gcfr_status;
  *   - shapes: B images, L lights per image, H rows, W columns, N samples per ray.
  *     Pixel (r,c) has image-plane coordinates x = c - W/2, y = H/2 - r           (T8:51-55).
  */
@@ -36,6 +38,37 @@ typedef enum gcfr_status {
 
 /* Library / build identification: "gcfr-hip <version> gfx950". */
 const char *gcfr_version(void);
+
+/*
+ * Per-call options of the forward entry points (HOST struct, read during the call only; NULL = defaults).
+ * Nothing here changes a result bit: the knobs select among kernels / schedules that are bit-identical
+ * (tests/test_gpu_parity.py asserts it for every combination), the hooks only observe.
+ */
+#define GCFR_N_COUNTERS 16
+typedef struct gcfr_options {
+    uint32_t struct_size;      /* sizeof(gcfr_options) of the caller's build; a mismatch is GCFR_ERR_INVALID_ARGUMENT */
+    int32_t tile_w;            /* pixels per tile row: 8, 16, 32 or 64 (a wave marches a tile_w x 64/tile_w tile); 0 = auto */
+    int32_t group;             /* samples per skip group: 1, 2 or 4; 0 = auto (4) */
+    int32_t ksplit;            /* split each tile's sample range over the 4 waves of a workgroup: 0, 1, -1 = auto by launch size */
+    int32_t depth_bound_skip;  /* exact depth-bound group skip: 0, 1, -1 = auto (on) */
+    int32_t schedule;          /* how tiles reach waves: 0 = 3-D grid, one workgroup per four adjacent tiles, image-major;
+                                  1 = persistent waves (as many as the chip holds), first tile by wave index, further
+                                  tiles from a device-side atomic queue; 2 = persistent waves, strided static assignment;
+                                  3 = 1-D grid in queue order (tile_order); -1 = auto */
+    int32_t tile_order;        /* queue order of schedules 1-3: 0 = image-major, row-major tiles; 1 = image-major, centre
+                                  rows first; 2 = centre rows first across all images (heavy tiles first); 3 = image-major with
+                                  each image's tiles rotated by a different amount (mixes heavy and light tiles on
+                                  every SIMD); -1 = auto */
+    int32_t reserved;
+    void *event_start;         /* hipEvent_t recorded on `stream` immediately before the march kernel, or NULL */
+    void *event_stop;          /* hipEvent_t recorded immediately after it, or NULL */
+    uint64_t *counters;        /* DEVICE array of GCFR_N_COUNTERS u64 the march kernel adds its work counts to (executed
+                                  groups, bound tests, ...; tools/count_work.py); only a library built with
+                                  -DGCFR_COUNTERS touches it (gcfr_version() then ends in "+counters"), else ignored */
+} gcfr_options;
+
+/* Fills `opt` with the defaults (struct_size set, every knob "auto", no hooks). */
+void gcfr_options_default(gcfr_options *opt);
 
 /*
  * Sample fractions t_k along the pixel->light segment, HOST side helper.
@@ -71,6 +104,7 @@ int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_z, float cl
  *               training form: bonus = 0 (bonus_box may be NULL).  bonus_box is a HOST pointer.
  *   min_dist    (B,L,H,W) f32 out   minimum_distance (T8:515)
  *   argmin      (B,L,H,W) i32 out   index of the minimising sample (saved for backward); may be NULL
+ *   opt         per-call options (host pointer) or NULL for the defaults; see gcfr_options
  *   workspace   device scratch of >= gcfr_shadow_workspace_bytes(B,H,W) bytes, 16-byte aligned, or NULL.
  *               With a workspace the depth maps are first repacked into 2x2-neighbourhood texels
  *               (one 16-byte gather per ray-step instead of four 4-byte gathers) and a coarse grid of
@@ -81,15 +115,11 @@ int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_z, float cl
  */
 size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W);
 
-/* Tuning / A-B knob for experiments (process-wide; not needed in normal use; results never change):
- * key 0 = tile width {8,16,32,64, 0 = auto} (default auto), key 1 = samples per skip group {1,2,4} (default 4),
- * key 2 = split each tile's sample range over the 4 waves of its workgroup {0,1,-1 = auto by launch size},
- * key 3 = depth-bound group skip {0,1} (default 1). */
-int gcfr_tune(int32_t key, int32_t value);
 int gcfr_shadow_fwd(const float *depth, const uint8_t *mask_u8, int32_t mask_batch,
                     const float *light_pt, int32_t B, int32_t L, int32_t H, int32_t W, int32_t N,
                     const double *t_table, float bonus, const float *bonus_box, float *min_dist,
-                    int32_t *argmin, void *workspace, size_t workspace_bytes, void *stream);
+                    int32_t *argmin, void *workspace, size_t workspace_bytes, void *stream,
+                    const gcfr_options *opt);
 
 /*
  * Soft-shadow transfer + Lambert shading + composite.  Replaces T8:364-369 and T8:517-522.
@@ -137,7 +167,7 @@ int gcfr_render_fwd(const float *light_raw, int32_t clamp_z, float clamp_min, fl
                     const float *bonus_box, float intensity, float *unit_out, float *light_pt_out,
                     float *min_dist, int32_t *argmin, float *shadow_w, float *full,
                     float *final_shading, float *rendered, void *workspace, size_t workspace_bytes,
-                    void *stream);
+                    void *stream, const gcfr_options *opt);
 
 /*
  * gcfr_render_fwd with the normals stage fused in: the march epilogue evaluates the 3x3 depth stencil of
@@ -152,12 +182,8 @@ int gcfr_render_from_depth_fwd(const float *light_raw, int32_t clamp_z, float cl
                                float bonus, const float *bonus_box, float intensity, float *unit_out,
                                float *light_pt_out, float *min_dist, int32_t *argmin, float *normals_out,
                                float *shadow_w, float *full, float *final_shading, float *rendered,
-                               void *workspace, size_t workspace_bytes, void *stream);
-
-/* Profiling hook: two hipEvent_t handles (or NULL, NULL to clear) that subsequent gcfr_shadow_fwd /
- * gcfr_render_fwd calls record immediately before and after the march kernel, on the launch stream.
- * Process-wide; used by bench.py to time the dominant kernel alone. */
-int gcfr_profile_events(void *start_event, void *stop_event);
+                               void *workspace, size_t workspace_bytes, void *stream,
+                               const gcfr_options *opt);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward.  The reference has no explicit backward: torch autograd replays T8:352-524

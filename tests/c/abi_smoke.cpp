@@ -112,9 +112,25 @@ int main()
     CK(hipStreamCreate(&st));
 
     // (1) one call
+    // per-call options: explicit knobs (grid schedule here; the NULL-options calls below use the defaults, i.e. the
+    // persistent tile queue) and an event pair the library records around the march kernel
+    gcfr_options opt;
+    gcfr_options_default(&opt);
+    hipEvent_t ev0, ev1;
+    CK(hipEventCreate(&ev0));
+    CK(hipEventCreate(&ev1));
+    opt.schedule = 0;
+    opt.event_start = ev0;
+    opt.event_stop = ev1;
     GK(gcfr_render_fwd(d_light, 1, 0.0f, 4013.0f, d_depth, d_mask, B, d_normals, d_albedo, d_amb, B, L, H, W, N,
-                       d_tt, 0.0f, nullptr, 0.5f, unit, pt, md, am, w, full, fin, ren, ws, ws_bytes, st));
+                       d_tt, 0.0f, nullptr, 0.5f, unit, pt, md, am, w, full, fin, ren, ws, ws_bytes, st, &opt));
     CK(hipStreamSynchronize(st));
+    float march_ms = -1.0f;
+    CK(hipEventElapsedTime(&march_ms, ev0, ev1));
+    if (!(march_ms > 0.0f)) {
+        std::fprintf(stderr, "event hook: march kernel time %g ms\n", march_ms);
+        return 1;
+    }
     auto h_md = host_copy(md, BL * P), h_w = host_copy(w, BL * P), h_ren = host_copy(ren, BL * 3 * P);
     auto h_am = host_copy(am, BL * P);
     auto h_pt = host_copy(pt, BL * 3);
@@ -123,7 +139,7 @@ int main()
     float *md2 = dev_alloc<float>(BL * P), *ren2 = dev_alloc<float>(BL * 3 * P), *w2 = dev_alloc<float>(BL * P);
     int32_t *am2 = dev_alloc<int32_t>(BL * P);
     GK(gcfr_light_prep(d_light, (int)BL, 1, 0.0f, 4013.0f, unit, pt, st));
-    GK(gcfr_shadow_fwd(d_depth, d_mask, B, pt, B, L, H, W, N, d_tt, 0.0f, nullptr, md2, am2, nullptr, 0, st));
+    GK(gcfr_shadow_fwd(d_depth, d_mask, B, pt, B, L, H, W, N, d_tt, 0.0f, nullptr, md2, am2, nullptr, 0, st, nullptr));
     GK(gcfr_shade_fwd(d_normals, d_depth, d_albedo, pt, d_amb, md2, B, L, H, W, 0.5f, w2, nullptr, nullptr, ren2, st));
     CK(hipStreamSynchronize(st));
     auto h_md2 = host_copy(md2, BL * P), h_ren2 = host_copy(ren2, BL * 3 * P);

@@ -37,10 +37,35 @@ def test_sample_table_host_helper_matches_numpy():
 def test_invalid_arguments_are_rejected_without_a_gpu():
     from geomconsistentfr_amd import _lib
     L = _lib.load()
-    assert L.gcfr_shadow_fwd(None, None, 1, None, 1, 1, 256, 256, 160, None, 0.0, None, None, None, None, 0, None) == -1
-    assert L.gcfr_shadow_workspace_bytes(8, 256, 256) == 8 * 257 * 257 * 16 + 8 * 256 * 16 + 8 * (33 * 33 + 1) * 16 + 8 * 256 * 8 + 16
+    assert L.gcfr_shadow_fwd(None, None, 1, None, 1, 1, 256, 256, 160, None, 0.0, None, None, None, None, 0, None, None) == -1
+    # workspace: quad texels + 4 statistics chunks per 256x256 image (box 16 B + depth range 8 B) + depth-bounds records
+    assert L.gcfr_shadow_workspace_bytes(8, 256, 256) == 8 * 257 * 257 * 16 + 8 * 4 * 16 + 8 * (33 * 33 + 1) * 16 + 8 * 4 * 8 + 65 * 4 + 12
     assert L.gcfr_light_prep(None, 1, 1, 0.0, 4013.0, None, None, None) == -1
     assert L.gcfr_shade_fwd(None, None, None, None, None, None, 1, 1, 8, 8, 0.5, None, None, None, None, None) == -1
+
+
+def test_options_struct_defaults_and_layout():
+    """gcfr_options: the python mirror has the header's layout; defaults are all 'auto'; a caller built against
+    another layout (wrong struct_size) or an out-of-range knob is rejected before anything is launched."""
+    import ctypes
+    from geomconsistentfr_amd import _lib
+    L = _lib.load()
+    o = _lib.Options()
+    L.gcfr_options_default(ctypes.byref(o))
+    assert o.struct_size == ctypes.sizeof(_lib.Options) == 56
+    assert (o.tile_w, o.group, o.ksplit, o.depth_bound_skip, o.schedule, o.tile_order) == (0, 0, -1, -1, -1, -1)
+    assert not o.event_start and not o.event_stop and not o.counters
+    # argument validation happens on the host before any launch, so it can be exercised without a GPU: dummy non-null
+    # pointers, a valid shape, then a bad options struct
+    dummy = ctypes.c_void_p(64)
+    args = (dummy, dummy, 1, dummy, 1, 1, 256, 256, 160, dummy, 0.0, None, dummy, None, None, 0, None)
+    bad = _lib.options(tile_w=24)
+    assert L.gcfr_shadow_fwd(*args, ctypes.byref(bad)) == -1
+    bad = _lib.options()
+    bad.struct_size = 8
+    assert L.gcfr_shadow_fwd(*args, ctypes.byref(bad)) == -1
+    bad = _lib.options(schedule=7)
+    assert L.gcfr_shadow_fwd(*args, ctypes.byref(bad)) == -1
 
 
 def test_product_has_no_cpu_fallback():

@@ -203,7 +203,6 @@ def test_sample_range_split_is_bit_identical(N):
     """The k-split variant (4 waves share a tile, a quarter of the samples each, LDS combine) against the
     one-tile-per-wave variant and the direct kernel: same bits, same argmin (ties -> earliest index)."""
     from geomconsistentfr_amd import RenderParams, shadow_min_distance, light_prep, _lib
-    L_ = _lib.load()
     rng = np.random.default_rng(N)
     B, Hs, Ws = 3, 66, 130
     depth = (40 * rng.random((B, Hs, Ws))).astype(np.float32)
@@ -213,14 +212,11 @@ def test_sample_range_split_is_bit_identical(N):
     prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
     _, pt = light_prep(to_dev(lights), prm)
     ref_md, ref_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=False)
-    try:
-        for ks in (0, 1):
-            assert L_.gcfr_tune(2, ks) == 0
-            md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True)
-            assert torch.equal(md, ref_md), ks
-            assert torch.equal(am, ref_am), ks
-    finally:
-        L_.gcfr_tune(2, -1)
+    for ks, sched in ((0, 0), (0, 1), (0, 2), (0, 3), (1, -1)):   # grid, tile queue, strided, ordered grid, k-split
+        md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True,
+                                     options=_lib.options(ksplit=ks, schedule=sched))
+        assert torch.equal(md, ref_md), (ks, sched)
+        assert torch.equal(am, ref_am), (ks, sched)
 
 
 def _compact_masks(Hs, Ws):
@@ -242,7 +238,6 @@ def test_mask_bounding_box_pruning_is_exact(Hs, Ws, N):
     """Compact / degenerate masks: the workspace kernel bounds each wave's sample loop by the mask's bounding
     box; values and argmin must stay bit-identical to the direct kernel, with and without k-split."""
     from geomconsistentfr_amd import RenderParams, shadow_min_distance, light_prep, _lib
-    L_ = _lib.load()
     rng = np.random.default_rng(Hs + Ws + N)
     masks = _compact_masks(Hs, Ws)
     B = len(masks)
@@ -256,15 +251,12 @@ def test_mask_bounding_box_pruning_is_exact(Hs, Ws, N):
     prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
     _, pt = light_prep(to_dev(lights), prm)
     ref_md, ref_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=False)
-    try:
-        for ks in (0, 1):
-            assert L_.gcfr_tune(2, ks) == 0
-            md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True)
-            bad = (md != ref_md).nonzero()
-            assert torch.equal(md, ref_md), (ks, bad[:5].tolist())
-            assert torch.equal(am, ref_am), ks
-    finally:
-        L_.gcfr_tune(2, -1)
+    for ks, sched, order in ((0, 0, 0), (0, 1, 0), (0, 1, 1), (0, 2, 2), (0, 2, 0), (0, 3, 2), (0, 3, 1), (1, -1, -1)):
+        md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True,
+                                     options=_lib.options(ksplit=ks, schedule=sched, tile_order=order))
+        bad = (md != ref_md).nonzero()
+        assert torch.equal(md, ref_md), (ks, sched, order, bad[:5].tolist())
+        assert torch.equal(am, ref_am), (ks, sched, order)
     empty = list(masks).index("empty")
     assert torch.all(ref_md[empty] == 1e6)
     # one mask shared by the whole batch (S1 form): bounding box of mask 0 applies to every image
@@ -316,29 +308,36 @@ def test_python_boundary_rejects_bad_shapes():
                             torch.ones(3, 1, 3, device="cuda:0"), RenderParams())
 
 
-def test_forward_is_hipgraph_capturable():
-    """The C entry points neither allocate nor synchronise: a torch.cuda.graph capture of render_fwd replays
-    bit-identically, also after the static inputs are overwritten."""
+def test_fractional_float_masks_mean_non_zero():
+    """The reference's masks are imread / 255.0 floats with four grey levels (64/255, 128/255, ...) and it tests
+    `mask == 0` (T8:510): every non-zero level is inside the face.  Every entry point converts with `!= 0`, never
+    by truncation -- eager call, plan call and a hipGraph replay after new data was copied into the captured inputs."""
     from geomconsistentfr_amd import RenderParams
     from geomconsistentfr_amd import block as R
     rng = np.random.default_rng(9)
     B, Hs, Ws = 2, 64, 64
     mk = lambda *s: to_dev(rng.random(s, dtype=np.float32))
     depth, albedo, normals = to_dev((30 * rng.random((B, Hs, Ws))).astype(np.float32)), mk(B, 3, Hs, Ws), mk(B, 3, Hs, Ws) - 0.5
-    mask = to_dev((rng.random((B, Hs, Ws)) > 0.3).astype(np.uint8))
+    levels = np.array([0.0, 64 / 255.0, 128 / 255.0, 192 / 255.0, 1.0])
+    mask_f = levels[rng.integers(0, 5, (B, Hs, Ws))]
     light, amb = to_dev(rng.standard_normal((B, 1, 3)).astype(np.float32)), mk(B, 1)
     prm = RenderParams(n_samples=40, dt=0.02)
-    g = R.GraphedRenderFwd(depth, mask, light, amb, normals, albedo, prm)
-    ref = R.render_fwd(depth, mask, light, amb, normals, albedo, prm, want_argmin=False)
-    out = g(depth, mask, light, amb, normals, albedo)
+    ref = R.render_fwd(depth, to_dev((mask_f != 0).astype(np.uint8)), light, amb, normals, albedo, prm, want_argmin=False)
+    for mdt in (np.float64, np.float32):
+        out = R.render_fwd(depth, to_dev(mask_f.astype(mdt)), light, amb, normals, albedo, prm, want_argmin=False)
+        assert torch.equal(out["rendered_images"], ref["rendered_images"])
+        assert torch.equal(out["minimum_distance"], ref["minimum_distance"])
+    assert R.mask_to_u8(to_dev(mask_f)).dtype == torch.uint8
+    assert int(R.mask_to_u8(to_dev(mask_f)).sum()) == int((mask_f != 0).sum())
+    # graph replay: new inputs are copied into the captured tensors (the mask through mask_to_u8), then replayed
+    plan = R.RenderFwdPlan(B, 1, Hs, Ws, prm, depth.device, want_argmin=False)
+    static = [depth.clone(), torch.zeros((B, Hs, Ws), dtype=torch.uint8, device=depth.device), light.clone(),
+              amb.clone(), normals.clone(), albedo.clone()]
+    plan.capture(*static)
+    static[1].copy_(R.mask_to_u8(to_dev(mask_f)))
+    out = plan.replay()
     torch.cuda.synchronize()
     assert torch.equal(out["rendered_images"], ref["rendered_images"])
-    depth2 = torch.roll(depth, 3, dims=2).contiguous()
-    ref2 = R.render_fwd(depth2, mask, light, amb, normals, albedo, prm, want_argmin=False)
-    out2 = g(depth2, mask, light, amb, normals, albedo)
-    torch.cuda.synchronize()
-    assert torch.equal(out2["rendered_images"], ref2["rendered_images"])
-    assert torch.equal(out2["minimum_distance"], ref2["minimum_distance"])
 
 
 def test_maximum_supported_size():
@@ -364,13 +363,12 @@ def test_maximum_supported_size():
 
 @pytest.mark.parametrize("Hs,Ws,N,dt", [(128, 128, 160, 0.005), (66, 130, 37, 0.02), (256, 256, 96, 0.008)])
 def test_depth_bound_skip_is_exact_for_every_tile_shape(Hs, Ws, N, dt):
-    """The depth-bound group skip (coarse min/max depth grid, include/gcfr.h tune key 3) must not change one bit:
+    """The depth-bound group skip (plane-band depth-bounds grid, gcfr_options.depth_bound_skip) must not change one bit:
     min distance and argmin against the C oracle and the direct kernel, for every tile shape and group size,
     on surfaces that make it fire (smooth bump), that defeat it (noise), that straddle zero and that are
     offset far from zero (the sampled-zero quirk of integral coordinates, coarse float spacing -> ties)."""
     import c_oracle
     from geomconsistentfr_amd import RenderParams, shadow_min_distance, light_prep, _lib
-    L_ = _lib.load()
     rng = np.random.default_rng(Hs * 7 + N)
     r, c = np.mgrid[0:Hs, 0:Ws]
     bump = 0.35 * Hs * np.exp(-(((c - 0.5 * Ws) / (0.25 * Ws)) ** 2 + ((r - 0.5 * Hs) / (0.3 * Hs)) ** 2))
@@ -390,18 +388,14 @@ def test_depth_bound_skip_is_exact_for_every_tile_shape(Hs, Ws, N, dt):
     ref_md, ref_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=False)
     assert np.array_equal(ref_md.cpu().numpy(), md_o)
     assert np.array_equal(ref_am.cpu().numpy()[lit], am_o[lit])
-    try:
-        for zb in (1, 0):
-            for tw in (8, 16, 32, 64):
-                for grp in ((4, 2, 1) if tw == 8 else (4,)):
-                    assert L_.gcfr_tune(3, zb) == 0 and L_.gcfr_tune(0, tw) == 0 and L_.gcfr_tune(1, grp) == 0
-                    md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True)
-                    assert torch.equal(md, ref_md), (zb, tw, grp)
-                    assert torch.equal(am, ref_am), (zb, tw, grp)
-    finally:
-        L_.gcfr_tune(3, 1)
-        L_.gcfr_tune(0, 0)
-        L_.gcfr_tune(1, 4)
+    for zb in (1, 0):
+        for tw in (8, 16, 32, 64):
+            for grp in ((4, 2, 1) if tw == 8 else (4,)):
+                for sched in ((2, 0, 1, 3) if grp == 4 else (2,)):
+                    opt = _lib.options(depth_bound_skip=zb, tile_w=tw, group=grp, schedule=sched, ksplit=0)
+                    md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True, options=opt)
+                    assert torch.equal(md, ref_md), (zb, tw, grp, sched)
+                    assert torch.equal(am, ref_am), (zb, tw, grp, sched)
 
 
 def test_render_fwd_plan_matches_eager_call_and_overlaps_on_two_streams():

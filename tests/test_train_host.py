@@ -72,14 +72,15 @@ def test_synthetic_batch_is_deterministic_and_rank_disjoint():
 class _FeatureLoss(torch.nn.Module):
     """RelightNet up to the T8:352 seam (CPU-runnable) with a scalar loss on its three heads."""
 
-    def __init__(self):
+    def __init__(self, epoch=200):
         super().__init__()
         from geomconsistentfr_amd.relightnet import RelightNet
         torch.manual_seed(1234)
         self.net = RelightNet()
+        self.epoch = epoch
 
     def forward(self, img):
-        albedo, depth, SL = self.net.features(img, 200)
+        albedo, depth, SL = self.net.features(img, self.epoch)
         return albedo.mean() + 1e-3 * depth.abs().mean() + SL.pow(2).mean()
 
 
@@ -115,6 +116,59 @@ def _ddp_worker_body(rank, world, port, q):
     ref = torch.stack(ref).mean(0)
     q.put((rank, float((g - ref).abs().max()), float(ref.abs().max()), g.numel()))
     dist.destroy_process_group()
+
+
+def _ddp_epoch0_worker(rank, world, port, q):
+    """Two optimiser steps at epoch 0 through DDP with the Trainer's own arguments (train.ddp_kwargs): the
+    epoch-gated skip convolutions run in forward but get no gradient (T8:245-283 gates 8/10/12/14)."""
+    try:
+        import torch.distributed as dist
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from geomconsistentfr_amd.train import TrainConfig, ddp_kwargs, shard_range, synthetic_batch
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.set_num_threads(2)
+        m = _FeatureLoss(epoch=0)
+        ddp = DDP(m, **ddp_kwargs(TrainConfig(), torch.device("cpu"), generator=True))
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+        lo, hi = shard_range(2, rank, world)
+        full = synthetic_batch(2, 0, 256, 256)["images"]
+        for _ in range(2):                                   # the failure mode only shows on the SECOND step
+            opt.zero_grad(set_to_none=True)
+            ddp(full[lo:hi]).backward()
+            opt.step()
+        named = dict(m.net.named_parameters())
+        unused = [n for n, p in named.items() if p.grad is None or float(p.grad.abs().max()) == 0.0]
+        used = torch.cat([p.grad.flatten() for n, p in named.items() if p.grad is not None])
+        gathered = [torch.zeros_like(used) for _ in range(world)]
+        dist.all_gather(gathered, used)
+        q.put((rank, float((gathered[0] - gathered[1]).abs().max()), float(used.abs().max()),
+               sum("skip" in n for n in unused)))
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, "error: %r" % (e,), 0.0, 0))
+        raise
+
+
+def test_gloo_world2_two_steps_at_epoch_zero_with_gated_skips():
+    """Regression (round-1 advisor finding): multi-GPU training from scratch.  At epoch 0 every additive skip is
+    gated off, so the skip convolutions' parameters are unused; DDP must be told (find_unused_parameters) or the
+    second step raises.  Both ranks end with identical averaged gradients, and the skip parameters got none."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_epoch0_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    assert all(not isinstance(r[1], str) for r in res), res
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, diff, scale, n_unused_skip in res:
+        assert diff == 0.0 and scale > 0
+        assert n_unused_skip >= 16          # 2 branches x 4 stages x (conv + bn weights/biases) of the gated skips
 
 
 def _ddp_disc_worker(rank, world, port, q):

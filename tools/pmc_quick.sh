@@ -1,5 +1,5 @@
 #!/bin/bash
-# quick PMC comparison of gcfr_tune settings: tools/pmc_quick.sh <faces> "<tune A>" "<tune B>" ...
+# quick PMC comparison of gcfr_options knob settings (bench.py --tune): tools/pmc_quick.sh <faces> "<tune A>" "<tune B>" ...
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 F=$1; shift
 cd /tmp && export TMPDIR=/tmp

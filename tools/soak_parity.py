@@ -55,25 +55,17 @@ def random_case(rng, H, W):
     return depth, mask.astype(np.uint8), l.astype(np.float32)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", type=int, default=240)
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--tune", type=str, default="", help="comma list key=value for gcfr_tune")
-    a = ap.parse_args()
-    if a.tune:
-        from geomconsistentfr_amd import _lib
-        for kv in a.tune.split(","):
-            k, v = kv.split("=")
-            _lib.check(_lib.load().gcfr_tune(int(k), int(v)), "gcfr_tune")
-    rng = np.random.default_rng(a.seed)
+def run_soak(n_cases, seed=0, options=None, sizes=None):
+    """`n_cases` random (depth, mask, light) cases in batches of 8: HIP workspace kernel vs the C oracle.
+    Returns the tallies (pixels compared, lit/masked disagreements, worst min-distance error, argmin differences)."""
+    rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
-    sizes = [(64, 64, 48), (96, 128, 80), (130, 70, 37), (128, 128, 160), (256, 256, 160)]
+    sizes = sizes or [(64, 64, 48), (96, 128, 80), (130, 70, 37), (128, 128, 160), (256, 256, 160)]
     worst = {"abs": 0.0, "rel": 0.0}
     n_pix = n_arg_diff = n_lit_mismatch = 0
     t0 = time.time()
     B = 8
-    for it in range(a.cases // B):
+    for it in range(n_cases // B):
         H, W, N = sizes[it % len(sizes)]
         cases = [random_case(rng, H, W) for _ in range(B)]
         depth = np.stack([c[0] for c in cases])
@@ -83,11 +75,11 @@ def main():
         # distance (near lights: rays far from parallel, small |BC|)
         scale = [1.0, 1.0, 0.01, 12.0, 300.0][it % 5] if it % 3 == 0 else 1.0
         depth = (depth * np.float32(scale)).astype(np.float32)
-        ld = [4013.0, 4013.0, 60.0, 500.0, 1.0e5][(it // 5) % 5]
+        ld = [4013.0, 4013.0, 60.0, 500.0, 1.0e5, 30.0][(it // 5) % 6]
         prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N, light_distance=ld)
         _, pt = light_prep(torch.from_numpy(lights).to(dev), prm)
         md, am = shadow_min_distance(torch.from_numpy(depth).to(dev), torch.from_numpy(mask).to(dev),
-                                     pt.reshape(B, 1, 3), prm)
+                                     pt.reshape(B, 1, 3), prm, options=options)
         _, pt_o = c_oracle.light_prep(lights, clamp_z_min=0.0, light_distance=ld)
         md_o, am_o = c_oracle.shadow_min_distance(depth, mask, pt_o[:, None, :], c_oracle.sample_table(0.025, 0.8 / N, N))
         md, am = md.cpu().numpy(), am.cpu().numpy()
@@ -100,11 +92,21 @@ def main():
             worst["rel"] = max(worst["rel"], float((err / np.maximum(np.abs(md_o[both]), 1.0)).max()))
         n_pix += int(both.sum())
         n_arg_diff += int((am[both] != am_o[both]).sum())
-    out = {"cases": (a.cases // B) * B, "pixels_compared": n_pix, "lit_mask_mismatches": n_lit_mismatch,
-           "max_abs_err_min_dist": worst["abs"], "max_rel_err_min_dist": worst["rel"],
-           "argmin_differences": n_arg_diff, "argmin_difference_rate": n_arg_diff / max(n_pix, 1),
-           "seconds": time.time() - t0}
-    print(json.dumps(out))
+    return {"cases": (n_cases // B) * B, "seed": seed, "pixels_compared": n_pix, "lit_mask_mismatches": n_lit_mismatch,
+            "max_abs_err_min_dist": worst["abs"], "max_rel_err_min_dist": worst["rel"],
+            "argmin_differences": n_arg_diff, "argmin_difference_rate": n_arg_diff / max(n_pix, 1),
+            "seconds": time.time() - t0}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=240)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--tune", type=str, default="", help="comma list of gcfr_options knobs, e.g. schedule=0,tile_w=16")
+    a = ap.parse_args()
+    from geomconsistentfr_amd import _lib
+    knobs = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)}
+    print(json.dumps(run_soak(a.cases, a.seed, _lib.options(**knobs) if knobs else None)))
 
 
 if __name__ == "__main__":
