@@ -42,6 +42,11 @@ def options(tile_w=0, group=0, ksplit=-1, depth_bound_skip=-1, schedule=-1, tile
     return o
 
 
+def has_experimental_schedules() -> bool:
+    """True for a library built with -DGCFR_EXPERIMENTAL_SCHEDULES (gcfr_options.schedule 1 ... 4 available)."""
+    return b"+schedules" in load().gcfr_version()
+
+
 def opt_ref(o):
     """ctypes argument for a `const gcfr_options *` parameter (None = library defaults)."""
     return ctypes.byref(o) if o is not None else None

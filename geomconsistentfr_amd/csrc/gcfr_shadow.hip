@@ -745,16 +745,23 @@ __device__ inline ImageStats reduce_image_stats(ArgPtr a, int b, int lane, bool 
     return st;
 }
 
-// One tile of one (image, light) pair: 64 lanes = 64 pixels, all N samples (KSPLIT: this wave's quarter of them).
-// KSPLIT = false: the waves of a workgroup march different tiles and never synchronise.
-// KSPLIT = true : the 4 waves march the SAME tile, a contiguous quarter of the sample range each, and
-//                 combine their partial minima through LDS (earliest index wins ties, as torch.min).
-//                 Same total work in 4x finer, more uniform pieces: used for tiny launches, where a few
-//                 heavy (fully unmasked) tiles otherwise leave the SIMDs idle at the tail of the launch.
+// One tile of one (image, light) pair: 64 lanes = 64 pixels.
+// SPLIT = 0: one wave marches all N samples of the tile; the waves of a workgroup march different tiles and never
+//            synchronise.
+// SPLIT = 1: the 4 waves of the workgroup march the SAME tile, a contiguous quarter of the sample range each
+//            (four gathers in flight per body, natural occupancy), and combine their partial minima through LDS
+//            (earliest index wins ties, as torch.min): tiny, latency-bound launches (one or two images).
+// SPLIT = 2: cooperative march: the 4 waves take the tile's sample GROUPS round-robin (wave w: groups w, w+4, ...),
+//            so they advance along the rays together, publish their running minima in LDS and use each other's as
+//            the bound of the exact depth-bound skip and of the early termination (any minimum already found for a
+//            pixel bounds its final minimum: a group skipped against it could neither win nor tie).  The heaviest
+//            tile's critical path -- which IS the launch time of the one-wave-per-tile schedule (timeline: the
+//            longest tile runs 69 of the launch's 74 us) -- shrinks fourfold and the work items are four times
+//            finer, so one launch keeps the SIMDs full to the end.
 #ifndef GCFR_TILE_INLINE
 #define GCFR_TILE_INLINE __forceinline__
 #endif
-template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool KSPLIT>
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, int SPLIT>
 __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy, const int tx,
                                            const ImageStats &st)
 {
@@ -773,11 +780,14 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // sample range of this wave
+    constexpr bool KSPLIT = SPLIT == 1, COOP = SPLIT == 2;
     const int chunk = KSPLIT ? (a->N + 3) >> 2 : a->N;
     const int k_lo = KSPLIT ? wave * chunk : 0;
     const int N = KSPLIT ? min(a->N, k_lo + chunk) : a->N;  // exclusive upper bound ("N" below)
 #ifdef GCFR_COUNTERS
     unsigned cnt[kCntUsed] = {};
+    // timeline record of this tile (tools/trace_timeline.py): constant 100 MHz clock + shader clock at entry
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime(), trace_c0 = __builtin_amdgcn_s_memtime();
 #endif
 
     const int b = bl / L;
@@ -822,6 +832,12 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     float prevS = __builtin_inff();  // the running minimum replaced last (distance-tie resolution, see epilogue)
     int prevk = -1;
     bool any_masked = false;
+#ifdef GCFR_PRIO_AFTER
+    int n_bodies = 0;
+#ifndef GCFR_PRIO_LEVEL
+#define GCFR_PRIO_LEVEL 3
+#endif
+#endif
 
     // Candidate sample range.  A sample can only be unmasked if its rounded cell lies inside the bounding
     // box of the mask's non-zero cells, i.e. if s(t) = start + t*delta lies inside that box inflated by
@@ -1006,8 +1022,24 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     // consumed in place -- with a single buffer copied at the loop's back edge the compiler waits for the
     // gathers (s_waitcnt vmcnt(0)) at the END of the iteration that issued them, which exposes their whole
     // latency on every skipped group.
+    // COOP: this wave's next group is four groups on; the running minima of the workgroup's four waves live in LDS
+    constexpr int GSTRIDE = COOP ? 4 * DEPTH : DEPTH;
+    __shared__ float s_run_min[COOP ? 4 : 1][64];
+    volatile float *run_min = &s_run_min[0][0];
+    if (COOP) {
+        run_min[wave * 64 + lane] = __builtin_inff();
+        __syncthreads();
+    }
+    // the bound the skip / termination tests compare against: the lane's own running minimum, or (COOP) the
+    // smallest one any of the four waves has published for this pixel -- stale values are larger, hence safe
+    auto bound_min = [&]() -> float {
+        if (!COOP)
+            return bestS;
+        const float m01 = fminf(run_min[lane], run_min[64 + lane]), m23 = fminf(run_min[128 + lane], run_min[192 + lane]);
+        return fminf(bestS, fminf(m01, m23));
+    };
     auto group = [&](int k0, const Prefetched &cur, Prefetched &nxt, bool check_finished) -> bool {
-        prefetch(k0 + DEPTH, nxt);
+        prefetch(k0 + GSTRIDE, nxt);
         GCFR_COUNT(kCntGroupsVisited, 1);
         bool none = true;
 #pragma unroll
@@ -1030,15 +1062,22 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
             const float gap = fmaxf(Flo + fminf(eA, eB), -(Fhi + fmaxf(eA, eB)));  // > 0 iff the band stays clear of the ray
             const float gap0 = fmaxf(-Qz - Thi, Tlo + Qz);     // the same for the isolated value z = 0
             const float g = fminf(gap, gap0) - Kerr;
-            const bool cannot_win = (g > 0.0f) && (g * g * 0.998f > bestS);
+            const bool cannot_win = (g > 0.0f) && (g * g * 0.998f > bound_min());
             run_body = __builtin_amdgcn_ballot_w64(!none && !cannot_win) != 0ull;
         }
         // samples of the group evaluated together (texel gathers in flight): one at a time in the throughput
         // variants (fewer live registers -> forced occupancy, see the __global__ wrappers), the whole group in the
         // k-split variant, whose launches are tiny and latency-bound
-        constexpr int GCFR_BODY_CHUNK = KSPLIT ? DEPTH : 1;
+        constexpr int GCFR_BODY_CHUNK = KSPLIT ? DEPTH : 1;  // (KSPLIT here: SPLIT == 1 only)
         if (run_body) {
           GCFR_COUNT(kCntBodies, 1);
+#ifdef GCFR_PRIO_AFTER
+          // Longest-job-first at the issue port: a wave that keeps executing bodies is one of the few heavy ones whose
+          // length sets the launch time; VALU issue is arbitrated by priority, so raising it lets the heavy wave run
+          // at its own pace while its light SIMD-mates fill the gaps.
+          if (++n_bodies == GCFR_PRIO_AFTER)
+              __builtin_amdgcn_s_setprio(GCFR_PRIO_LEVEL);
+#endif
 #ifdef GCFR_COUNTERS
 #pragma unroll
           for (int j = 0; j < DEPTH; ++j)
@@ -1091,11 +1130,14 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
                 bestS = take ? S : bestS;
             }
           }
+          if (COOP)
+              run_min[wave * 64 + lane] = bestS;  // publish (racy by design: any value ever written is a valid bound)
         }
         if (check_finished && use_zb && k0 + DEPTH < k_end) {  // early termination, see Dcap
             const float tn = (float)tt[k0 + DEPTH];
             const float gd = __builtin_fmaf(c1, tn, -Dcap);
-            const bool finished = ((gd > 0.0f) && (gd * gd * 0.998f > bestS) && (bestS < safeS)) ||
+            const float bS = bound_min();
+            const bool finished = ((gd > 0.0f) && (gd * gd * 0.998f > bS) && (bS < safeS)) ||
                                   (lane_last < k0 + DEPTH);
             if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) {
                 any_masked |= (lane_last < k0 + DEPTH);
@@ -1108,18 +1150,20 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 
     Prefetched bufA, bufB;
     bufA.z = bufB.z = f32x4{0.0f, 0.0f, -__builtin_inff(), __builtin_inff()};
-    if (k_begin < k_end)
-        prefetch(k_begin, bufA);
-    for (int k0 = k_begin; k0 < k_end; k0 += 2 * DEPTH) {
+    const int k_first = k_begin + (COOP ? wave * DEPTH : 0);
+    if (k_first < k_end)
+        prefetch(k_first, bufA);
+    for (int k0 = k_first; k0 < k_end; k0 += 2 * GSTRIDE) {
         if (!group(k0, bufA, bufB, false))
             break;
-        if (k0 + DEPTH >= k_end)
+        if (k0 + GSTRIDE >= k_end)
             break;
-        if (!group(k0 + DEPTH, bufB, bufA, true))  // the termination test runs every other group (it costs ~18 VALU)
+        if (!group(k0 + GSTRIDE, bufB, bufA, true))  // the termination test runs every other group (it costs ~18 VALU)
             break;
     }
 
-    if (KSPLIT) {  // combine the four sample-range quarters of this tile
+    bool coop_tie = false;  // COOP + argmin: some wave holds an earlier sample that may round to the same distance
+    if (KSPLIT || COOP) {  // combine the four waves' partial results for this tile
         __shared__ float sS[4][64], sPS[4][64];
         __shared__ int sK[4][64], sPK[4][64];
         __shared__ uint8_t sM[4][64];
@@ -1131,8 +1175,40 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         __syncthreads();
         if (wave != 0)
             return;
+        if (COOP) {
+            // interleaved groups: the minimum of the four partial minima, the SMALLER index on equal S (first minimum,
+            // T8:514).  Distance ties (a slightly larger S at an earlier index rounding to the same distance): every
+            // wave's chain of running minima ends in (prevS, prevk) -> (bestS, besti), and the tie class restricted to
+            // one wave is a suffix of that wave's chain, so if neither link of any wave ties at an earlier index
+            // nothing does; otherwise the epilogue re-marches [0, besti) for the lane (first_tied_sample, exact).
+            float fS = bestS;
+            int fK = besti;
 #pragma unroll
-        for (int q = 1; q < 4; ++q) {
+            for (int q = 1; q < 4; ++q) {
+                const float Sq = sS[q][lane];
+                const int Kq = sK[q][lane];
+                const bool take = (Sq < fS) || (WANT_ARGMIN && Sq == fS && Kq >= 0 && (fK < 0 || Kq < fK));
+                fS = take ? Sq : fS;
+                fK = take ? Kq : fK;
+                any_masked |= (sM[q][lane] != 0);
+            }
+            if (WANT_ARGMIN) {
+                const float den_c = __builtin_sqrtf(((BCx * BCx + BCy * BCy) + BCz * BCz) + kEps4);
+                const float d_c = __builtin_sqrtf(fS) / den_c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float Sb = sS[q][lane], Sp = sPS[q][lane];
+                    const int Kb = sK[q][lane], Kp = sPK[q][lane];
+                    coop_tie |= (Kb >= 0) && (Kb < fK) && (__builtin_sqrtf(Sb) / den_c == d_c);
+                    coop_tie |= (Kp >= 0) && (Kp < fK) && (__builtin_sqrtf(Sp) / den_c == d_c);
+                }
+                prevk = -1;  // the sequential tie test below does not apply
+            }
+            bestS = fS;
+            besti = fK;
+        }
+#pragma unroll
+        for (int q = 1; q < 4 && KSPLIT; ++q) {
             const float Sq = sS[q][lane];
             const bool take = Sq < bestS;  // strict: the earlier quarter keeps ties (first minimum, T8:514)
             // predecessor of a new best from quarter q: q's own predecessor if it already beat the running
@@ -1151,7 +1227,9 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     float d = __builtin_sqrtf(bestS) / den;
     // torch.min (T8:514) returns the FIRST index of the minimal distance: see first_tied_sample.
     if (WANT_ARGMIN) {
-        const bool tie = (prevk >= 0) && (__builtin_sqrtf(prevS) / den == d);
+        const bool tie = COOP ? coop_tie : ((prevk >= 0) && (__builtin_sqrtf(prevS) / den == d));
+        if (COOP)
+            prevk = besti;  // re-march [0, besti): the first sample whose distance equals d, else besti itself
         if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare; wave-uniform branch
             GCFR_COUNT(kCntTieRemarch, 1);
             RayConst rc;
@@ -1182,6 +1260,9 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     }
     if (!finite_ray)
         d = __builtin_nanf("");
+#ifdef GCFR_PRIO_AFTER
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const EpiPtr ep = launder((EpiPtr)&a->epi);
     const bool inside = (Cx >= ep->bx_lo) && (Cx <= ep->bx_hi) && (Cy >= ep->by_lo) && (Cy <= ep->by_hi);
     if (inside)
@@ -1235,10 +1316,22 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         }
     }
 #ifdef GCFR_COUNTERS
-    if (a->counters && lane == 0)
+    if (a->counters && lane == 0 && !(KSPLIT && wave != 0)) {
+#ifndef GCFR_TRACE_ONLY   // (ten same-address atomics per tile cost ~20 ns each: they distort the timeline)
 #pragma unroll
         for (int i = 0; i < kCntUsed; ++i)
             atomicAdd(a->counters + i, (unsigned long long)cnt[i]);
+#endif
+        // per-tile record after the GCFR_N_COUNTERS tallies: {t0, t1 (100 MHz), shader cycles, hw ids | work}
+        unsigned long long *rec = a->counters + GCFR_N_COUNTERS + 4 * ((size_t)(bl * a->tiles_y + qy) * a->tiles_x + tx);
+        const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: wave, simd, cu, sh, se
+        const unsigned xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+        rec[0] = trace_t0;
+        rec[1] = __builtin_amdgcn_s_memrealtime();
+        rec[2] = __builtin_amdgcn_s_memtime() - trace_c0;
+        rec[3] = (unsigned long long)hw_id | ((unsigned long long)(xcc_id & 0xf) << 32) |
+                 ((unsigned long long)(cnt[kCntBodies] & 0xfff) << 36) | ((unsigned long long)(cnt[kCntGroupsVisited] & 0xfff) << 48);
+    }
 #endif
 }
 
@@ -1267,9 +1360,14 @@ __device__ __forceinline__ void march_grid(ArgPtr a)
     const int bl = a->bl_offset + (int)blockIdx.z;
     const bool want_z = (a->zb != nullptr);
     const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, want_z);
-    march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, false>(a, bl, (int)blockIdx.y, tx, st);
+    march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0>(a, bl, (int)blockIdx.y, tx, st);
 }
 
+// ---- experimental schedules (-DGCFR_EXPERIMENTAL_SCHEDULES; profiles/r02_schedule_experiments.md) -----------------
+// Round 2 measured four alternatives to the plain grid, all bit-identical to it and all slower on this workload; they
+// are kept behind a build flag so that the evidence stays reproducible while the product library instantiates only the
+// grid and the k-split kernels.
+#ifdef GCFR_EXPERIMENTAL_SCHEDULES
 // Queue order of the persistent / strided schedules: tile index t -> (image-light pair, tile row, tile column).
 //   tile_order 0: image-major, row-major -- consecutive indices are horizontal neighbours;
 //   tile_order 1: the same with each image's tile rows centre-first;
@@ -1283,6 +1381,40 @@ __device__ __forceinline__ void decode_tile(ArgPtr a, int t, int &bl, int &qy, i
 {
     const int tiles_x = a->tiles_x, tiles_y = a->tiles_y;
     int k;
+    if (a->tile_order == 4 && tiles_y >= 4) {
+        // heavy / light mix: the middle half of every image's tile rows ("heavy": the face) and the outer half
+        // ("light") are two lists, both image-major; the queue takes two heavy rows, then one light row, so the heavy
+        // rows are spread evenly over the first three quarters of the launch and the last quarter is light rows only
+        const int BL = a->B * a->L;
+        const int q1 = tiles_y >> 2, nhr = tiles_y - 2 * q1, nlr = 2 * q1;  // heavy rows [q1, q1 + nhr)
+        const int nH = BL * nhr;
+        const int s_ = t / tiles_x;
+        tx = t - s_ * tiles_x;
+        const int mixed = 3 * (nH >> 1);  // row slots in the mixed part (nH even: nhr is even for even tiles_y ... else the tail absorbs it)
+        int hi = -1, li = -1;
+        if (s_ < mixed) {
+            const int blk = s_ / 3, pos = s_ - 3 * blk;
+            if (pos < 2)
+                hi = 2 * blk + pos;
+            else
+                li = blk;
+        } else {
+            li = (nH >> 1) + (s_ - mixed);
+        }
+        if ((nH & 1) && li >= 0 && s_ == mixed + (BL * nlr - (nH >> 1))) {  // odd heavy count: the last slot is the last heavy row
+            hi = nH - 1;
+            li = -1;
+        }
+        if (hi >= 0) {
+            bl = hi / nhr;
+            qy = q1 + (hi - bl * nhr);
+        } else {
+            bl = li / nlr;
+            const int r_ = li - bl * nlr;
+            qy = r_ < q1 ? r_ : r_ + nhr;
+        }
+        return;
+    }
     if (a->tile_order == 2) {  // t = (k * BL + bl) * tiles_x + tx
         const int BL = a->B * a->L;
         const int row = t / tiles_x;
@@ -1337,7 +1469,7 @@ __device__ __forceinline__ void march_persistent(ArgPtr a)
         int bl, qy, tx;
         decode_tile(a, t, bl, qy, tx);
         const ImageStats st = reduce_image_stats(a, bl / a->L, lane, a->zb != nullptr);
-        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, false>(a, bl, qy, tx, st);
+        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0>(a, bl, qy, tx, st);
         if (DYNAMIC) {
             int *queue = a->tflag + kQueueSlot;  // counts tiles handed out beyond the first n_waves
             int nxt = a->total_tiles;
@@ -1363,14 +1495,17 @@ __device__ __forceinline__ void march_grid_ordered(ArgPtr a)
     int bl, qy, tx;
     decode_tile(a, t, bl, qy, tx);
     const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, a->zb != nullptr);
-    march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, false>(a, bl, qy, tx, st);
+    march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0>(a, bl, qy, tx, st);
 }
+
+#endif  // GCFR_EXPERIMENTAL_SCHEDULES
 
 enum { kSchedGrid = 0, kSchedQueue = 1, kSchedStrided = 2, kSchedGridOrdered = 3 };
 
 template <int SCHED, int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE>
 __device__ __forceinline__ void march_dispatch()
 {
+#ifdef GCFR_EXPERIMENTAL_SCHEDULES
     if (SCHED == kSchedQueue)
         march_persistent<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, true>(kernel_args());
     else if (SCHED == kSchedStrided)
@@ -1378,6 +1513,7 @@ __device__ __forceinline__ void march_dispatch()
     else if (SCHED == kSchedGridOrdered)
         march_grid_ordered<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE>(kernel_args());
     else
+#endif
         march_grid<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE>(kernel_args());
 }
 
@@ -1401,8 +1537,31 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_ksplit_kernel(ShadowQuadA
     const ArgPtr a = kernel_args();
     const int bl = a->bl_offset + (int)blockIdx.z;
     const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, a->zb != nullptr);
-    march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, true>(a, bl, (int)blockIdx.y, (int)blockIdx.x, st);
+    march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 1>(a, bl, (int)blockIdx.y, (int)blockIdx.x, st);
 }
+
+#ifdef GCFR_EXPERIMENTAL_SCHEDULES
+// cooperative march (SPLIT = 2): one workgroup per tile, throughput variant -- one sample at a time, forced occupancy;
+// grid x = tile column, y = tile row, z = (image, light)
+template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(GCFR_MARCH_WAVES_PER_EU, GCFR_MARCH_WAVES_PER_EU))) void shadow_fwd_quad_coop_kernel(ShadowQuadArgs)
+{
+    const ArgPtr a = kernel_args();
+    const int bl = a->bl_offset + (int)blockIdx.z;
+    const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, a->zb != nullptr);
+    march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, 2>(a, bl, (int)blockIdx.y, (int)blockIdx.x, st);
+}
+template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(GCFR_MARCH_ARGMIN_WAVES_PER_EU, GCFR_MARCH_ARGMIN_WAVES_PER_EU))) void shadow_fwd_quad_coop_argmin_kernel(ShadowQuadArgs)
+{
+    const ArgPtr a = kernel_args();
+    const int bl = a->bl_offset + (int)blockIdx.z;
+    const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, a->zb != nullptr);
+    march_tile<TILE_W, EVEN_HALF, true, DEPTH, FUSE_SHADE, 2>(a, bl, (int)blockIdx.y, (int)blockIdx.x, st);
+}
+#endif  // GCFR_EXPERIMENTAL_SCHEDULES
 
 }  // namespace gcfr
 
@@ -1418,8 +1577,12 @@ static inline int launch_status()
 
 extern "C" const char *gcfr_version(void)
 {
-#ifdef GCFR_COUNTERS
+#if defined(GCFR_COUNTERS) && defined(GCFR_EXPERIMENTAL_SCHEDULES)
+    return "gcfr-hip 0.2.0 gfx950 +counters +schedules";
+#elif defined(GCFR_COUNTERS)
     return "gcfr-hip 0.2.0 gfx950 +counters";
+#elif defined(GCFR_EXPERIMENTAL_SCHEDULES)
+    return "gcfr-hip 0.2.0 gfx950 +schedules";
 #else
     return "gcfr-hip 0.2.0 gfx950";
 #endif
@@ -1470,8 +1633,12 @@ static int resolve_options(const gcfr_options *opt, Knobs &k)
     const int tw = opt->tile_w, g = opt->group;
     if ((tw != 0 && tw != 8 && tw != 16 && tw != 32 && tw != 64) || (g != 0 && g != 1 && g != 2 && g != 4) ||
         opt->ksplit < -1 || opt->ksplit > 1 || opt->depth_bound_skip < -1 || opt->depth_bound_skip > 1 ||
-        opt->schedule < -1 || opt->schedule > 3 || opt->tile_order < -1 || opt->tile_order > 3)
+        opt->schedule < -1 || opt->schedule > 4 || opt->tile_order < -1 || opt->tile_order > 4)
         return GCFR_ERR_INVALID_ARGUMENT;
+#ifndef GCFR_EXPERIMENTAL_SCHEDULES
+    if (opt->schedule > 0)
+        return GCFR_ERR_INVALID_ARGUMENT;  // the alternatives to the grid exist in experimental builds only
+#endif
     k.tile_w = tw;
     k.group = g ? g : 4;
     k.ksplit = opt->ksplit;
@@ -1520,7 +1687,7 @@ static int device_cu_count()
     return n;
 }
 
-enum Schedule { kGrid = kSchedGrid, kQueue = kSchedQueue, kStrided = kSchedStrided, kGridOrdered = kSchedGridOrdered, kKSplit };
+enum Schedule { kGrid = kSchedGrid, kQueue = kSchedQueue, kStrided = kSchedStrided, kGridOrdered = kSchedGridOrdered, kCoop = 4, kKSplit };
 
 template <int TILE_W, int DEPTH, bool FUSE>
 static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argmin, Schedule sch, dim3 grid,
@@ -1553,12 +1720,26 @@ static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argm
             else
                 GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, false, false, DEPTH, FUSE);
         }
+#ifdef GCFR_EXPERIMENTAL_SCHEDULES
+    } else if (sch == kCoop) {
+        if (even_half) {
+            if (want_argmin)
+                GCFR_LAUNCH(shadow_fwd_quad_coop_argmin_kernel, true, DEPTH, FUSE);
+            else
+                GCFR_LAUNCH(shadow_fwd_quad_coop_kernel, true, DEPTH, FUSE);
+        } else {
+            if (want_argmin)
+                GCFR_LAUNCH(shadow_fwd_quad_coop_argmin_kernel, false, DEPTH, FUSE);
+            else
+                GCFR_LAUNCH(shadow_fwd_quad_coop_kernel, false, DEPTH, FUSE);
+        }
     } else if (sch == kQueue) {
         GCFR_LAUNCH_SCHED(kSchedQueue);
     } else if (sch == kStrided) {
         GCFR_LAUNCH_SCHED(kSchedStrided);
     } else if (sch == kGridOrdered) {
         GCFR_LAUNCH_SCHED(kSchedGridOrdered);
+#endif
     } else {
         GCFR_LAUNCH_SCHED(kSchedGrid);
     }
@@ -1600,7 +1781,7 @@ static void launch_quad(ShadowQuadArgs a, bool even_half, bool want_argmin, int 
     } else if (sch == kGridOrdered) {
         one(dim3((unsigned)(((long long)a.total_tiles + 3) / 4)));
     } else {
-        const unsigned gx = sch == kKSplit ? (unsigned)a.tiles_x : (unsigned)((a.tiles_x + 3) / 4);
+        const unsigned gx = (sch == kKSplit || sch == kCoop) ? (unsigned)a.tiles_x : (unsigned)((a.tiles_x + 3) / 4);
         for (int z0 = 0; z0 < total_bl; z0 += 65535) {  // grid z is limited to 65535 (image, light) pairs per launch
             a.bl_offset = z0;
             one(dim3(gx, (unsigned)a.tiles_y, (unsigned)((total_bl - z0) < 65535 ? (total_bl - z0) : 65535)));

@@ -51,20 +51,21 @@ typedef struct gcfr_options {
     int32_t group;             /* samples per skip group: 1, 2 or 4; 0 = auto (4) */
     int32_t ksplit;            /* split each tile's sample range over the 4 waves of a workgroup: 0, 1, -1 = auto by launch size */
     int32_t depth_bound_skip;  /* exact depth-bound group skip: 0, 1, -1 = auto (on) */
-    int32_t schedule;          /* how tiles reach waves: 0 = 3-D grid, one workgroup per four adjacent tiles, image-major;
-                                  1 = persistent waves (as many as the chip holds), first tile by wave index, further
-                                  tiles from a device-side atomic queue; 2 = persistent waves, strided static assignment;
-                                  3 = 1-D grid in queue order (tile_order); -1 = auto */
-    int32_t tile_order;        /* queue order of schedules 1-3: 0 = image-major, row-major tiles; 1 = image-major, centre
-                                  rows first; 2 = centre rows first across all images (heavy tiles first); 3 = image-major with
-                                  each image's tiles rotated by a different amount (mixes heavy and light tiles on
-                                  every SIMD); -1 = auto */
+    int32_t schedule;          /* how tiles reach waves: 0 (= -1, auto) the 3-D grid, one workgroup per four adjacent tiles,
+                                  image-major.  1 ... 4 select the alternatives round 2 measured and rejected (persistent
+                                  waves with an atomic tile queue / strided assignment, a 1-D grid in `tile_order`, four
+                                  cooperating waves per tile; profiles/r02_schedule_experiments.md): they exist only in a
+                                  library built with -DGCFR_EXPERIMENTAL_SCHEDULES (gcfr_version() then contains
+                                  "+schedules"), otherwise GCFR_ERR_INVALID_ARGUMENT */
+    int32_t tile_order;        /* queue order of the experimental schedules 1-3 (0 ... 4), ignored by the grid; -1 = auto */
     int32_t reserved;
     void *event_start;         /* hipEvent_t recorded on `stream` immediately before the march kernel, or NULL */
     void *event_stop;          /* hipEvent_t recorded immediately after it, or NULL */
-    uint64_t *counters;        /* DEVICE array of GCFR_N_COUNTERS u64 the march kernel adds its work counts to (executed
-                                  groups, bound tests, ...; tools/count_work.py); only a library built with
-                                  -DGCFR_COUNTERS touches it (gcfr_version() then ends in "+counters"), else ignored */
+    uint64_t *counters;        /* DEVICE array of GCFR_N_COUNTERS + 4 * (number of tiles) u64: the march kernel adds its work
+                                  counts (executed groups, bound tests, ...; tools/count_work.py) to the first
+                                  GCFR_N_COUNTERS and writes a 4-word timeline record per tile behind them
+                                  (tools/trace_timeline.py); only a library built with -DGCFR_COUNTERS touches it
+                                  (gcfr_version() then ends in "+counters"), else ignored */
 } gcfr_options;
 
 /* Fills `opt` with the defaults (struct_size set, every knob "auto", no hooks). */

@@ -66,6 +66,8 @@ def test_options_struct_defaults_and_layout():
     assert L.gcfr_shadow_fwd(*args, ctypes.byref(bad)) == -1
     bad = _lib.options(schedule=7)
     assert L.gcfr_shadow_fwd(*args, ctypes.byref(bad)) == -1
+    if not _lib.has_experimental_schedules():          # the product build has the grid schedule only
+        assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(schedule=2))) == -1
 
 
 def test_product_has_no_cpu_fallback():

@@ -45,6 +45,11 @@ def camera(f, Hh, Ww):
 CASES = list(all_cases())
 
 
+def _experimental():
+    from geomconsistentfr_amd import _lib
+    return _lib.has_experimental_schedules()
+
+
 @pytest.mark.parametrize("name,case", CASES, ids=[c[0] for c in CASES])
 def test_minimum_distance_and_argmin_match_the_reference(name, case):
     """HIP workspace kernel vs what the reference's torch.min returned.  Bit-equal except where torch-CPU's
@@ -96,7 +101,7 @@ def test_config5_full_shape_18_lights_512_320():
     assert np.abs(out["rendered_images"].cpu().numpy() - ref["rendered"]).max() <= 1e-6
     # every schedule gives the same bits at this shape too (16 x 4 tiles, 4096 tiles per light)
     from geomconsistentfr_amd import _lib
-    for sched, order in ((0, 0), (1, 2), (2, 2), (3, 1)):
+    for sched, order in (((0, 0), (1, 2), (2, 2), (3, 4), (4, -1)) if _experimental() else ((0, 0),)):
         o2 = R.render_fwd(to_dev(depth), to_dev(mask), to_dev(light), to_dev(amb), to_dev(normals), to_dev(albedo), prm,
                           want_argmin=True, options=_lib.options(schedule=sched, tile_order=order))
         assert torch.equal(o2["minimum_distance"], out["minimum_distance"]) and torch.equal(o2["argmin"], out["argmin"])
@@ -160,7 +165,8 @@ def test_soak_slice_is_bit_exact():
     distances 30 ... 1e5): minimum distance AND argmin bit-equal to the C oracle on every unmasked pixel."""
     import soak_parity
     from geomconsistentfr_amd import _lib
-    for opt in (None, _lib.options(schedule=0), _lib.options(schedule=1, tile_order=2), _lib.options(schedule=3, tile_order=1)):
+    extra = [_lib.options(schedule=4), _lib.options(schedule=1, tile_order=2), _lib.options(schedule=3, tile_order=4)] if _experimental() else []
+    for opt in [None, _lib.options(tile_w=16, group=2)] + extra:
         r = soak_parity.run_soak(200 if opt is None else 40, seed=20260928, options=opt)
         assert r["pixels_compared"] > (2_000_000 if opt is None else 300_000)
         assert r["lit_mask_mismatches"] == 0 and r["argmin_differences"] == 0, r
@@ -205,9 +211,9 @@ def test_adversarial_surfaces_for_the_depth_bound_skip(light_distance):
     pt_o = c_oracle.light_prep(lights.reshape(-1, 3), clamp_z_min=0.0, light_distance=light_distance)[1].reshape(B, 3, 3)
     md_o, am_o = c_oracle.shadow_min_distance(depth, mask, pt_o, c_oracle.sample_table(0.025, 0.8 / N, N))
     lit = md_o < 1e5
-    for tw, sched in ((0, -1), (8, 0), (16, 1), (32, 2), (64, 3), (8, 2)):
+    for tw, sched in ((0, -1), (8, 0), (16, 0), (32, 0), (64, 0)) + (((8, 4), (16, 4), (16, 1), (32, 2), (64, 3), (8, 2)) if _experimental() else ()):
         md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm,
-                                     options=_lib.options(tile_w=tw, schedule=sched, ksplit=0, tile_order=2 if sched > 0 else -1))
+                                     options=_lib.options(tile_w=tw, schedule=sched, ksplit=0, tile_order=2 if sched in (1, 2, 3) else -1))
         md, am = md.cpu().numpy(), am.cpu().numpy()
         bad = np.argwhere(md != md_o)
         assert bad.size == 0, (tw, sched, list(surf)[bad[0][0]], bad[:3].tolist())
@@ -223,7 +229,7 @@ def test_two_host_threads_two_streams_different_options():
     B, L, Hs, Ws = 4, 2, 128, 128
     r, c = np.mgrid[0:Hs, 0:Ws]
     prm = RenderParams(n_samples=96, dt=0.008)
-    opts = [_lib.options(tile_w=8, schedule=2, tile_order=2), _lib.options(tile_w=32, schedule=1, depth_bound_skip=0, group=2)]
+    opts = [_lib.options(tile_w=8, ksplit=0), _lib.options(tile_w=32, depth_bound_skip=0, group=2)]
     batches, refs = [], []
     for s in range(2):
         depth = (30 * np.exp(-(((c - 60 - 9 * s) / 30.0) ** 2 + ((r - 64) / 35.0) ** 2)) + rng.random((B, Hs, Ws))).astype(np.float32)

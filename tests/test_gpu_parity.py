@@ -26,6 +26,14 @@ def dev():
     return torch.device("cuda:0")
 
 
+def _sched(cases):
+    """Keep the (.., schedule, ..) cases the loaded library can run: the alternatives to the grid schedule exist only in
+    experimental builds (tools/build_variant.sh experimental -DGCFR_EXPERIMENTAL_SCHEDULES; run the suite with
+    GCFR_HIP_LIB pointing at it to cover them)."""
+    from geomconsistentfr_amd import _lib
+    return cases if _lib.has_experimental_schedules() else [c for c in cases if max(c[1] if isinstance(c, tuple) else c, 0) == 0]
+
+
 def to_dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
 
@@ -212,7 +220,7 @@ def test_sample_range_split_is_bit_identical(N):
     prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
     _, pt = light_prep(to_dev(lights), prm)
     ref_md, ref_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=False)
-    for ks, sched in ((0, 0), (0, 1), (0, 2), (0, 3), (1, -1)):   # grid, tile queue, strided, ordered grid, k-split
+    for ks, sched in _sched([(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (1, -1)]):   # grid, tile queue, strided, ordered grid, cooperative, k-split
         md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True,
                                      options=_lib.options(ksplit=ks, schedule=sched))
         assert torch.equal(md, ref_md), (ks, sched)
@@ -251,7 +259,7 @@ def test_mask_bounding_box_pruning_is_exact(Hs, Ws, N):
     prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
     _, pt = light_prep(to_dev(lights), prm)
     ref_md, ref_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=False)
-    for ks, sched, order in ((0, 0, 0), (0, 1, 0), (0, 1, 1), (0, 2, 2), (0, 2, 0), (0, 3, 2), (0, 3, 1), (1, -1, -1)):
+    for ks, sched, order in _sched([(0, 0, 0), (0, 1, 0), (0, 1, 1), (0, 2, 2), (0, 2, 0), (0, 3, 2), (0, 3, 4), (0, 4, -1), (1, -1, -1)]):
         md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True,
                                      options=_lib.options(ksplit=ks, schedule=sched, tile_order=order))
         bad = (md != ref_md).nonzero()
@@ -391,7 +399,7 @@ def test_depth_bound_skip_is_exact_for_every_tile_shape(Hs, Ws, N, dt):
     for zb in (1, 0):
         for tw in (8, 16, 32, 64):
             for grp in ((4, 2, 1) if tw == 8 else (4,)):
-                for sched in ((2, 0, 1, 3) if grp == 4 else (2,)):
+                for sched in [c[1] for c in _sched([(0, x) for x in ((0, 4, 2, 1, 3) if grp == 4 else (0, 4))])]:
                     opt = _lib.options(depth_bound_skip=zb, tile_w=tw, group=grp, schedule=sched, ksplit=0)
                     md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True, options=opt)
                     assert torch.equal(md, ref_md), (zb, tw, grp, sched)

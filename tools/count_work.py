@@ -26,6 +26,13 @@ from geomconsistentfr_amd import RenderParams, _lib  # noqa: E402
 from geomconsistentfr_amd import block as R  # noqa: E402
 
 
+def knobs_tile_w(tune, size):
+    for kv in tune.split(","):
+        if kv.startswith("tile_w=") and int(kv[7:]):
+            return int(kv[7:])
+    return 8 if size <= 256 else 16          # the library's auto rule with the depth-bound skip on
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--faces", type=int, default=8)
@@ -54,13 +61,15 @@ def main():
     if a.depth_noise > 0:
         depth = depth + (a.depth_noise * np.random.default_rng(7).random(depth.shape)).astype(np.float32)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
-    counters = torch.zeros(_lib.N_COUNTERS, dtype=torch.int64, device=dev)
+    tile_w = knobs_tile_w(a.tune, S)
+    n_tiles = B * L * ((S + tile_w - 1) // tile_w) * ((S + 64 // tile_w - 1) // (64 // tile_w))
+    counters = torch.zeros(_lib.N_COUNTERS + 4 * n_tiles, dtype=torch.int64, device=dev)   # tallies + per-tile records
     knobs = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)}
     opt = _lib.options(**knobs, counters=counters.data_ptr())
     R.render_fwd(t(depth), t(mask), t(light).reshape(B, L, 3), t(amb).reshape(B, L), t(normals), t(albedo), prm,
                  want_argmin=a.argmin, options=opt)
     torch.cuda.synchronize()
-    c = dict(zip(_lib.COUNTER_NAMES, counters.cpu().tolist()))
+    c = dict(zip(_lib.COUNTER_NAMES, counters[:_lib.N_COUNTERS].cpu().tolist()))
     group = knobs.get("group", 0) or 4
     nominal = B * L * S * S * N
     out = {"library": ver, "workload": {"faces": B, "size": S, "lights": L, "samples": N, "mask": a.mask,
