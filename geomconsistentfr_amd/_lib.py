@@ -68,7 +68,7 @@ _SIGNATURES = {
     "gcfr_shade_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p]),
     "gcfr_shadow_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "gcfr_shade_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "gcfr_render_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _d, _d, _d, _d, _f, _i, _f, _p, _p, _p, _p, _p,
+    "gcfr_render_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _d, _d, _d, _d, _f, _i, _f, _p, _p, _p, _p, _p,
                              _p, _p, _p, _p, _p]),
     "gcfr_light_prep_bwd": (_i, [_p, _i, _i, _f, _f, _p, _p, _p, _p]),
 }

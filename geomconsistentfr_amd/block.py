@@ -436,7 +436,7 @@ class _RenderFromDepthFunction(torch.autograd.Function):
         ctx.params, ctx.cam = params, cam
         if need_grad:
             ctx.save_for_backward(depth3, albedo_c, light2, amb, o["light_pt"].reshape(B, 3), o["minimum_distance"],
-                                  o["argmin"])
+                                  o["argmin"], o["surface_normals"])
         md0 = o["minimum_distance"][:, 0]
         ctx.mark_non_differentiable(md0)
         return (o["shadow_mask_weights"][:, 0], o["full_shading"][:, 0], o["final_shading"][:, 0],
@@ -444,7 +444,7 @@ class _RenderFromDepthFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_w, g_full, g_fin, g_ren, g_unit, g_nrm, _g_md):
-        depth3, albedo, light2, amb, pt, md, am = ctx.saved_tensors
+        depth3, albedo, light2, amb, pt, md, am, nrm_fwd = ctx.saved_tensors
         prm, cam = ctx.params, ctx.cam
         L_ = _lib.load()
         B, H, W = depth3.shape
@@ -460,7 +460,8 @@ class _RenderFromDepthFunction(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = _stream_ptr(dev)
             _lib.check(L_.gcfr_render_bwd(depth3.data_ptr(), albedo.data_ptr(), pt.data_ptr(), amb.data_ptr(),
-                                          md.data_ptr(), am.data_ptr(), B, 1, H, W, prm.n_samples, tt.data_ptr(),
+                                          md.data_ptr(), am.data_ptr(), nrm_fwd.data_ptr(), B, 1, H, W, prm.n_samples,
+                                          tt.data_ptr(),
                                           fx, fy, cx, cy, z_off, 1, float(prm.directional_intensity),
                                           _opt_ptr(gw), _opt_ptr(gfull), _opt_ptr(gfin), _opt_ptr(gren), _opt_ptr(gnrm),
                                           grad_albedo.data_ptr(), grad_depth.data_ptr(), grad_pt.data_ptr(),

@@ -15,6 +15,8 @@
 // f64 atomic per block and component).
 #include "gcfr_device.hpp"
 
+#include <type_traits>
+
 #include "../../include/gcfr.h"
 
 #ifndef GCFR_BWD_INLINE
@@ -52,6 +54,48 @@ __device__ inline void block_reduce_atomic(double (&v)[NV], double *dst)
     __syncthreads();
 }
 
+// Wave-wide f64 sum with DPP row shifts / broadcasts (the 32-bit halves travel separately, v_add_f64 has no DPP
+// form): 6 steps x (2 v_mov_dpp + 1 v_add_f64) at VALU speed instead of 12 dependent ds_bpermute round trips.
+// Lanes with no source read 0 bits = +0.0.  The total ends up in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_add_step_f64(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return v + __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ inline double wave_sum_dpp(double v)
+{
+    v = dpp_add_step_f64<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add_step_f64<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add_step_f64<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add_step_f64<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row holds the row's sum
+    v = dpp_add_step_f64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add_step_f64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+    return v;
+}
+
+// Block-wide sum of the four per-(image, light) partials {dC.x, dC.y, dC.z, d ambient} -> one f64 atomicAdd each.
+__device__ inline void block_reduce_atomic4(double (&v)[4], double *dst_light3, double *dst_ambient)
+{
+    __shared__ double part[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double s = wave_sum_dpp(v[i]);
+        if (lane == 63)
+            part[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const double s = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (s != 0.0)
+            atomicAdd(threadIdx.x < 3 ? dst_light3 + threadIdx.x : dst_ambient, s);
+    }
+    __syncthreads();
+}
+
 // ----------------------------------------------------------------------------------------------
 // shadow backward
 // ----------------------------------------------------------------------------------------------
@@ -69,9 +113,14 @@ struct ShadowBwdArgs {
 // Backward of the ray march for ONE pixel and light: re-evaluates the argmin sample k and applies the chain
 // rule (see the file header).  g32 = dLoss/d minimum_distance.  Scatters the depth gradients (five f32 atomics
 // into gz, the image's grad_depth plane) and returns the light-point gradient in gC.
+struct CornerScatter {  // the four bilinear-corner depth gradients of one argmin sample, to be added atomically later
+    int idx[4];
+    float val[4];
+};
 __device__ GCFR_BWD_INLINE void shadow_bwd_pixel(const float *zimg, float *gz, const double *t_table, int H, int W,
                                         int r, int c, float Cx, float Cy, float Cz, int k, float g32,
-                                        double (&gC)[3])
+                                        double (&gC)[3], double *own_depth_grad = nullptr,
+                                        CornerScatter *defer = nullptr)
 {
     const size_t p = (size_t)r * W + c;
     const Box box = image_box(H, W);
@@ -138,15 +187,21 @@ __device__ GCFR_BWD_INLINE void shadow_bwd_pixel(const float *zimg, float *gz, c
     const double BAx = (double)(Axf - x), BAy = (double)(Ayf - y), BAz = (double)(Azf - zb);
     const double BCx = (double)(Cx - x), BCy = (double)(Cy - y), BCz = (double)(Cz - zb);
     const double Xx = BAy * BCz - BAz * BCy, Xy = BAz * BCx - BAx * BCz, Xz = BAx * BCy - BAy * BCx;
-    const double num = sqrt(Xx * Xx + Xy * Xy + Xz * Xz + 1e-4);
-    const double den = sqrt(BCx * BCx + BCy * BCy + BCz * BCz + 1e-4);
+  {  // everything below is backward-only arithmetic (compared under tolerances): fused multiply-adds, fast sqrt / 1/x
+#pragma clang fp contract(fast)
+    const double num = fast_sqrt64(Xx * Xx + Xy * Xy + Xz * Xz + 1e-4);
+    const double den = fast_sqrt64(BCx * BCx + BCy * BCy + BCz * BCz + 1e-4);
 
     // ---- chain rule ----
+    // (reciprocal-multiply instead of IEEE divisions from here on: gradients are compared under tolerances, and an
+    // f64 division costs ~17 instructions against 5 for fast_rcp64; the recomputation above stays exact because it
+    // must reproduce the forward's decisions)
     const double g = (double)g32;
-    const double dnum = g / den, dden = -g * num / (den * den);
-    const double s1 = dnum / num;  // d(|X|^2+eps)^(1/2) = X/num
+    const double inv_den = fast_rcp64(den), inv_num = fast_rcp64(num);
+    const double dnum = g * inv_den, dden = -g * num * (inv_den * inv_den);
+    const double s1 = dnum * inv_num;  // d(|X|^2+eps)^(1/2) = X/num
     const double dXx = s1 * Xx, dXy = s1 * Xy, dXz = s1 * Xz;
-    const double s2 = dden / den;
+    const double s2 = dden * inv_den;
     double dBCx = s2 * BCx, dBCy = s2 * BCy, dBCz = s2 * BCz;
     // X = BA x BC:  dBA = BC x dX ;  dBC += dX x BA
     const double dBAx = BCy * dXz - BCz * dXy;
@@ -174,23 +229,39 @@ __device__ GCFR_BWD_INLINE void shadow_bwd_pixel(const float *zimg, float *gz, c
         dm = dEy * (double)xb;
         dic = dEy;
     } else if (kind == 2) {  // E = ((yb - ic)/(m + e), yb)
-        const double q = (double)(m + kEps4);
-        dic = -dEx / q;
-        dm = -dEx * (double)ux_raw / q;
+        const double inv_q = fast_rcp64((double)(m + kEps4));
+        dic = -dEx * inv_q;
+        dm = -dEx * (double)ux_raw * inv_q;
     }
     // ic = Cy - m*Cx ;  m = (Cy - y)/(Cx - x + e)
     gC[1] += dic;
     dm += -dic * (double)Cx;
     gC[0] += -dic * (double)m;
-    gC[1] += dm / (double)pden;
-    gC[0] += -dm * (double)m / (double)pden;
+    const double inv_pden = fast_rcp64((double)pden);
+    gC[1] += dm * inv_pden;
+    gC[0] += -dm * (double)m * inv_pden;
 
     // depth: four bilinear corners + the pixel's own depth
-    atomicAdd(gz + iUL, (float)(dzA * wx0 * wy0));
-    atomicAdd(gz + iUR, (float)(dzA * wx1 * wy0));
-    atomicAdd(gz + iLL, (float)(dzA * wx0 * wy1));
-    atomicAdd(gz + iLR, (float)(dzA * wx1 * wy1));
-    atomicAdd(gz + p, (float)dzb);
+    if (defer) {  // the caller issues them after its last barrier (a barrier waits for every outstanding atomic)
+        defer->idx[0] = (int)iUL;
+        defer->idx[1] = (int)iUR;
+        defer->idx[2] = (int)iLL;
+        defer->idx[3] = (int)iLR;
+        defer->val[0] = (float)(dzA * wx0 * wy0);
+        defer->val[1] = (float)(dzA * wx1 * wy0);
+        defer->val[2] = (float)(dzA * wx0 * wy1);
+        defer->val[3] = (float)(dzA * wx1 * wy1);
+    } else {
+        atomicAdd(gz + iUL, (float)(dzA * wx0 * wy0));
+        atomicAdd(gz + iUR, (float)(dzA * wx1 * wy0));
+        atomicAdd(gz + iLL, (float)(dzA * wx0 * wy1));
+        atomicAdd(gz + iLR, (float)(dzA * wx1 * wy1));
+    }
+    if (own_depth_grad)
+        *own_depth_grad += dzb;  // the caller folds it into its single own-pixel atomic
+    else
+        atomicAdd(gz + p, (float)dzb);
+  }
 }
 
 __global__ __launch_bounds__(256) void shadow_bwd_kernel(ShadowBwdArgs a)
@@ -237,8 +308,12 @@ struct ShadeBwdArgs {
     const float *g_normals_out;  // (B,3,H,W) upstream grad on the returned unit normals, may be null
 };
 
+#ifndef GCFR_BWD_WAVES_PER_EU
+#define GCFR_BWD_WAVES_PER_EU 2
+#endif
 template <bool FUSED>
-__global__ __launch_bounds__(256) void shade_bwd_kernel(ShadeBwdArgs a)
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(FUSED ? GCFR_BWD_WAVES_PER_EU : 4))) void shade_bwd_kernel(ShadeBwdArgs a)
 {
     const int H = a.H, W = a.W, L = a.L;
     const size_t P = (size_t)H * W;
@@ -254,7 +329,7 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(ShadeBwdArgs a)
     double nx, ny, nz;
     if (FUSED) {  // the f32 unit normal the forward epilogue fed to shade_pixel()
         float n[3];
-        unit_normal(a.nrm, zimg, r, c, n);
+        unit_normal<true>(a.nrm, zimg, r, c, n);
         nx = n[0];
         ny = n[1];
         nz = n[2];
@@ -265,7 +340,8 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(ShadeBwdArgs a)
     }
     double nn = sqrt(nx * nx + ny * ny + nz * nz);
     nn = nn > 1e-12 ? nn : 1e-12;
-    const double n0 = nx / nn, n1 = ny / nn, n2 = nz / nn;
+    const double inv_nn = fast_rcp64(nn);
+    const double n0 = nx * inv_nn, n1 = ny * inv_nn, n2 = nz * inv_nn;
     const double al0 = a.albedo[((size_t)b * 3 + 0) * P + pp];
     const double al1 = a.albedo[((size_t)b * 3 + 1) * P + pp];
     const double al2 = a.albedo[((size_t)b * 3 + 2) * P + pp];
@@ -283,13 +359,14 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(ShadeBwdArgs a)
             const double lx = Cx - x, ly = Cy - y, lz = Cz - zb;
             double ln = sqrt(lx * lx + ly * ly + lz * lz);
             ln = ln > 1e-12 ? ln : 1e-12;
-            const double u0 = lx / ln, u1 = ly / ln, u2 = lz / ln;
+            const double inv_ln = fast_rcp64(ln);
+            const double u0 = lx * inv_ln, u1 = ly * inv_ln, u2 = lz * inv_ln;
             const double dot = n0 * u0 + n1 * u1 + n2 * u2;
             const double full = amb + (double)a.intensity * (dot > 0.0 ? dot : 0.0);
-            const double d = a.min_dist[o];
-            const double e = exp(-d);
+            const double e = (double)expf(-a.min_dist[o]);  // the forward evaluates the transfer function in f32 too (T8:517)
             const double ope = 1.0 + e;
-            const double w = 1.0 - 4.0 * e / (ope * ope);
+            const double inv_ope = fast_rcp64(ope), inv_ope2 = inv_ope * inv_ope;
+            const double w = 1.0 - 4.0 * e * inv_ope2;
             const double fin = w * full + (1.0 - w) * amb;
             // upstream
             const double gr0 = a.g_rendered ? (double)a.g_rendered[((size_t)bl * 3 + 0) * P + pp] : 0.0;
@@ -304,7 +381,7 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(ShadeBwdArgs a)
             const double dfull = dfin * w + (a.g_full ? (double)a.g_full[o] : 0.0);
             red[3] = dfin * (1.0 - w) + dfull;  // ambient enters final directly and through full
             // w = 1 - 4e/(1+e)^2, e = exp(-d):  dw/dd = 4e(1-e)/(1+e)^3  (T8:517)
-            const float gmd = (float)(dw * (4.0 * e * (1.0 - e)) / (ope * ope * ope));
+            const float gmd = (float)(dw * (4.0 * e * (1.0 - e)) * (inv_ope2 * inv_ope));
             if (a.grad_min_dist)
                 a.grad_min_dist[o] = gmd;
             if (FUSED) {  // ray-march backward through the argmin sample, right here
@@ -324,22 +401,19 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(ShadeBwdArgs a)
             const double du0 = ddot * n0, du1 = ddot * n1, du2 = ddot * n2;  // d l_hat
             // n_hat = n/|n|
             const double nd = n0 * dn0 + n1 * dn1 + n2 * dn2;
-            gn0 += (dn0 - n0 * nd) / nn;
-            gn1 += (dn1 - n1 * nd) / nn;
-            gn2 += (dn2 - n2 * nd) / nn;
+            gn0 += (dn0 - n0 * nd) * inv_nn;
+            gn1 += (dn1 - n1 * nd) * inv_nn;
+            gn2 += (dn2 - n2 * nd) * inv_nn;
             // l_hat = l/|l|, l = C - P
             const double ud = u0 * du0 + u1 * du1 + u2 * du2;
-            const double dl0 = (du0 - u0 * ud) / ln, dl1 = (du1 - u1 * ud) / ln, dl2 = (du2 - u2 * ud) / ln;
+            const double dl0 = (du0 - u0 * ud) * inv_ln, dl1 = (du1 - u1 * ud) * inv_ln, dl2 = (du2 - u2 * ud) * inv_ln;
             red[0] += dl0;
             red[1] += dl1;
             red[2] += dl2;
             gzb -= dl2;
         }
-        // per-(image, light) reductions: light point and ambient
-        double red3[3] = {red[0], red[1], red[2]};
-        block_reduce_atomic<3>(red3, a.grad_light_pt + 3 * (size_t)bl);
-        double red1[1] = {red[3]};
-        block_reduce_atomic<1>(red1, a.grad_ambient + bl);
+        // per-(image, light) reductions: light point (3) and ambient (1), one pass through LDS
+        block_reduce_atomic4(red, a.grad_light_pt + 3 * (size_t)bl, a.grad_ambient + bl);
     }
     if (live) {
         if (FUSED) {  // stencil backward: grad w.r.t. the unit normal (rounded to f32 as the unfused path stores it)
@@ -360,6 +434,281 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(ShadeBwdArgs a)
         a.grad_albedo[((size_t)b * 3 + 2) * P + p] = (float)ga2;
         atomicAdd(gz + p, (float)gzb);
     }
+}
+
+// ----------------------------------------------------------------------------------------------
+// fused backward, one light per image (the training shape: T8 has one predicted light per face)
+//
+// Same per-pixel device functions and the same numbers as shade_bwd_kernel<true>, but staged so that each phase
+// keeps only its own operands alive: (1) shading backward -- writes grad_albedo at once and leaves three f32 normal
+// gradients, the own-depth term, the four reduction partials and the f32 gradient on the minimum distance;
+// (2) ray-march backward through the argmin sample; (3) block reduction; (4) normals-stencil backward.  The
+// general kernel runs (1)-(2) inside a loop over lights, which keeps every loop-invariant (unit normal, albedo,
+// accumulators in f64) alive across the inlined march backward: 232 VGPRs, two waves per SIMD.
+// ----------------------------------------------------------------------------------------------
+#ifdef GCFR_BWD_TRACE   // debug build: per-wave stage stamps of render_bwd_single_light_kernel (tools/bwd_stage_trace.py)
+__device__ unsigned long long *g_bwd_trace = nullptr;
+#define GCFR_BWD_STAMP(i) (stamp[i] = __builtin_amdgcn_s_memrealtime())
+#else
+#define GCFR_BWD_STAMP(i) ((void)0)
+#endif
+
+#ifndef GCFR_BWD1_WAVES_PER_EU
+#define GCFR_BWD1_WAVES_PER_EU 4
+#endif
+constexpr int kBwdTileW = 32, kBwdTileH = 8;  // 256 threads
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(GCFR_BWD1_WAVES_PER_EU, GCFR_BWD1_WAVES_PER_EU))) void render_bwd_single_light_kernel(ShadeBwdArgs a)
+{
+    const int H = a.H, W = a.W;
+    const size_t P = (size_t)H * W;
+    const int b = blockIdx.y;  // == the (image, light) index: L = 1
+    // One workgroup marches over several kBwdTileW x kBwdTileH pixel tiles (rows of 32 f32 = whole 128-B lines) of ONE
+    // image: tiles, so that the stencil backward can exchange most of its eight-neighbour contributions through LDS
+    // instead of global atomics; several, so that the per-image light / ambient gradients (four f64 atomics per
+    // workgroup, all workgroups of an image on the same two cache lines, ~20 ns each when they queue on one line)
+    // are issued once per `tiles per workgroup` tiles -- with one tile per workgroup that queue alone was 80 us long.
+    const int tiles_x = (W + kBwdTileW - 1) / kBwdTileW;
+    const int n_tiles = tiles_x * ((H + kBwdTileH - 1) / kBwdTileH);
+    const int ty = (int)threadIdx.x / kBwdTileW, tx = (int)threadIdx.x - ty * kBwdTileW;
+    const float *zimg = a.depth + (size_t)b * P;
+    float *gz = a.grad_depth + (size_t)b * P;
+    const float Cxf = a.light_pt[3 * b + 0], Cyf = a.light_pt[3 * b + 1], Czf = a.light_pt[3 * b + 2];
+    __shared__ double s_dd[6][256];
+    __shared__ double s_part[4][4];
+    double red[4] = {0.0, 0.0, 0.0, 0.0};  // dC.xyz, d ambient: accumulated over this workgroup's tiles
+
+#ifdef GCFR_BWD_TRACE
+    unsigned long long stamp[8] = {};
+    unsigned long long acc[8] = {};
+#endif
+  for (int tile = (int)blockIdx.x; tile < n_tiles; tile += (int)gridDim.x) {
+    GCFR_BWD_STAMP(0);
+    const int tile_r = tile / tiles_x, tile_c = tile - tile_r * tiles_x;
+    const int r_raw = tile_r * kBwdTileH + ty, c_raw = tile_c * kBwdTileW + tx;
+    const bool live = (r_raw < H) && (c_raw < W);
+    const int r = live ? r_raw : 0, c = live ? c_raw : 0;
+    const size_t pp = (size_t)r * W + c, p = pp;
+    float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f;  // gradient on the unit normal, rounded to f32 as the unfused path stores it
+    float gmd = 0.0f;
+    double gzb = 0.0;
+    if (live) {  // ---- (1) shading backward ----
+#pragma clang fp contract(fast)  // backward-only arithmetic (compared under tolerances)
+        // f32: the forward evaluates this stage in f32 (shade_pixel), and every result leaves it as f32 (grad_albedo,
+        // the normal gradient handed to the stencil, the gradient on the minimum distance) or enters an f64 sum
+        // over 65 536 pixels (light, ambient); an f64 VALU op costs 1.6x an f32 one here and twice the registers.
+        const size_t o = (size_t)b * P + pp;
+        const float gr0 = a.g_rendered ? a.g_rendered[((size_t)b * 3 + 0) * P + pp] : 0.0f;
+        const float gr1 = a.g_rendered ? a.g_rendered[((size_t)b * 3 + 1) * P + pp] : 0.0f;
+        const float gr2 = a.g_rendered ? a.g_rendered[((size_t)b * 3 + 2) * P + pp] : 0.0f;
+        const float gfin = a.g_final ? a.g_final[o] : 0.0f, gw = a.g_w ? a.g_w[o] : 0.0f, gfull = a.g_full ? a.g_full[o] : 0.0f;
+        // A pixel nothing upstream depends on (the training losses mask the rendered image: about half of a face
+        // batch) contributes exactly zero to every gradient of this stage and of the march backward.
+        if (gr0 != 0.0f || gr1 != 0.0f || gr2 != 0.0f || gfin != 0.0f || gw != 0.0f || gfull != 0.0f) {
+            const float x = (float)c - W / 2.0f, y = H / 2.0f - (float)r;
+            const float zb = zimg[pp];
+            float n[3];
+            if (a.normals) {  // the unit normals the forward wrote (normals_out): no second stencil evaluation
+                n[0] = a.normals[((size_t)b * 3 + 0) * P + pp];
+                n[1] = a.normals[((size_t)b * 3 + 1) * P + pp];
+                n[2] = a.normals[((size_t)b * 3 + 2) * P + pp];
+            } else {
+                unit_normal<true>(a.nrm, zimg, r, c, n);
+            }
+            float nn = __builtin_sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            nn = nn > 1e-12f ? nn : 1e-12f;
+            const float inv_nn = 1.0f / nn;
+            const float n0 = n[0] * inv_nn, n1 = n[1] * inv_nn, n2 = n[2] * inv_nn;
+            const float amb = a.ambient[b];
+            const float lx = Cxf - x, ly = Cyf - y, lz = Czf - zb;
+            float ln = __builtin_sqrtf(lx * lx + ly * ly + lz * lz);
+            ln = ln > 1e-12f ? ln : 1e-12f;
+            const float inv_ln = 1.0f / ln;
+            const float u0 = lx * inv_ln, u1 = ly * inv_ln, u2 = lz * inv_ln;
+            const float dot = n0 * u0 + n1 * u1 + n2 * u2;
+            const float full = amb + a.intensity * (dot > 0.0f ? dot : 0.0f);
+            const float e = expf(-a.min_dist[o]);  // T8:517
+            const float ope = 1.0f + e;
+            const float inv_ope = 1.0f / ope, inv_ope2 = inv_ope * inv_ope;
+            const float w = 1.0f - 4.0f * e * inv_ope2;
+            const float fin = w * full + (1.0f - w) * amb;
+            const float al0 = a.albedo[((size_t)b * 3 + 0) * P + pp];
+            const float al1 = a.albedo[((size_t)b * 3 + 1) * P + pp];
+            const float al2 = a.albedo[((size_t)b * 3 + 2) * P + pp];
+            a.grad_albedo[((size_t)b * 3 + 0) * P + p] = gr0 * fin;  // rendered = albedo * final  (T8:520-522)
+            a.grad_albedo[((size_t)b * 3 + 1) * P + p] = gr1 * fin;
+            a.grad_albedo[((size_t)b * 3 + 2) * P + p] = gr2 * fin;
+            const float dfin = (gr0 * al0 + gr1 * al1 + gr2 * al2) + gfin;
+            const float dw = dfin * (full - amb) + gw;  // final = w*full + (1-w)*amb (T8:518)
+            const float dfull = dfin * w + gfull;
+            red[3] += (double)(dfin * (1.0f - w) + dfull);  // ambient enters final directly and through full
+            gmd = dw * (4.0f * e * (1.0f - e)) * (inv_ope2 * inv_ope);  // dw/dd = 4e(1-e)/(1+e)^3 (T8:517)
+            const float ddot = (dot > 0.0f) ? dfull * a.intensity : 0.0f;  // full = amb + I*max(dot,0) (T8:366)
+            const float dn0 = ddot * u0, dn1 = ddot * u1, dn2 = ddot * u2;
+            const float du0 = ddot * n0, du1 = ddot * n1, du2 = ddot * n2;
+            const float nd = n0 * dn0 + n1 * dn1 + n2 * dn2;  // n_hat = n/|n|
+            h0 = (dn0 - n0 * nd) * inv_nn;
+            h1 = (dn1 - n1 * nd) * inv_nn;
+            h2 = (dn2 - n2 * nd) * inv_nn;
+            const float ud = u0 * du0 + u1 * du1 + u2 * du2;  // l_hat = l/|l|, l = C - P
+            const float dl2 = (du2 - u2 * ud) * inv_ln;
+            red[0] += (double)((du0 - u0 * ud) * inv_ln);
+            red[1] += (double)((du1 - u1 * ud) * inv_ln);
+            red[2] += (double)dl2;
+            gzb = -(double)dl2;
+        } else {
+            a.grad_albedo[((size_t)b * 3 + 0) * P + p] = 0.0f;
+            a.grad_albedo[((size_t)b * 3 + 1) * P + p] = 0.0f;
+            a.grad_albedo[((size_t)b * 3 + 2) * P + p] = 0.0f;
+        }
+    }
+    GCFR_BWD_STAMP(1);
+    CornerScatter corners = {{0, 0, 0, 0}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    bool have_corners = false;
+    if (live) {  // ---- (2) ray-march backward through the argmin sample (atomics deferred) ----
+        const int k = a.argmin[(size_t)b * P + pp];
+        if (k >= 0 && k < a.N && gmd != 0.0f) {
+            double gC[3];
+            shadow_bwd_pixel(zimg, gz, a.t_table, H, W, r, c, Cxf, Cyf, Czf, k, gmd, gC, &gzb, &corners);
+            have_corners = true;
+            red[0] += gC[0];
+            red[1] += gC[1];
+            red[2] += gC[2];
+        }
+    }
+    GCFR_BWD_STAMP(2);
+    // ---- (4) stencil backward: ONE barrier per tile, no global atomic in front of it (a barrier waits for every
+    // outstanding memory operation of the wave -- scattered atomics before it would be paid as latency by the whole
+    // workgroup).  The L2 executes f32 atomic elements at a finite rate and the scatter form costs 14 per pixel (8
+    // stencil neighbours, 4 bilinear corners, own pixel twice): gather form instead -- every pixel publishes its two
+    // stencil vectors in LDS, sums what its in-tile neighbours owe it and issues ONE atomic for its own depth; only
+    // contributions that cross the tile border (0.9 per pixel) and those of image-border pixels (replicate padding
+    // folds several offsets onto one target) remain scattered.
+    StencilGrad sg = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+    bool have_sg = false;
+    const bool on_image_border = (r == 0) || (c == 0) || (r == H - 1) || (c == W - 1);
+    if (live) {
+        double g0 = (double)h0, g1 = (double)h1, g2 = (double)h2;
+        if (a.g_normals_out) {
+            g0 += a.g_normals_out[((size_t)b * 3 + 0) * P + p];
+            g1 += a.g_normals_out[((size_t)b * 3 + 1) * P + p];
+            g2 += a.g_normals_out[((size_t)b * 3 + 2) * P + p];
+        }
+        if (g0 != 0.0 || g1 != 0.0 || g2 != 0.0) {  // (zero in, zero out: masked-out pixels skip the stencil)
+            sg = normals_bwd_terms(a.nrm, zimg, r, c, g0, g1, g2);
+            have_sg = true;
+        }
+    }
+    const bool via_lds = live && !on_image_border;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        s_dd[q][threadIdx.x] = via_lds ? sg.ddu[q] : 0.0;
+        s_dd[3 + q][threadIdx.x] = via_lds ? sg.ddv[q] : 0.0;
+    }
+    GCFR_BWD_STAMP(3);
+    __syncthreads();
+    GCFR_BWD_STAMP(4);
+    if (live) {
+        // what the in-tile neighbours owe this pixel: source = this pixel minus the offset
+        double Sx = 0.0, Sy = 0.0, Sz = 0.0;
+#pragma unroll
+        for (int dr = -1; dr <= 1; ++dr) {
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc) {
+                const double ku = kSobelU[dr + 1][dc + 1], kv = kSobelV[dr + 1][dc + 1];
+                if (ku == 0.0 && kv == 0.0)
+                    continue;
+                const int sy = ty - dr, sx = tx - dc;
+                if ((unsigned)sy < (unsigned)kBwdTileH && (unsigned)sx < (unsigned)kBwdTileW) {
+                    const int src = sy * kBwdTileW + sx;  // (a source on the image border or outside it published zeros)
+                    Sx += ku * s_dd[0][src] + kv * s_dd[3][src];
+                    Sy += ku * s_dd[1][src] + kv * s_dd[4][src];
+                    Sz += ku * s_dd[2][src] + kv * s_dd[5][src];
+                }
+            }
+        }
+        const double ax = ((double)c - a.nrm.cx) * fast_rcp64(a.nrm.fx), ay = ((double)r - a.nrm.cy) * fast_rcp64(a.nrm.fy);
+        atomicAdd(gz + p, (float)((ax * Sx + ay * Sy + Sz) + gzb));
+    }
+    // The four bilinear-corner atomics of the argmin samples were 78 of this kernel's 167 us: neighbouring pixels march
+    // nearly parallel rays, so at sample fraction t their samples are only (1 - t) texels apart and 2 ... 5 adjacent lanes
+    // hit the SAME texel -- the L2 serialises those.  Runs of adjacent lanes (inside aligned groups of 8) with identical
+    // corner addresses are therefore summed in registers first (segmented scan over DPP row shifts, 3 steps) and only the
+    // last lane of a run issues the atomics.  Wave-uniform code: every lane takes part, lanes without a sample form runs
+    // of their own.
+    {
+        const int lane = threadIdx.x & 63;
+        const int kx = corners.idx[1] - corners.idx[0], ky = (corners.idx[2] != corners.idx[0]) ? 1 : 0;
+        const int key = (live && have_corners) ? (corners.idx[0] | (kx << 28) | (ky << 29)) : (-1 - lane);
+        const int key_prev = __builtin_amdgcn_update_dpp(0, key, 0x111, 0xf, 0xf, true);  // row_shr:1
+        int head = ((lane & 7) == 0) || (key_prev != key);
+        float v0 = corners.val[0], v1 = corners.val[1], v2 = corners.val[2], v3 = corners.val[3];
+        auto shr = [](float v, auto ctrl) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+        };
+        auto step = [&](auto ctrl, int d) {
+            const float a0 = shr(v0, ctrl), a1 = shr(v1, ctrl), a2 = shr(v2, ctrl), a3 = shr(v3, ctrl);
+            const int hp = __builtin_amdgcn_update_dpp(1, head, decltype(ctrl)::value, 0xf, 0xf, false);
+            const bool take = ((lane & 7) >= d) && !head;
+            v0 = take ? v0 + a0 : v0;
+            v1 = take ? v1 + a1 : v1;
+            v2 = take ? v2 + a2 : v2;
+            v3 = take ? v3 + a3 : v3;
+            head = take ? (head | hp) : head;
+        };
+        step(std::integral_constant<int, 0x111>{}, 1);  // row_shr:1
+        step(std::integral_constant<int, 0x112>{}, 2);  // row_shr:2
+        step(std::integral_constant<int, 0x114>{}, 4);  // row_shr:4
+        // the run ends here if the next lane starts a new one (computed from the ORIGINAL keys)
+        const int key_next = __builtin_amdgcn_update_dpp(0, key, 0x101, 0xf, 0xf, true);   // row_shl:1
+        const bool last = ((lane & 7) == 7) || (key_next != key);
+        if (last && key >= 0) {
+            atomicAdd(gz + corners.idx[0], v0);
+            atomicAdd(gz + corners.idx[1], v1);
+            atomicAdd(gz + corners.idx[2], v2);
+            atomicAdd(gz + corners.idx[3], v3);
+        }
+    }
+    if (live) {
+        if (!have_sg) {
+            // nothing to scatter
+        } else if (on_image_border)  // clamped targets: all eight by atomics, as the stand-alone kernel does
+            normals_bwd_scatter(a.nrm, sg, gz, r, c, [](int, int) { return true; });
+        else                  // targets outside this tile only
+            normals_bwd_scatter(a.nrm, sg, gz, r, c, [&](int dr, int dc) {
+                return (unsigned)(ty + dr) >= (unsigned)kBwdTileH || (unsigned)(tx + dc) >= (unsigned)kBwdTileW;
+            });
+    }
+    GCFR_BWD_STAMP(5);
+    __syncthreads();  // s_dd is rewritten by the next tile
+    GCFR_BWD_STAMP(6);
+#ifdef GCFR_BWD_TRACE
+    for (int i = 0; i < 6; ++i)
+        acc[i] += stamp[i + 1] - stamp[i];
+    acc[6] += 1;
+#endif
+  }
+    // ---- (3) per-image reductions: light point (3) and ambient (1), once per workgroup ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double ws = wave_sum_dpp(red[i]);
+        if ((threadIdx.x & 63) == 63)
+            s_part[threadIdx.x >> 6][i] = ws;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const double sum = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+        if (sum != 0.0)
+            atomicAdd(threadIdx.x < 3 ? a.grad_light_pt + 3 * (size_t)b + threadIdx.x : a.grad_ambient + b, sum);
+    }
+#ifdef GCFR_BWD_TRACE
+    if (g_bwd_trace && (threadIdx.x & 63) == 0) {
+        unsigned long long *rec = g_bwd_trace + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8;
+        for (int i = 0; i < 7; ++i)
+            rec[i] = acc[i];
+        rec[7] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -472,7 +821,8 @@ extern "C" int gcfr_shade_bwd(const float *normals, const float *depth, const fl
 }
 
 extern "C" int gcfr_render_bwd(const float *depth, const float *albedo, const float *light_pt,
-                               const float *ambient, const float *min_dist, const int32_t *argmin, int32_t B,
+                               const float *ambient, const float *min_dist, const int32_t *argmin,
+                               const float *normals_fwd, int32_t B,
                                int32_t L, int32_t H, int32_t W, int32_t N, const double *t_table, double fx,
                                double fy, double cx, double cy, float z_offset, int32_t negate_y,
                                float intensity, const float *g_shadow_w, const float *g_full,
@@ -505,6 +855,7 @@ extern "C" int gcfr_render_bwd(const float *depth, const float *albedo, const fl
     a.W = W;
     a.intensity = intensity;
     a.argmin = argmin;
+    a.normals = (L == 1) ? normals_fwd : nullptr;  // (the multi-light kernel recomputes)
     a.t_table = t_table;
     a.N = N;
     a.nrm.depth = depth;
@@ -518,10 +869,27 @@ extern "C" int gcfr_render_bwd(const float *depth, const float *albedo, const fl
     a.nrm.negate_y = negate_y;
     a.g_normals_out = g_normals_out;
     const size_t P = (size_t)H * W;
-    hipLaunchKernelGGL(shade_bwd_kernel<true>, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0,
-                       (hipStream_t)stream, a);
+    if (L == 1)  // the training shape: staged kernel, higher occupancy (same device functions, same numbers)
+    {
+        // workgroups per image: enough to fill the chip about twice (256 CUs x 4 resident workgroups), at most one per tile
+        const int n_tiles = ((W + kBwdTileW - 1) / kBwdTileW) * ((H + kBwdTileH - 1) / kBwdTileH);
+        int per_image = (2048 + B - 1) / B;
+        per_image = per_image < 1 ? 1 : (per_image > n_tiles ? n_tiles : per_image);
+        hipLaunchKernelGGL(render_bwd_single_light_kernel, dim3((unsigned)per_image, (unsigned)B), dim3(256), 0,
+                           (hipStream_t)stream, a);
+    }
+    else
+        hipLaunchKernelGGL(shade_bwd_kernel<true>, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0,
+                           (hipStream_t)stream, a);
     return launch_status();
 }
+
+#ifdef GCFR_BWD_TRACE
+extern "C" int gcfr_debug_set_bwd_trace(unsigned long long *device_buffer)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(gcfr::g_bwd_trace), &device_buffer, sizeof(device_buffer)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int gcfr_light_prep_bwd(const float *light_raw, int32_t n, int32_t clamp_z, float clamp_min,
                                    float light_distance, const float *grad_unit,

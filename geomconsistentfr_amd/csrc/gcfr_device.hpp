@@ -153,19 +153,58 @@ struct Grad3 {
     double du[3], dv[3];
 };
 
+// 1/x to full f64 precision (<= 1 ulp) in 5 instructions instead of the ~17 of an IEEE division: v_rcp_f64 seed (about
+// 2^-26) and two Newton steps.  BACKWARD kernels only -- gradients are compared under tolerances, never bit for
+// bit -- and only for normal, non-zero x (norms clamped to >= 1e-12, focal lengths, distances).
+__device__ inline double fast_rcp64(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+    return r;
+}
+
+// sqrt(x) to ~1 ulp of f64 in 8 instructions instead of the ~30 of the IEEE routine: v_rsq_f64 seed and two coupled
+// Newton steps (Goldschmidt).  BACKWARD kernels only, x normal and > 0 (squared norms with a +1e-4 / >= 1e-24 floor).
+__device__ inline double fast_sqrt64(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);       // ~2^-26
+    double g = x * y, h = 0.5 * y;
+    double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    return g;
+}
+
 // dP/du and dP/dv at pixel (r,c); neighbours are clamped to the image (replicate padding).
+// FAST = false: the forward's arithmetic, (c - cx) / fx * d with an IEEE division (what the march epilogue and the
+// stand-alone forward kernel share, so both produce the same bits).  FAST = true (backward recomputation): the
+// divisions become multiplications by 1/fx, 1/fy -- at most an ulp of f64 away, far below the f32 normal it feeds.
+template <bool FAST>
 __device__ inline Grad3 point_gradients(const NormalsArgs &a, const float *z, int r, int c)
 {
     Grad3 g = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+    const double inv_fx = FAST ? fast_rcp64(a.fx) : 0.0, inv_fy = FAST ? fast_rcp64(a.fy) : 0.0;
 #pragma unroll
     for (int dr = -1; dr <= 1; ++dr) {
 #pragma unroll
         for (int dc = -1; dc <= 1; ++dc) {
             const int rr = min(max(r + dr, 0), a.H - 1), cc = min(max(c + dc, 0), a.W - 1);
             const double d = (double)(z[(size_t)rr * a.W + cc] + a.z_offset);  // depth + 1610 in f32 (T8:353)
-            const double X = ((double)cc - a.cx) / a.fx * d;
-            const double Y = ((double)rr - a.cy) / a.fy * d;
+            const double X = FAST ? ((double)cc - a.cx) * inv_fx * d : ((double)cc - a.cx) / a.fx * d;
+            const double Y = FAST ? ((double)rr - a.cy) * inv_fy * d : ((double)rr - a.cy) / a.fy * d;
             const double ku = kSobelU[dr + 1][dc + 1], kv = kSobelV[dr + 1][dc + 1];
+            if (FAST) {  // fused multiply-adds: half the instructions, an ulp of f64 away from the forward's sums
+                g.du[0] = __builtin_fma(ku, X, g.du[0]);
+                g.du[1] = __builtin_fma(ku, Y, g.du[1]);
+                g.du[2] = __builtin_fma(ku, d, g.du[2]);
+                g.dv[0] = __builtin_fma(kv, X, g.dv[0]);
+                g.dv[1] = __builtin_fma(kv, Y, g.dv[1]);
+                g.dv[2] = __builtin_fma(kv, d, g.dv[2]);
+                continue;
+            }
             g.du[0] += ku * X;
             g.du[1] += ku * Y;
             g.du[2] += ku * d;
@@ -179,50 +218,79 @@ __device__ inline Grad3 point_gradients(const NormalsArgs &a, const float *z, in
 
 // Unit normal of pixel (r,c) as f32, y negated if requested (T8:353-354) -- shared by normals_fwd_kernel and
 // the march kernel's fused epilogue so that both produce the same bits.
+template <bool FAST = false>
 __device__ inline void unit_normal(const NormalsArgs &a, const float *z, int r, int c, float (&n)[3])
 {
-    const Grad3 g = point_gradients(a, z, r, c);
+    const Grad3 g = point_gradients<FAST>(a, z, r, c);
     const double nx = g.du[1] * g.dv[2] - g.du[2] * g.dv[1];
     const double ny = g.du[2] * g.dv[0] - g.du[0] * g.dv[2];
     const double nz = g.du[0] * g.dv[1] - g.du[1] * g.dv[0];
-    double nn = sqrt(nx * nx + ny * ny + nz * nz);
+    const double n2sum = nx * nx + ny * ny + nz * nz;
+    double nn = FAST ? (n2sum > 1e-24 ? fast_sqrt64(n2sum) : 1e-12) : sqrt(n2sum);
     nn = nn > 1e-12 ? nn : 1e-12;
-    n[0] = (float)(nx / nn);
-    n[1] = (float)(a.negate_y ? -(ny / nn) : (ny / nn));  // T8:354
-    n[2] = (float)(nz / nn);
+    if (FAST) {
+        const double inv = fast_rcp64(nn);
+        n[0] = (float)(nx * inv);
+        n[1] = (float)(a.negate_y ? -(ny * inv) : (ny * inv));
+        n[2] = (float)(nz * inv);
+    } else {
+        n[0] = (float)(nx / nn);
+        n[1] = (float)(a.negate_y ? -(ny / nn) : (ny / nn));  // T8:354
+        n[2] = (float)(nz / nn);
+    }
 }
 
-// Backward of unit_normal() for one pixel: (g0,g1,g2) = dLoss/d(unit normal output, y already negated);
-// scatters dLoss/d depth to the eight stencil neighbours (f32 atomics into gz, the image's grad_depth plane).
-#ifndef GCFR_NBWD_INLINE
-#define GCFR_NBWD_INLINE inline
-#endif
-__device__ GCFR_NBWD_INLINE void normals_bwd_pixel(const NormalsArgs &a, const float *z, float *gz, int r, int c,
-                                         double g0, double g1_in, double g2)
+// Backward of unit_normal() for one pixel, first half: (g0,g1,g2) = dLoss/d(unit normal output, y already negated)
+// -> dLoss/d(dP/du), dLoss/d(dP/dv), the two 3-vectors every stencil neighbour's depth gradient is built from.
+struct StencilGrad {
+    double ddu[3], ddv[3];
+};
+__device__ inline StencilGrad normals_bwd_terms(const NormalsArgs &a, const float *z, int r, int c, double g0,
+                                                double g1_in, double g2)
 {
-    const Grad3 g = point_gradients(a, z, r, c);
+#pragma clang fp contract(fast)  // backward-only arithmetic: fused multiply-adds allowed (the TU default is off)
+    const Grad3 g = point_gradients<true>(a, z, r, c);
     const double cx_ = g.du[1] * g.dv[2] - g.du[2] * g.dv[1];
     const double cy_ = g.du[2] * g.dv[0] - g.du[0] * g.dv[2];
     const double cz_ = g.du[0] * g.dv[1] - g.du[1] * g.dv[0];
-    const double nrm = sqrt(cx_ * cx_ + cy_ * cy_ + cz_ * cz_);
+    const double c2sum = cx_ * cx_ + cy_ * cy_ + cz_ * cz_;
+    const double nrm = c2sum > 1e-24 ? fast_sqrt64(c2sum) : 0.0;
     const double nn = nrm > 1e-12 ? nrm : 1e-12;
-    const double n0 = cx_ / nn, n1 = cy_ / nn, n2 = cz_ / nn;
+    const double inv_nn = fast_rcp64(nn);
+    const double n0 = cx_ * inv_nn, n1 = cy_ * inv_nn, n2 = cz_ * inv_nn;
     const double g1 = a.negate_y ? -g1_in : g1_in;
     // n = c/|c|  (if |c| <= eps the denominator is the constant eps)
     double dc0, dc1, dc2;
     if (nrm > 1e-12) {
         const double ng = n0 * g0 + n1 * g1 + n2 * g2;
-        dc0 = (g0 - n0 * ng) / nn;
-        dc1 = (g1 - n1 * ng) / nn;
-        dc2 = (g2 - n2 * ng) / nn;
+        dc0 = (g0 - n0 * ng) * inv_nn;
+        dc1 = (g1 - n1 * ng) * inv_nn;
+        dc2 = (g2 - n2 * ng) * inv_nn;
     } else {
-        dc0 = g0 / nn;
-        dc1 = g1 / nn;
-        dc2 = g2 / nn;
+        dc0 = g0 * inv_nn;
+        dc1 = g1 * inv_nn;
+        dc2 = g2 * inv_nn;
     }
     // c = du x dv:  d(du) = dv x dc,  d(dv) = dc x du
-    const double ddu[3] = {g.dv[1] * dc2 - g.dv[2] * dc1, g.dv[2] * dc0 - g.dv[0] * dc2, g.dv[0] * dc1 - g.dv[1] * dc0};
-    const double ddv[3] = {dc1 * g.du[2] - dc2 * g.du[1], dc2 * g.du[0] - dc0 * g.du[2], dc0 * g.du[1] - dc1 * g.du[0]};
+    StencilGrad o;
+    o.ddu[0] = g.dv[1] * dc2 - g.dv[2] * dc1;
+    o.ddu[1] = g.dv[2] * dc0 - g.dv[0] * dc2;
+    o.ddu[2] = g.dv[0] * dc1 - g.dv[1] * dc0;
+    o.ddv[0] = dc1 * g.du[2] - dc2 * g.du[1];
+    o.ddv[1] = dc2 * g.du[0] - dc0 * g.du[2];
+    o.ddv[2] = dc0 * g.du[1] - dc1 * g.du[0];
+    return o;
+}
+
+// Second half, scatter form: the depth gradient of the neighbour at offset (dr, dc) of pixel (r, c) -- clamped to the
+// image, i.e. replicate padding -- is  ax*dP_x + ay*dP_y + dP_z  with dP = ku*d(du) + kv*d(dv) and the neighbour's own
+// (ax, ay) = ((cc - cx)/fx, (rr - cy)/fy), because P_j = (ax*d, ay*d, d).  `want(dr, dc)` selects the offsets to emit
+// (f32 atomics into gz, the image's grad_depth plane).
+template <class Pred>
+__device__ inline void normals_bwd_scatter(const NormalsArgs &a, const StencilGrad &sg, float *gz, int r, int c, Pred want)
+{
+#pragma clang fp contract(fast)
+    const double inv_fx = fast_rcp64(a.fx), inv_fy = fast_rcp64(a.fy);
 #pragma unroll
     for (int dr = -1; dr <= 1; ++dr) {
 #pragma unroll
@@ -230,15 +298,24 @@ __device__ GCFR_NBWD_INLINE void normals_bwd_pixel(const NormalsArgs &a, const f
             const double ku = kSobelU[dr + 1][dc + 1], kv = kSobelV[dr + 1][dc + 1];
             if (ku == 0.0 && kv == 0.0)
                 continue;
+            if (!want(dr, dc))
+                continue;
             const int rr = min(max(r + dr, 0), a.H - 1), cc = min(max(c + dc, 0), a.W - 1);
-            const double ax = ((double)cc - a.cx) / a.fx, ay = ((double)rr - a.cy) / a.fy;
-            // P_j = (ax*d, ay*d, d):  dd_j = ax*dP_x + ay*dP_y + dP_z,  dP = ku*d(du) + kv*d(dv)
-            const double dPx = ku * ddu[0] + kv * ddv[0];
-            const double dPy = ku * ddu[1] + kv * ddv[1];
-            const double dPz = ku * ddu[2] + kv * ddv[2];
+            const double ax = ((double)cc - a.cx) * inv_fx, ay = ((double)rr - a.cy) * inv_fy;
+            const double dPx = ku * sg.ddu[0] + kv * sg.ddv[0];
+            const double dPy = ku * sg.ddu[1] + kv * sg.ddv[1];
+            const double dPz = ku * sg.ddu[2] + kv * sg.ddv[2];
             atomicAdd(gz + (size_t)rr * a.W + cc, (float)(ax * dPx + ay * dPy + dPz));
         }
     }
+}
+
+// Backward of unit_normal() for one pixel, all eight neighbours by atomics (stand-alone kernel, multi-light kernel).
+__device__ inline void normals_bwd_pixel(const NormalsArgs &a, const float *z, float *gz, int r, int c,
+                                         double g0, double g1_in, double g2)
+{
+    const StencilGrad sg = normals_bwd_terms(a, z, r, c, g0, g1_in, g2);
+    normals_bwd_scatter(a, sg, gz, r, c, [](int, int) { return true; });
 }
 
 }  // namespace gcfr

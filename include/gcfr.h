@@ -226,11 +226,14 @@ int gcfr_shade_bwd(const float *normals, const float *depth, const float *albedo
  * the ray-march backward through each light's argmin sample and the normals-stencil backward, with no
  * intermediate grad_min_dist / grad_normals tensors (same per-pixel device functions as the three kernels
  * above, so the same numbers up to atomic ordering).  Follow with gcfr_light_prep_bwd.
+ *   normals_fwd (B,3,H,W) f32 or NULL: the unit normals the forward wrote (gcfr_render_from_depth_fwd's normals_out);
+ *                 given them the backward evaluates the depth stencil once instead of twice
  *   g_normals_out (B,3,H,W) f32 or NULL: upstream gradient on the returned unit normals
  *   grad_albedo (B,3,H,W) f32 =;  grad_depth (B,H,W) f32 +=;  grad_light_pt (B,L,3) f64 +=;  grad_ambient (B,L) f64 +=
  */
 int gcfr_render_bwd(const float *depth, const float *albedo, const float *light_pt, const float *ambient,
-                    const float *min_dist, const int32_t *argmin, int32_t B, int32_t L, int32_t H, int32_t W,
+                    const float *min_dist, const int32_t *argmin, const float *normals_fwd, int32_t B, int32_t L,
+                    int32_t H, int32_t W,
                     int32_t N, const double *t_table, double fx, double fy, double cx, double cy,
                     float z_offset, int32_t negate_y, float intensity, const float *g_shadow_w,
                     const float *g_full, const float *g_final, const float *g_rendered,

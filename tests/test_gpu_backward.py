@@ -254,7 +254,7 @@ def test_fused_backward_multi_light_equals_sum_of_single_lights():
     g_amb = torch.zeros((B, L), dtype=torch.float64, device=d)
     tt = R.sample_table(prm, d)
     _lib.check(L_.gcfr_render_bwd(depth.data_ptr(), albedo.data_ptr(), o["light_pt"].data_ptr(), amb.data_ptr(),
-                                  o["minimum_distance"].data_ptr(), o["argmin"].data_ptr(), B, L, Hs, Ws, prm.n_samples,
+                                  o["minimum_distance"].data_ptr(), o["argmin"].data_ptr(), None, B, L, Hs, Ws, prm.n_samples,
                                   tt.data_ptr(), *cam[:4], cam[4], 1, 0.5, None, None, None, G.data_ptr(), None,
                                   g_alb.data_ptr(), g_depth.data_ptr(), g_pt.data_ptr(), g_amb.data_ptr(),
                                   torch.cuda.current_stream().cuda_stream), "gcfr_render_bwd")
