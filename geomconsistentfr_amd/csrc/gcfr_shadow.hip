@@ -478,9 +478,10 @@ constexpr int kQueueSlot = 64;
 constexpr int kStatChunk = 16384;
 __host__ __device__ inline int n_stat_chunks(int H, int W) { return (H * W + kStatChunk - 1) / kStatChunk; }
 
-__device__ inline void stat_mask_dword(uint32_t d, int r, int c, int &rmin, int &cmin, int &nrmax, int &ncmax)
+__device__ inline void stat_mask_dword(uint32_t d, int r, int c, int &rmin, int &cmin, int &nrmax, int &ncmax, int &all_set)
 {
     const uint32_t nz = (d | ((d & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;  // bit 7 of every non-zero byte
+    all_set &= (nz == 0x80808080u) ? 1 : 0;
     if (nz) {
         const int first = __builtin_ctz(nz) >> 3, last = (31 - __builtin_clz(nz)) >> 3;
         rmin = min(rmin, r);
@@ -492,12 +493,14 @@ __device__ inline void stat_mask_dword(uint32_t d, int r, int c, int &rmin, int 
 
 __device__ inline void build_stats_block(int chunk, int b, const float *__restrict__ depth,
                                          const uint8_t *__restrict__ mask, int mask_batch, int H, int W,
-                                         int *__restrict__ bbox, int *__restrict__ zrange, bool want_z, bool vec_ok)
+                                         int *__restrict__ bbox, int *__restrict__ zrange, int *__restrict__ mones,
+                                         bool want_z, bool vec_ok)
 {
     const int P = H * W;
     const int p0 = chunk * kStatChunk;
     const bool want_box = b < mask_batch;
     int rmin = kBBoxInit, cmin = kBBoxInit, nrmax = kBBoxInit, ncmax = kBBoxInit;
+    int all_set = 1;  // every mask cell this lane saw is non-zero
     float zlo = __builtin_inff(), zhi = -__builtin_inff();  // fminf / fmaxf drop NaN cells (a NaN sample never wins)
     const float *z = depth + (size_t)b * P;
     const uint8_t *m = mask + (size_t)b * P;  // only dereferenced when want_box
@@ -518,10 +521,10 @@ __device__ inline void build_stats_block(int chunk, int b, const float *__restri
                 if (want_box) {
                     const uint4 mv = *(const uint4 *)(m + i);
                     const int r = i / W, c = i - r * W;
-                    stat_mask_dword(mv.x, r, c, rmin, cmin, nrmax, ncmax);
-                    stat_mask_dword(mv.y, r, c + 4, rmin, cmin, nrmax, ncmax);
-                    stat_mask_dword(mv.z, r, c + 8, rmin, cmin, nrmax, ncmax);
-                    stat_mask_dword(mv.w, r, c + 12, rmin, cmin, nrmax, ncmax);
+                    stat_mask_dword(mv.x, r, c, rmin, cmin, nrmax, ncmax, all_set);
+                    stat_mask_dword(mv.y, r, c + 4, rmin, cmin, nrmax, ncmax, all_set);
+                    stat_mask_dword(mv.z, r, c + 8, rmin, cmin, nrmax, ncmax, all_set);
+                    stat_mask_dword(mv.w, r, c + 12, rmin, cmin, nrmax, ncmax, all_set);
                 }
             }
         }
@@ -535,19 +538,24 @@ __device__ inline void build_stats_block(int chunk, int b, const float *__restri
                 zlo = fminf(zlo, v);
                 zhi = fmaxf(zhi, v);
             }
-            if (want_box && m[i] != 0) {
-                const int r = i / W, c = i - r * W;
-                rmin = min(rmin, r);
-                cmin = min(cmin, c);
-                nrmax = min(nrmax, -r);
-                ncmax = min(ncmax, -c);
+            if (want_box) {
+                if (m[i] != 0) {
+                    const int r = i / W, c = i - r * W;
+                    rmin = min(rmin, r);
+                    cmin = min(cmin, c);
+                    nrmax = min(nrmax, -r);
+                    ncmax = min(ncmax, -c);
+                } else {
+                    all_set = 0;
+                }
             }
         }
     }
-    __shared__ int part[4][6];
+    __shared__ int part[4][7];
     const int wv = threadIdx.x >> 6;
     const int v0 = wave_min_i32(rmin), v1 = wave_min_i32(cmin), v2 = wave_min_i32(nrmax), v3 = wave_min_i32(ncmax);
     const int v4 = wave_min_i32(f32_sortable(zlo)), v5 = wave_min_i32(f32_sortable(-zhi));
+    const int v6 = __builtin_amdgcn_ballot_w64(all_set == 0) == 0ull ? 1 : 0;
     if ((threadIdx.x & 63) == 0) {
         part[wv][0] = v0;
         part[wv][1] = v1;
@@ -555,17 +563,21 @@ __device__ inline void build_stats_block(int chunk, int b, const float *__restri
         part[wv][3] = v3;
         part[wv][4] = v4;
         part[wv][5] = v5;
+        part[wv][6] = v6;
     }
     __syncthreads();
-    if (threadIdx.x < 6) {
+    if (threadIdx.x < 7) {
         const int q = threadIdx.x;
         const int v = min(min(part[0][q], part[1][q]), min(part[2][q], part[3][q]));
         const size_t rec = (size_t)b * n_stat_chunks(H, W) + chunk;
         if (q < 4) {
             if (want_box)
                 bbox[rec * 4 + q] = v;
-        } else if (want_z) {
-            zrange[rec * 2 + (q - 4)] = v;
+        } else if (q < 6) {
+            if (want_z)
+                zrange[rec * 2 + (q - 4)] = v;
+        } else if (want_box) {
+            mones[rec] = v;  // 1 iff every mask cell of the chunk is non-zero
         }
     }
 }
@@ -580,6 +592,7 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
                                                          PrepassLights pl,
                                                          const uint8_t *__restrict__ mask, int mask_batch,
                                                          int *__restrict__ bbox, int *__restrict__ zrange,
+                                                         int *__restrict__ mones,
                                                          float4 *__restrict__ zb, int zb_blocks, int stat_blocks,
                                                          int want_z, int vec_ok, int N,
                                                          const double *__restrict__ t_table, int group,
@@ -592,8 +605,8 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
         return;
     }
     if ((int)blockIdx.x < zb_blocks + stat_blocks) {
-        build_stats_block((int)blockIdx.x - zb_blocks, b, depth, mask, mask_batch, H, W, bbox, zrange, want_z != 0,
-                          vec_ok != 0);
+        build_stats_block((int)blockIdx.x - zb_blocks, b, depth, mask, mask_batch, H, W, bbox, zrange, mones,
+                          want_z != 0, vec_ok != 0);
         return;
     }
     const int qb = (int)blockIdx.x - zb_blocks - stat_blocks;
@@ -659,6 +672,7 @@ struct ShadowQuadArgs {
     const int *bbox;        // (MB,n_stat,4) prepass output: partial mask bounding boxes {r_min, c_min, -r_max, -c_max}
     const float4 *zb;       // (B,zb_max_tiles) prepass output: depth bounds grid {a, b, c_lo, c_hi}, or null (skip off)
     const int *zrange;      // (B,n_stat,2) prepass output: partial depth ranges {z_min, -z_max} (sortable ints)
+    const int *mones;       // (MB,n_stat)  prepass output: 1 iff every mask cell of the chunk is non-zero
     int *tflag;             // [0] prepass output: 1 iff the sample table is increasing, inside [0,1] and uniform;
                             // [kQueueSlot] the persistent schedule's tile queue (zeroed by the prepass)
     const uint8_t *mask;    // (MB,H,W)
@@ -715,15 +729,19 @@ enum { kCntTiles, kCntGroupsNominal, kCntGroupsVisited, kCntBoundTests, kCntBodi
 struct ImageStats {
     int r_min, c_min, r_max, c_max;  // bounding box of the mask's non-zero cells (r_min == kBBoxInit: none)
     int gz_lo_s, gz_nhi_s;           // depth range {z_min, -z_max} as sortable ints
+    int mask_all_ones;               // 1 iff the image's mask has no zero cell at all
 };
 __device__ inline ImageStats reduce_image_stats(ArgPtr a, int b, int lane, bool want_z)
 {
     const int n = n_stat_chunks(a->H, a->W);
     const int4 *pb = (const int4 *)a->bbox + (size_t)(a->mask_batch == 1 ? 0 : b) * n;
     const int2 *pz = (const int2 *)a->zrange + (size_t)b * n;
+    const int *po = a->mones + (size_t)(a->mask_batch == 1 ? 0 : b) * n;
     int4 m = make_int4(kBBoxInit, kBBoxInit, kBBoxInit, kBBoxInit);
     int2 mz = make_int2(0x7fffffff, 0x7fffffff);
+    int ones = 1;
     for (int j = lane; j < n; j += 64) {
+        ones = min(ones, po[j]);
         const int4 v = pb[j];
         m.x = min(m.x, v.x);
         m.y = min(m.y, v.y);
@@ -742,6 +760,7 @@ __device__ inline ImageStats reduce_image_stats(ArgPtr a, int b, int lane, bool 
     st.c_max = -wave_min_i32(m.w);
     st.gz_lo_s = want_z ? wave_min_i32(mz.x) : 0x7fffffff;
     st.gz_nhi_s = want_z ? wave_min_i32(mz.y) : 0x7fffffff;
+    st.mask_all_ones = wave_min_i32(ones);
     return st;
 }
 
@@ -761,7 +780,7 @@ __device__ inline ImageStats reduce_image_stats(ArgPtr a, int b, int lane, bool 
 #ifndef GCFR_TILE_INLINE
 #define GCFR_TILE_INLINE __forceinline__
 #endif
-template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, int SPLIT>
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, int SPLIT, bool ALL_ONES = false>
 __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy, const int tx,
                                            const ImageStats &st)
 {
@@ -851,7 +870,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     // (gcfr_sample_table with dt > 0, the reference's np.arange); anything else marches every sample, which is
     // always right
     const bool t_increasing = (a->N >= 2) && (((ConstI32Ptr)(unsigned long long)a->tflag)[0] != 0);  // checked by the prepass (see its table check)
-    const bool use_zb = (a->zb != nullptr) && t_increasing;
+    bool use_zb = (a->zb != nullptr) && t_increasing;
     const int gz_lo_s = st.gz_lo_s, gz_nhi_s = st.gz_nhi_s;  // image depth range {z_min, -z_max} (sortable ints)
     int lane_last = a->N - 1;  // last sample of this lane that can be unmasked (mask bounding box), see below
     if (t_increasing) {
@@ -929,6 +948,26 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     const float c1 = BCz * ((dxf * BCx + dyf * BCy) / nrm);
     const float Qz = nrm * zb;
     const float t_abs = fmaxf(fabsf((float)tt[0]), fabsf((float)tt[a->N - 1]));
+    // Give-up test (a heuristic about WORK, never about results: without the bounds every group is marched).  A group
+    // can only be skipped while the ray's height over the pixel, c1 t / n, exceeds what the surface band leaves open,
+    // about half its width; on a surface rougher than the rays rise (an untrained network's depth) no test can ever
+    // succeed and the tests, the bounds gathers and the termination checks are pure cost (round 1: -24 % against the
+    // kernel without them at noise amplitude 400).  The band of the tile under the wave's own pixels stands for the
+    // roughness of its neighbourhood: if for every lane the whole ray rises less than GCFR_GIVEUP_FACTOR band widths,
+    // the wave marches this tile without the bounds machinery.
+#ifndef GCFR_GIVEUP_FACTOR
+#define GCFR_GIVEUP_FACTOR 0.5f
+#endif
+    if (use_zb) {
+        const int own = __mul24((qy * TILE_H) >> zls, zntw) + ((tx * TILE_W) >> zls);
+        const ConstF32Ptr rec = (ConstF32Ptr)(unsigned long long)a->zb + 4 * ((size_t)b * zb_max_tiles(H, W) + own);
+        const float band = rec[3] - rec[2];  // c_hi - c_lo (wave-uniform address: scalar loads)
+        const bool hopeless = !(fabsf(c1) * t_abs >= GCFR_GIVEUP_FACTOR * nrm * band);  // (NaN / inf bands: hopeless)
+        if (__builtin_amdgcn_ballot_w64(!hopeless) == 0ull) {
+            use_zb = false;
+            GCFR_COUNT(kCntBoundsGivenUp, 1);
+        }
+    }
     float Kerr = __builtin_inff();  // never skips
     // Early termination (exact).  Once the ray is above max(image depth maximum, 0) by more than the running
     // minimum allows (same bound as above, with the image-wide zmax instead of a tile's) and is still rising
@@ -1006,8 +1045,26 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         uint32_t m[DEPTH];
         f32x4 z;  // {a, b, c_lo, c_hi}
     };
+    // ALL_ONES: a mask without a single zero cell (the worst case of the mask-group skip: nothing is ever masked)
+    // needs no mask gathers at all -- the prefetch then only locates the group's first and last cell for the bounds
+    // record.  A compile-time variant of the whole tile function, chosen per tile by the caller: as a run-time
+    // branch inside the prefetch it cost the common case 6 % (the sample loop's schedule falls apart around it).
     auto prefetch = [&](int kfirst, Prefetched &p) {
         int cj[DEPTH], rj[DEPTH];
+        if (ALL_ONES) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j)
+                p.m[j] = 1u;
+            if (use_zb) {
+                double px, py;
+                sample_pos(clampk(kfirst), px, py);
+                (void)mask_offset(px, py, cj[0], rj[0]);
+                sample_pos(clampk(kfirst + DEPTH - 1), px, py);
+                (void)mask_offset(px, py, cj[DEPTH - 1], rj[DEPTH - 1]);
+                p.z = zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1]);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
             double px, py;
@@ -1360,7 +1417,10 @@ __device__ __forceinline__ void march_grid(ArgPtr a)
     const int bl = a->bl_offset + (int)blockIdx.z;
     const bool want_z = (a->zb != nullptr);
     const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, want_z);
-    march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0>(a, bl, (int)blockIdx.y, tx, st);
+    if (st.mask_all_ones != 0)  // wave-uniform (a fact about the mask: valid for any sample table)
+        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, true>(a, bl, (int)blockIdx.y, tx, st);
+    else
+        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, false>(a, bl, (int)blockIdx.y, tx, st);
 }
 
 // ---- experimental schedules (-DGCFR_EXPERIMENTAL_SCHEDULES; profiles/r02_schedule_experiments.md) -----------------
@@ -1660,7 +1720,7 @@ extern "C" void gcfr_options_default(gcfr_options *opt)
     opt->ksplit = opt->depth_bound_skip = opt->schedule = opt->tile_order = -1;
 }
 
-// workspace layout: [quad texels | partial boxes | depth-bounds records | partial depth ranges | tflag, queue]
+// workspace layout: [quad texels | partial boxes | depth-bounds records | partial depth ranges | tflag, queue | all-ones flags]
 extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
 {
     if (B <= 0 || H <= 0 || W <= 0)
@@ -1668,7 +1728,7 @@ extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
     const size_t n_stat = (size_t)n_stat_chunks(H, W);
     return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4) + (size_t)B * n_stat * 4 * sizeof(int) +
            (size_t)B * (size_t)zb_max_tiles(H, W) * sizeof(float4) + (size_t)B * n_stat * 2 * sizeof(int) +
-           (kQueueSlot + 1) * sizeof(int) + 12;
+           (kQueueSlot + 1) * sizeof(int) + 12 + (size_t)B * n_stat * sizeof(int);
 }
 
 // Number of compute units of the current device (immutable hardware fact; queried once per device and process).
@@ -1819,9 +1879,11 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
     if (resolve_options(opt, kn) != GCFR_OK)
         return GCFR_ERR_INVALID_ARGUMENT;
 
-    // auto tile shape (measured): with the depth-bound skip compact tiles win
-    // (the lanes of a wave agree more often): 8x8 up to 256 px wide, 16x4 above; without it 32x2 streams best.
-    const int tile_auto = (kn.zbound && N >= 2) ? (W <= 256 ? 8 : 16) : 32;
+    // auto tile shape (measured): with the depth-bound skip compact tiles win (the lanes of a wave
+    // agree more often).  16x4 everywhere: on the smooth bench faces it ties with 8x8 at 256 px (1690 vs 1688 G
+    // ray-steps/s) and wins above, and it degrades more gracefully when the bounds stop helping -- rough depth
+    // (+15 % at noise 400, level with the kernel without bounds), all-ones masks (+4 %).  Without bounds 32x2 streams best.
+    const int tile_auto = (kn.zbound && N >= 2) ? 16 : 32;
     const int TILE_W = workspace ? (kn.tile_w ? kn.tile_w : tile_auto) : 16, TILE_H = 64 / TILE_W, WAVES = 4;
     const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
     const int quads_x = (tiles_x + WAVES - 1) / WAVES;
@@ -1843,17 +1905,19 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         int *bbox = (int *)((char *)workspace + (size_t)B * texels * sizeof(float4));
         float4 *zb = (float4 *)((char *)bbox + (size_t)B * n_stat * 4 * sizeof(int));
         int *zrange = (int *)(zb + (size_t)B * zb_max_tiles(H, W));  // (B, n_stat, 2)
-        int *tflag = zrange + (size_t)B * n_stat * 2;                 // [0] table flag, [1] tile queue
+        int *tflag = zrange + (size_t)B * n_stat * 2;                 // [0] table flag, [kQueueSlot] tile queue
+        int *mones = tflag + kQueueSlot + 4;                          // (B, n_stat) all-ones flags of the mask chunks
         const bool use_zb = kn.zbound && N >= 2;
         const int quad_blocks = (texels + 255) / 256;
         const int zb_blocks = use_zb ? (zb_max_tiles(H, W) + 3) / 4 : 0;  // sized for the finest stride
         const int vec_ok = ((W & 15) == 0) && (((uintptr_t)depth & 15u) == 0) && (((uintptr_t)mask_u8 & 15u) == 0);
         hipLaunchKernelGGL(build_quad_kernel, dim3(zb_blocks + (int)n_stat + quad_blocks, B), dim3(256), 0, st, depth,
-                           (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox, zrange, zb, zb_blocks,
+                           (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox, zrange, mones, zb, zb_blocks,
                            (int)n_stat, use_zb ? 1 : 0, vec_ok, N, t_table, kn.group, tflag);
         ShadowQuadArgs a = {};
         a.zb = use_zb ? zb : nullptr;
         a.zrange = zrange;
+        a.mones = mones;
         a.tflag = tflag;
         a.depth = depth;
         a.quad = (const float4 *)workspace;

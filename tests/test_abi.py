@@ -39,7 +39,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     L = _lib.load()
     assert L.gcfr_shadow_fwd(None, None, 1, None, 1, 1, 256, 256, 160, None, 0.0, None, None, None, None, 0, None, None) == -1
     # workspace: quad texels + 4 statistics chunks per 256x256 image (box 16 B + depth range 8 B) + depth-bounds records
-    assert L.gcfr_shadow_workspace_bytes(8, 256, 256) == 8 * 257 * 257 * 16 + 8 * 4 * 16 + 8 * (33 * 33 + 1) * 16 + 8 * 4 * 8 + 65 * 4 + 12
+    assert L.gcfr_shadow_workspace_bytes(8, 256, 256) == 8 * 257 * 257 * 16 + 8 * 4 * 16 + 8 * (33 * 33 + 1) * 16 + 8 * 4 * 8 + 65 * 4 + 12 + 8 * 4 * 4
     assert L.gcfr_light_prep(None, 1, 1, 0.0, 4013.0, None, None, None) == -1
     assert L.gcfr_shade_fwd(None, None, None, None, None, None, 1, 1, 8, 8, 0.5, None, None, None, None, None) == -1
 

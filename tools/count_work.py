@@ -30,7 +30,7 @@ def knobs_tile_w(tune, size):
     for kv in tune.split(","):
         if kv.startswith("tile_w=") and int(kv[7:]):
             return int(kv[7:])
-    return 8 if size <= 256 else 16          # the library's auto rule with the depth-bound skip on
+    return 16                                # the library's auto rule with the depth-bound skip on
 
 
 def main():

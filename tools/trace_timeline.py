@@ -84,7 +84,7 @@ def main():
     depth, mask, albedo, normals, light, amb = bench.synth_faces(B, 0)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     args = (t(depth), t(mask), t(light).reshape(B, 1, 3), t(amb).reshape(B, 1), t(normals), t(albedo))
-    n_tiles = B * 32 * 32
+    n_tiles = B * 16 * 64                                      # 16 x 4 tiles of a 256 x 256 face
     saved = {}
     for tune in (a.tune or ["schedule=0"]):
         knobs = {k: int(v) for k, v in (kv.split("=") for kv in tune.split(",") if kv)}
