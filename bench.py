@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the render block on MI355X.
+"""bench.py -- benchmarks of the render block on MI355X.
 
-Metric (BASELINE.json): ray-steps/s (whole job) + relit faces/s on 256x256 faces, 160 march steps.
-Workload at N=1: BASELINE configs[1] -- batch of 8 synthetic 256x256 faces, one light each,
-forward-only shadow + shade.  One "step" = one pass of the hot path over one batch:
-one gcfr_render_fwd enqueue (depth repack + light prep, then the ray march with the shading fused into
-its epilogue), inputs resident in HBM.  --from-depth also fuses the normals stencil (+3 %).
+Metric (BASELINE.json): ray-steps/s (whole job) + relit faces/s on 256x256 faces, 160 march steps;
 ray_steps = B*L*H*W*N nominal, never "steps executed".
 
-Multi-GPU (`torchrun --nproc-per-node N bench.py --gpus N`): faces are independent, so each rank
-renders its own batch of 8 with no data-path collective ("weak" scaling); the timed region is
-bracketed by barrier + synchronize on both sides and the max over ranks is reported.
+--workload render (default; BASELINE configs[1]): a batch of 8 synthetic 256x256 faces per GPU, one light each,
+    forward-only shadow + shade.  One "step" = one pass of the hot path over one batch: one gcfr_render_fwd enqueue
+    (prepass: depth repack, statistics, depth bounds, light prep; then the ray march with the shading fused into its
+    epilogue), inputs resident in HBM.  Steps are independent batches: `--streams S` (default 4) keeps S of them in
+    flight on S HIP streams, each a hipGraph replay of a preallocated RenderFwdPlan -- `value` is that throughput;
+    `single_stream` in the same line is the one-batch-at-a-time rate (= the batch-8 latency).
+--workload train (BASELINE configs[2]; configs[3] under torchrun): batch of 32 faces per GPU, one full training step
+    (RelightNet forward incl. the fused render block, PatchGAN every 5th step, seven losses, backward through the
+    fused backward kernel, two Adam steps; DistributedDataParallel over RCCL when WORLD_SIZE > 1).
+
+Multi-GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`): faces are independent, so each
+rank works on its own batch with no data-path collective ("weak" scaling; training adds DDP's gradient all-reduce);
+the timed region is bracketed by barrier + synchronize on both sides and the max over ranks is reported.
 
 The JSON line also carries
-  roofline     -- for the dominant kernel (shadow_fwd_kernel): algorithmic bytes (17.4 B per ray-step,
-                  SURVEY.md 8d) per launch / average launch duration measured with HIP events on the
-                  launch stream, against the 8 TB/s HBM peak; `traffic` = HBM bytes per launch from the
-                  rocprofv3 PMC pass committed under profiles/ (null if that file is absent);
-  cpu_baseline -- the oracle's materialised-torch port (same op sequence as the reference, which cannot
-                  travel to the GPU box) timed on this host's cores on a bounded sample (rank 0, N=1 only).
+  roofline     -- for the dominant kernel, measured live with HIP events on the launch stream (un-captured plan calls
+                  on one stream, library-recorded events around the kernel):
+                  bound "valu": the SIMD issue time the kernel's instruction mix needs (rocprofv3 SQ_INSTS_VALU_* per
+                  launch from profiles/pmc_summary.json x the per-class issue cost measured by tools/ubench_valu on this
+                  chip) / launch duration, against 1024 SIMDs x 2.4 GHz -- a fraction <= 1 of a limit that binds;
+                  `hbm`: north_star's accounting kept beside it (17.4 algorithmic B per nominal ray-step vs 8 TB/s; the
+                  gathers are cache-served and ~91 % of the nominal ray-steps are provably skipped, so it exceeds 1);
+                  `traffic` = HBM bytes per launch from the PMC passes (separate --pmc runs, KiB units, read side x2);
+  cpu_baseline -- oracle/materialised.py (op-for-op torch-CPU port of the reference, which cannot travel to the GPU
+                  box), T8 form B=3, forward and forward+backward, best of {8, 32, all} host threads (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -98,9 +108,9 @@ def cpu_baseline(seed0=0, runs=3, with_backward=True):
     """The CPU baseline of record: oracle/materialised.py -- the op-for-op torch-CPU port
     of T8:352-524, bit-equal to the imported reference (tests/test_oracle_vs_reference.py); the reference's own .py
     cannot travel to the GPU box -- in the reference's training form: a batch of B = 3 faces, normals from depth
-    inside the timed region (T8:353), 256 x 256 x 160.  Forward under no_grad at 8, 32 and all host threads, median
-    of `runs` after a warm-up each, the BEST thread count reported (all 256 hyper-threads of the GPU host are ~10x
-    slower than 8-32 for these memory-bound elementwise ops); then forward+backward (autograd through the port, as
+    inside the timed region (T8:353), 256 x 256 x 160.  Forward under no_grad at 8, 32 and 64 host threads, median
+    of `runs` after a warm-up each, the BEST thread count reported (all 256 hyper-threads of the GPU host are 14x
+    slower than 32 for these memory-bound elementwise ops); then forward+backward (autograd through the port, as
     loss.backward() replays the reference's graph, T8:655) at that thread count, median of `runs`.
     Checker code used strictly as the reported baseline; bounded: about 2-3 minutes of host time."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -140,7 +150,9 @@ def cpu_baseline(seed0=0, runs=3, with_backward=True):
 
     steps = B * H * W * N_SAMPLES
     by_threads = {}
-    for th in sorted({min(8, cores), min(32, cores), cores}):
+    # (all 256 hyper-threads of the GPU host: 60 s per batch, 14x slower than 32 -- measured once in round 2,
+    #  profiles/r02_bench_render.json; the sweep stops at 64 so that the default run stays within minutes)
+    for th in sorted({min(8, cores), min(32, cores), min(64, cores)}):
         torch.set_num_threads(th)
         forward()                                                            # warm-up (thread pool, allocator)
         med, ts = median_time(forward, runs)
@@ -199,35 +211,360 @@ def measured_copy_bandwidth_gbs(dev, mb=1024, iters=5):
     return 2.0 * n * 4 * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per shadow_fwd launch from the committed rocprofv3 PMC pass, or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if not os.path.exists(p):
-        return None
+def pmc_summary():
+    """profiles/pmc_summary.json (tools/summarize_profile.py), or {}."""
     try:
-        return json.load(open(p)).get("shadow_fwd_hbm_bytes_per_launch")
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
     except Exception:
+        return {}
+
+
+N_SIMD, NOMINAL_HZ = 1024, 2.4e9      # 256 CUs x 4 SIMDs; MI355X_MICROARCH.md max clock
+
+
+def valu_roofline(kernel_entry, launch_ms):
+    """VALU-issue roofline of one kernel from its committed PMC instruction mix and a LIVE launch duration."""
+    v = kernel_entry["valu"]
+    demanded = v["issue_cycles_per_launch"] / (launch_ms * 1e-3)            # SIMD issue cycles needed per second
+    peak = N_SIMD * NOMINAL_HZ
+    return {"bound": "valu", "kernel": kernel_entry["kernel"], "achieved": demanded / 1e9, "peak": peak / 1e9,
+            "unit": "G SIMD-issue-cycles/s", "frac": demanded / peak, "avg_launch_ms": launch_ms,
+            "valu_insts_per_launch": v["insts_per_launch"], "mean_issue_cycles_per_inst": v["mean_issue_cycles_per_inst"],
+            "traffic": kernel_entry["hbm"]["bytes_per_launch"],
+            "note": "achieved = sum over VALU instruction classes of (wave-instructions per launch, rocprofv3 "
+                    "SQ_INSTS_VALU_* of this workload, profiles/pmc_summary.json) x (sustained issue cost of the class on "
+                    "this chip, tools/ubench_valu -> profiles/r02_valu_cost_table.json), divided by the kernel's "
+                    "un-overlapped launch duration measured live (HIP events recorded by the library around the "
+                    "kernel, 100 plan calls on one stream); peak = 1024 SIMDs x 2.4 GHz"}
+
+
+class HipEvents:
+    """hipEvent_t handles through the HIP runtime torch already loaded (same inode -> the same runtime instance)."""
+
+    def __init__(self):
+        import ctypes
+        self.ct = ctypes
+        self.hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+
+    def new(self):
+        e = self.ct.c_void_p()
+        assert self.hip.hipEventCreate(self.ct.byref(e)) == 0
+        return e
+
+    def elapsed_ms(self, e0, e1):
+        ms = self.ct.c_float()
+        assert self.hip.hipEventElapsedTime(self.ct.byref(ms), e0, e1) == 0
+        return ms.value
+
+
+def setup_distributed(a):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and a.gpus > 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d" % (a.gpus, a.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+    return rank, world, dev, dist
+
+
+def fence(dist):
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(dist, dev, seconds):
+    if dist is None:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------------
+# workload "render": BASELINE configs[1]
+# ------------------------------------------------------------------------------------------------
+def run_render(a, rank, world, dev, dist):
+    from geomconsistentfr_amd import RenderParams, _lib
+    from geomconsistentfr_amd import block as R
+
+    knobs = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)}
+    base_opt = _lib.options(**knobs) if knobs else None
+    B = a.faces
+    headline = (a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse" and a.depth_noise == 0.0
+                and B == FACES_PER_GPU and not knobs and not (a.direct or a.unfused or a.from_depth))
+    if a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse":
+        prm = RenderParams()
+        depth, mask, albedo, normals, light, amb = synth_faces(B, seed0=rank * 1_000_000)
+    else:
+        prm = RenderParams(n_samples=a.samples, dt=0.8 / a.samples)
+        depth, mask, albedo, normals, light, amb = synth_faces_sized(B, rank * 1_000_000, a.size, a.lights, a.mask)
+    if a.depth_noise > 0.0:
+        depth = depth + (a.depth_noise * np.random.default_rng(7).random(depth.shape)).astype(np.float32)
+    Hh = Ww = a.size
+    Ll, Nn = a.lights, a.samples
+    d_depth, d_mask, d_albedo, d_normals, d_light, d_amb = [torch.from_numpy(x).to(dev) for x in
+                                                            (depth, mask, albedo, normals, light, amb)]
+    ev = HipEvents()
+    cam = (1570.0 * Hh / 256.0, 1570.0 * Hh / 256.0, Ww / 2.0, Hh / 2.0, 1610.0)
+    d_mask_u8 = R.mask_to_u8(d_mask).reshape(-1, Hh, Ww).contiguous()
+    d_light3, d_amb2 = d_light.reshape(B, Ll, 3).contiguous(), d_amb.reshape(B, Ll).contiguous()
+    plan_inputs = (d_depth, d_mask_u8, d_light3, d_amb2, None if a.from_depth else d_normals, d_albedo)
+
+    def new_plan():
+        return R.RenderFwdPlan(B, Ll, Hh, Ww, prm, dev, want_argmin=False, mask_batch=d_mask_u8.shape[0],
+                               camera=cam if a.from_depth else None, options=base_opt)
+
+    n_streams = max(1, a.streams)
+    use_plans = not (a.eager or a.direct or a.unfused)
+    plans = [new_plan() for _ in range(n_streams)] if use_plans else None
+    use_graph, graph_error = use_plans and not a.no_graph, None
+    if use_graph:
+        try:
+            for p_ in plans:
+                p_.capture(*plan_inputs)
+        except Exception as e:      # a runtime that cannot capture: same kernels, issued call by call
+            graph_error, use_graph = repr(e), False
+            torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+
+    def eager_step(opt):
+        if a.direct or a.unfused:
+            _, pt = R.light_prep(d_light, prm)
+            md, _ = R.shadow_min_distance(d_depth, d_mask, pt.reshape(B, Ll, 3), prm, want_argmin=False,
+                                          use_workspace=not a.direct, options=opt)
+            return R.shade(d_normals, d_depth, d_albedo, pt.reshape(B, Ll, 3), d_amb.reshape(B, Ll), md, prm)
+        return R.render_fwd(d_depth, d_mask, d_light.reshape(B, Ll, 3), d_amb.reshape(B, Ll),
+                            None if a.from_depth else d_normals, d_albedo, prm, want_argmin=False,
+                            camera=cam if a.from_depth else None, options=opt)
+
+    def issue(i):
+        """enqueue step i (no events): graph replay, plan call or eager call on stream i % S"""
+        with torch.cuda.stream(streams[i % n_streams]):
+            if use_graph:
+                plans[i % n_streams].replay()
+            elif use_plans:
+                plans[i % n_streams](*plan_inputs)
+            else:
+                eager_step(base_opt)
+
+    def timed_run(n_steps, stream_count):
+        """n_steps steps round-robin over the first `stream_count` streams, fenced on both sides"""
+        nonlocal n_streams
+        saved, n_streams = n_streams, stream_count
+        fence(dist)
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            issue(i)
+        host = time.perf_counter() - t0
+        fence(dist)
+        dt = time.perf_counter() - t0
+        n_streams = saved
+        return max_over_ranks(dist, dev, dt), host
+
+    for i in range(a.warmup):
+        issue(i)
+    elapsed, host_issue = timed_run(a.steps, n_streams)
+
+    # the dominant kernel's un-overlapped launch duration: plan calls (not graph replays) on ONE stream, each with
+    # its own event pair recorded by the library immediately before / after the march kernel on that stream
+    def kernel_launch_ms(n=100):
+        pairs = []
+        torch.cuda.synchronize()
+        with torch.cuda.stream(streams[0]):
+            for _ in range(n):
+                e0, e1 = ev.new(), ev.new()
+                opt = _lib.options(**knobs, event_start=e0, event_stop=e1)
+                pairs.append((e0, e1, opt))
+                if use_plans:
+                    plans[0].options = opt
+                    plans[0](*plan_inputs)
+                    plans[0].options = base_opt
+                else:
+                    eager_step(opt)
+        torch.cuda.synchronize()
+        return float(np.mean([ev.elapsed_ms(e0, e1) for e0, e1, _ in pairs]))
+
+    shadow_ms = kernel_launch_ms()
+    single_steps = max(50, min(a.steps, 1000))
+    single_elapsed, _ = timed_run(single_steps, 1) if n_streams > 1 else (elapsed * single_steps / a.steps, None)
+    ray_steps_per_step_rank = B * Ll * Hh * Ww * Nn
+    value = world * ray_steps_per_step_rank * a.steps / elapsed
+    single = {"ms_per_step": 1e3 * single_elapsed / single_steps,
+              "ray_steps_per_sec": world * ray_steps_per_step_rank * single_steps / single_elapsed,
+              "note": "the same steps one at a time on ONE stream (hipGraph replay): the latency of one batch"}
+    if rank != 0:
         return None
+    algo_bytes = ray_steps_per_step_rank * ALGO_BYTES_PER_RAY_STEP          # per launch (one rank)
+    achieved_gbs = algo_bytes / (shadow_ms * 1e-3) / 1e9
+    pm = pmc_summary()
+    hbm_line = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": algo_bytes, "measured_copy_GBs": measured_copy_bandwidth_gbs(dev),
+                "note": "north_star's accounting: 17.4 algorithmic B per NOMINAL ray-step (SURVEY 8d) / launch duration; the "
+                        "gathers are cache-served and most nominal ray-steps are provably skipped, so this is not a "
+                        "fraction of a limit (it exceeds 1) -- the binding roofline is the VALU one"}
+    fwd = pm.get("kernels", {}).get("fwd")
+    if headline and fwd:
+        roof = valu_roofline(fwd, shadow_ms)
+        roof["hbm"] = hbm_line
+        roof["kernel_ray_steps_per_sec"] = ray_steps_per_step_rank / (shadow_ms * 1e-3)
+        if "work" in fwd:
+            roof["executed_fraction_of_nominal_ray_steps"] = fwd["work"]["executed_fraction_of_nominal"]
+            roof["valu_wave_insts_per_executed_wave_step"] = fwd["work"]["valu_wave_insts_per_executed_wave_step"]
+        if "l1" in fwd:
+            roof["l1_frac_of_peak_under_rocprofv3"] = fwd["l1"]["frac"]
+        # the same mix against the overlapped rate: what the chip's VALU does when `streams` launches share it
+        roof["frac_at_throughput"] = fwd["valu"]["issue_cycles_per_launch"] / (N_SIMD * NOMINAL_HZ * elapsed / a.steps)
+    else:       # no PMC mix for this workload / kernel selection: HBM accounting only
+        roof = dict(hbm_line, kernel="shadow_fwd_quad_kernel" if not a.direct else "shadow_fwd_kernel",
+                    avg_launch_ms=shadow_ms, traffic=None,
+                    kernel_ray_steps_per_sec=ray_steps_per_step_rank / (shadow_ms * 1e-3))
+    out = {
+        "metric": "ray_steps_per_sec", "value": value, "unit": "ray-steps/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+f32", "data": "synthetic",
+        "config": {"workload": ("BASELINE configs[1]: batch=%d synthetic 256x256 faces per GPU, 1 light each, 160 march "
+                                "steps, forward-only shadow+shade; %d batch(es) in flight" % (B, n_streams)) if headline else
+                               ("non-headline: batch=%d synthetic %dx%d faces per GPU, %d light(s) each, %d march steps, mask=%s, "
+                                "depth noise %g, knobs %s, forward-only shadow+shade; %d batch(es) in flight"
+                                % (B, Hh, Ww, Ll, Nn, a.mask, a.depth_noise, knobs or "default", n_streams)),
+                   "faces_per_gpu": B, "H": Hh, "W": Ww, "lights_per_face": Ll, "n_samples": Nn,
+                   "parallelism": "dp%d" % world, "hip_streams": n_streams, "batches_in_flight": n_streams,
+                   "host_path": ("RenderFwdPlan, hipGraph replay" if use_graph else "RenderFwdPlan (preallocated outputs)")
+                   if use_plans else "render_fwd (eager)"},
+        "faces_per_sec": world * B * Ll * a.steps / elapsed,
+        "host_issue_ms_per_step": 1e3 * host_issue / a.steps,
+        "ray_steps_per_sec_per_gpu": value / world,
+        "single_stream": single,
+        "latency_one_batch_ms": single["ms_per_step"],
+        "roofline": roof,
+    }
+    if graph_error:
+        out["config"]["graph_capture_failed"] = graph_error
+    if world == 1 and not a.no_cpu_baseline and headline:
+        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline_c_openmp"] = cpu_baseline_c()
+    return out
 
 
-def pmc_valu_insts():
-    """VALU wave-instructions per shadow_fwd launch from the committed PMC pass (SQ_INSTS_VALU), or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    try:
-        return json.load(open(p)).get("valu_insts_per_launch")
-    except Exception:
+# ------------------------------------------------------------------------------------------------
+# workload "train": BASELINE configs[2] (1 GPU) / configs[3] (8 GPUs, DDP over RCCL)
+# ------------------------------------------------------------------------------------------------
+def run_train(a, rank, world, dev, dist):
+    from geomconsistentfr_amd import _lib
+    from geomconsistentfr_amd import block as R
+    from geomconsistentfr_amd.train import TrainConfig, Trainer, synthetic_batch
+
+    B = a.faces if a.faces != FACES_PER_GPU else 32                          # configs[2]: batch=32 per GPU
+    torch.manual_seed(1234 + rank)
+    tr = Trainer(TrainConfig(), device=dev, distributed=dist is not None)
+    batch = synthetic_batch(B, rank * 1_000_000, device=dev)
+    epoch = 200                                                               # every epoch-gated skip on (T8:245-283)
+    for j in range(max(a.warmup, 6)):                                        # MIOpen find mode tunes on first use
+        tr.step(batch, epoch, j, log=False)
+    fence(dist)
+    t0 = time.perf_counter()
+    for j in range(a.steps):
+        tr.step(batch, epoch, j, log=False)                                  # D step every 5th (T8:624), G step always
+    fence(dist)
+    elapsed = max_over_ranks(dist, dev, time.perf_counter() - t0)
+
+    # the render block's own kernels on this batch, measured live on the current stream: forward (prepass + march with
+    # fused normals + shading, argmin variant) and the fused backward, from the tensors of a real step's forward
+    with torch.no_grad():
+        albedo, depth, SL = tr.model.features(batch["images"], epoch)
+    prm = tr.model.render_params
+    masks = R.mask_to_u8(batch["masks_fill"].reshape(B, 256, 256))
+    cam = R.camera_scalars(tr.K) + (tr.model.normal_z_offset,)
+    plan = R.RenderFwdPlan(B, 1, 256, 256, prm, dev, want_argmin=True, camera=cam)
+    ins = (depth.reshape(B, 256, 256).contiguous(), masks, SL[:, 0, 0, 1:4].reshape(B, 1, 3).contiguous(),
+           SL[:, 0, 0, 0].reshape(B, 1).contiguous(), None, albedo.contiguous())
+    ev = HipEvents()
+    pairs = []
+    for _ in range(30):
+        e0, e1 = ev.new(), ev.new()
+        plan.options = _lib.options(event_start=e0, event_stop=e1)
+        pairs.append((e0, e1, plan.options))
+        o = plan(*ins)
+    torch.cuda.synchronize()
+    march_ms = float(np.mean([ev.elapsed_ms(e0, e1) for e0, e1, _ in pairs[5:]]))
+    L_ = _lib.load()
+    g_ren = torch.rand((B, 1, 3, 256, 256), device=dev) * masks[:, None, None].float()  # the losses mask the rendered image
+    g_alb, g_depth = torch.empty((B, 3, 256, 256), device=dev), torch.zeros((B, 256, 256), device=dev)
+    g_pt, g_amb = torch.zeros((B, 1, 3), dtype=torch.float64, device=dev), torch.zeros((B, 1), dtype=torch.float64, device=dev)
+    tt = R.sample_table(prm, dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    t_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def bwd_once():
+        _lib.check(L_.gcfr_render_bwd(ins[0].data_ptr(), ins[5].data_ptr(), o["light_pt"].data_ptr(), ins[3].data_ptr(),
+                                      o["minimum_distance"].data_ptr(), o["argmin"].data_ptr(), o["surface_normals"].data_ptr(),
+                                      B, 1, 256, 256, prm.n_samples, tt.data_ptr(), *cam[:4], cam[4], 1,
+                                      float(prm.directional_intensity), None, None, None, g_ren.data_ptr(), None,
+                                      g_alb.data_ptr(), g_depth.data_ptr(), g_pt.data_ptr(), g_amb.data_ptr(), st), "gcfr_render_bwd")
+
+    for _ in range(5):
+        bwd_once()
+    t_ev[0].record()
+    for _ in range(30):
+        bwd_once()
+    t_ev[1].record()
+    torch.cuda.synchronize()
+    bwd_ms = t_ev[0].elapsed_time(t_ev[1]) / 30
+    if rank != 0:
         return None
-
-
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0     # wave-instructions/s: 1024 SIMDs, one wave64 VALU op per 4 cycles at 2.4 GHz
+    ray_steps = B * 256 * 256 * N_SAMPLES
+    value = world * ray_steps * a.steps / elapsed
+    pm = pmc_summary().get("kernels", {})
+    px_bytes = 72.0     # per pixel: reads depth 4 + albedo 12 + g_rendered 12 + min_dist 4 + argmin 4 + normals 12 (+ stencil
+    #                     neighbours from cache), writes grad_albedo 12 + grad_depth read-modify-write 8 + light partials ~0
+    bwd_roof = {"bound": "hbm", "kernel": "gcfr::render_bwd_single_light_kernel", "avg_launch_ms": bwd_ms,
+                "achieved": B * 65536 * px_bytes / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": B * 65536 * px_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": B * 65536 * px_bytes,
+                "traffic": pm.get("bwd", {}).get("hbm", {}).get("bytes_per_launch"),
+                "note": "one backward sample per pixel: compulsory I/O 72 B per pixel; what holds the kernel back is the L2's "
+                        "f32 atomic rate (4 bilinear-corner atomics per pixel: 78 of 167 us before same-texel merging, "
+                        "profiles/r02_bwd_stage_trace.txt, DESIGN.md 4.5), then f64 VALU issue"}
+    # (no VALU line here: the committed instruction mixes are those of tools/bwd_bench.py -- dense upstream gradient,
+    #  depth noise 2 -- not of this step's masked gradient and untrained-network depth; profiles/pmc_summary.json has
+    #  them with their own launch times: backward 0.40, training march 0.66 of the VALU issue capacity)
+    return {
+        "metric": "ray_steps_per_sec", "value": value, "unit": "ray-steps/s", "n_gpus": world, "steps": a.steps,
+        "warmup": max(a.warmup, 6), "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 network (MIOpen) + f64/f32 render block", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[%d]: batch=%d per GPU, full training step (RelightNet forward with the fused HIP "
+                               "render block, PatchGAN step every 5th iteration, seven losses, backward through the fused HIP "
+                               "backward, two Adam steps)%s" % (2 if world == 1 else 3, B,
+                                                               "" if world == 1 else ", DistributedDataParallel over RCCL"),
+                   "faces_per_gpu": B, "global_batch": B * world, "H": 256, "W": 256, "n_samples": N_SAMPLES,
+                   "parallelism": "dp%d" % world, "epoch": epoch},
+        "faces_per_sec": world * B * a.steps / elapsed,
+        "render_block_ms": {"forward_march_kernel": march_ms, "fused_backward_kernel": bwd_ms,
+                            "share_of_step": (march_ms + bwd_ms) / (1e3 * elapsed / a.steps),
+                            "note": "the step is MIOpen-bound (fp32 convolutions of the hourglass and PatchGAN); the render "
+                                    "block's two big kernels are this share of it"},
+        "roofline": bwd_roof,
+    }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3000)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--faces", type=int, default=FACES_PER_GPU, help="faces per GPU per step (configs[1]: 8)")
+    ap.add_argument("--steps", type=int, default=None, help="default: 3000 (render), 20 (train)")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 50 (render), 6 (train)")
+    ap.add_argument("--workload", choices=["render", "train"], default="render",
+                    help="render = BASELINE configs[1] (batch 8, forward); train = configs[2]/[3] (batch 32, full step)")
+    ap.add_argument("--faces", type=int, default=FACES_PER_GPU, help="faces per GPU per step (configs[1]: 8; train: 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--direct", action="store_true", help="A/B: direct-gather kernel (no workspace prepass)")
     ap.add_argument("--unfused", action="store_true", help="A/B: three separate entry points instead of gcfr_render_fwd")
@@ -235,12 +572,13 @@ def main():
                     help="also compute the normals (T8:353-354) inside the march epilogue instead of reading them "
                          "(SURVEY 8d's 17.4 B/ray-step accounting counts normals as a 12 B/pixel input, the default)")
     ap.add_argument("--streams", type=int, default=4,
-                    help="issue successive steps round-robin on this many HIP streams, one RenderFwdPlan (own outputs "
-                         "and workspace) per stream: independent batches overlap, the next step's prepass and "
-                         "prologue fill the previous march's tail (B=8 is 8192 waves for 256 CUs).  1 = one stream")
+                    help="batches in flight: successive steps go round-robin to this many HIP streams, one RenderFwdPlan (own "
+                         "outputs and workspace) per stream.  One launch cannot fill the chip to its end -- its duration is "
+                         "that of its heaviest tile (profiles/r02_schedule_experiments.md) -- a second batch at a different "
+                         "phase does.  1 = one batch at a time (also always reported as `single_stream`)")
     ap.add_argument("--no-graph", action="store_true",
-                    help="issue every step as a plan call (two kernel launches + event records, ~55 us of host time) "
-                         "instead of replaying the plan's captured hipGraph (~10 us)")
+                    help="issue every step as a plan call (two kernel launches, ~55 us of host time) instead of replaying "
+                         "the plan's captured hipGraph (~10 us)")
     ap.add_argument("--eager", action="store_true",
                     help="call render_fwd (allocates its outputs per call, ~60 us of host time) instead of a plan")
     ap.add_argument("--size", type=int, default=256, help="other workloads: image side (config 5: 512)")
@@ -252,225 +590,16 @@ def main():
     ap.add_argument("--mask", choices=["ellipse", "ones"], default="ellipse",
                     help="'ones' = worst case: no fully masked wave-step exists, nothing is skipped")
     ap.add_argument("--tune", type=str, default="",
-                    help="A/B: comma list of gcfr_options knobs, e.g. tile_w=32,schedule=0,tile_order=2,ksplit=1,"
-                         "depth_bound_skip=0,group=2 (never changes a result bit)")
+                    help="A/B: comma list of gcfr_options knobs, e.g. tile_w=32,ksplit=1,depth_bound_skip=0,group=2 "
+                         "(never changes a result bit)")
     a = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d" % (a.gpus, a.gpus))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
-
-    from geomconsistentfr_amd import RenderParams
-    from geomconsistentfr_amd import block as R
-
-    from geomconsistentfr_amd import _lib
-    knobs = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)}
-    base_opt = _lib.options(**knobs) if knobs else None
-    B = a.faces
-    headline = (a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse" and a.depth_noise == 0.0)
-    if headline:
-        prm = RenderParams()
-        depth, mask, albedo, normals, light, amb = synth_faces(B, seed0=rank * 1_000_000)
-    else:
-        prm = RenderParams(n_samples=a.samples, dt=0.8 / a.samples)
-        depth, mask, albedo, normals, light, amb = synth_faces_sized(B, rank * 1_000_000, a.size, a.lights, a.mask)
-    if a.depth_noise > 0.0:
-        depth = depth + (a.depth_noise * np.random.default_rng(7).random(depth.shape)).astype(np.float32)
-    Hh = Ww = a.size
-    Ll, Nn = a.lights, a.samples
-    d_depth = torch.from_numpy(depth).to(dev)
-    d_mask = torch.from_numpy(mask).to(dev)
-    d_albedo = torch.from_numpy(albedo).to(dev)
-    d_normals = torch.from_numpy(normals).to(dev)
-    d_light = torch.from_numpy(light).to(dev)
-    d_amb = torch.from_numpy(amb).to(dev)
-
-    # HIP events around the dominant (march) kernel alone, recorded on the launch stream by the library
-    # itself (gcfr_options.event_start / event_stop); created through the same HIP runtime torch loaded.
-    import ctypes
-    L_ = _lib.load()
-    # the exact file torch loaded (same inode -> the same runtime instance, never a second HIP runtime)
-    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
-    ev_pairs = []
-
-    def new_event():
-        e = ctypes.c_void_p()
-        assert hip.hipEventCreate(ctypes.byref(e)) == 0
-        return e
-
-    cam = (1570.0 * Hh / 256.0, 1570.0 * Hh / 256.0, Ww / 2.0, Hh / 2.0, 1610.0)
-    plans = None
-    if not (a.eager or a.direct or a.unfused):
-        d_mask_u8 = R.mask_to_u8(d_mask).reshape(-1, Hh, Ww).contiguous()
-        d_light3, d_amb2 = d_light.reshape(B, Ll, 3).contiguous(), d_amb.reshape(B, Ll).contiguous()
-        plans = [R.RenderFwdPlan(B, Ll, Hh, Ww, prm, dev, want_argmin=False, mask_batch=d_mask_u8.shape[0],
-                                 camera=cam if a.from_depth else None, options=base_opt)
-                 for _ in range(max(1, a.streams))]
-
-    use_graph = plans is not None and not a.no_graph
-    graph_error = None
-    if use_graph:
-        try:
-            for p_ in plans:
-                p_.capture(d_depth, d_mask_u8, d_light3, d_amb2, None if a.from_depth else d_normals, d_albedo)
-        except Exception as e:      # a runtime that cannot capture: same kernels, issued call by call
-            graph_error, use_graph = repr(e), False
-            torch.cuda.synchronize()
-
-    def step(timed):
-        if use_graph and step.graph_ok:      # timed region: one hipGraph replay per step (no per-launch events)
-            return plans[step.i % len(plans)].replay()
-        opt = base_opt
-        if timed:        # this call's options carry an event pair the library records around the march kernel
-            e0, e1 = new_event(), new_event()
-            opt = _lib.options(**knobs, event_start=e0, event_stop=e1)
-            ev_pairs.append((e0, e1, opt))
-        if plans is not None:
-            pl_ = plans[step.i % len(plans)]
-            pl_.options = opt
-            out = pl_(d_depth, d_mask_u8, d_light3, d_amb2, None if a.from_depth else d_normals, d_albedo)
-            pl_.options = base_opt
-        elif a.direct or a.unfused:
-            _, pt = R.light_prep(d_light, prm)
-            md, _ = R.shadow_min_distance(d_depth, d_mask, pt.reshape(B, Ll, 3), prm, want_argmin=False,
-                                          use_workspace=not a.direct, options=opt)
-            out = R.shade(d_normals, d_depth, d_albedo, pt.reshape(B, Ll, 3), d_amb.reshape(B, Ll), md, prm)
-        else:
-            out = R.render_fwd(d_depth, d_mask, d_light.reshape(B, Ll, 3), d_amb.reshape(B, Ll),
-                               None if a.from_depth else d_normals, d_albedo, prm, want_argmin=False,
-                               camera=cam if a.from_depth else None, options=opt)
-        return out
-
-    streams = [torch.cuda.Stream(device=dev) for _ in range(a.streams)] if a.streams > 1 else None
-    step.graph_ok = True
-    step.i = 0
-
-    def run_step(i, timed):
-        step.i = i
-        if streams is None:
-            return step(timed)
-        with torch.cuda.stream(streams[i % len(streams)]):
-            return step(timed)
-
-    for i in range(a.warmup):
-        run_step(i, False)
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        run_step(i, True)
-    host_issue = time.perf_counter() - t0      # host time to enqueue every step (before waiting for the GPU)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    def single_stream_reference(n=100):
-        """the same steps on ONE stream, after the timed region (information only): per-step time and the
-        march's un-overlapped launch duration"""
-        saved = ev_pairs[:]
-        del ev_pairs[:]
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(n):
-            step.i = 0
-            step(True)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        ms = float(np.mean([elapsed_ms(e0, e1) for e0, e1, _ in ev_pairs]))
-        ev_pairs[:] = saved
-        return {"ms_per_step": 1e3 * dt / n, "ray_steps_per_sec": B * Ll * Hh * Ww * Nn * n / dt, "avg_launch_ms": ms}
-
-    ray_steps_per_step = world * B * Ll * Hh * Ww * Nn
-    value = ray_steps_per_step * a.steps / elapsed
-    def elapsed_ms(e0, e1):
-        ms = ctypes.c_float()
-        assert hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1) == 0
-        return ms.value
-
-    if use_graph:   # graph replays carry no per-launch events: measured below, on one stream
-        shadow_ms = None
-    else:
-        shadow_ms = float(np.mean([elapsed_ms(e0, e1) for e0, e1, _ in ev_pairs]))
-    # With several streams the launches of successive steps overlap: an event pair then brackets a kernel that
-    # shares the GPU (and rocprofv3's tracing perturbs that overlap, so its average could not agree).  The
-    # roofline therefore uses the kernel's UN-overlapped duration, measured live right after the timed region
-    # with the same events over 100 launches of the same step on one stream; profiles/ holds the rocprofv3
-    # summary of `bench.py --streams 1`, which that number agrees with.  The overlapped mean is kept beside it.
-    overlapped_ms = None
-    single = None
-    if (streams is not None or use_graph) and not a.direct:
-        step.graph_ok = False                      # plan calls with the library's event hook, one stream
-        single = single_stream_reference()
-        step.graph_ok = True
-        overlapped_ms, shadow_ms = shadow_ms, single["avg_launch_ms"]
-    algo_bytes = B * Ll * Hh * Ww * Nn * ALGO_BYTES_PER_RAY_STEP          # per launch (one rank)
-    achieved = algo_bytes / (shadow_ms * 1e-3) / 1e9
-
+    if a.steps is None:
+        a.steps = 3000 if a.workload == "render" else 20
+    if a.warmup is None:
+        a.warmup = 50 if a.workload == "render" else 6
+    rank, world, dev, dist = setup_distributed(a)
+    out = (run_render if a.workload == "render" else run_train)(a, rank, world, dev, dist)
     if rank == 0:
-        out = {
-            "metric": "ray_steps_per_sec", "value": value, "unit": "ray-steps/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+f32",
-            "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: batch=%d synthetic 256x256 faces per GPU, 1 light each, "
-                                    "160 march steps, forward-only shadow+shade" % B) if headline else
-                                   ("non-headline: batch=%d synthetic %dx%d faces per GPU, %d light(s) each, %d march "
-                                    "steps, mask=%s, depth noise %g, forward-only shadow+shade" % (B, Hh, Ww, Ll, Nn, a.mask, a.depth_noise)),
-                       "faces_per_gpu": B, "H": Hh, "W": Ww, "lights_per_face": Ll, "n_samples": Nn,
-                       "parallelism": "dp%d" % world, "hip_streams": (a.streams if plans is not None or streams else 1),
-                       "host_path": ("RenderFwdPlan, hipGraph replay" if use_graph else "RenderFwdPlan (preallocated outputs)")
-                       if plans is not None else "render_fwd (eager)"},
-            "faces_per_sec": world * B * Ll * a.steps / elapsed,
-            "host_issue_ms_per_step": 1e3 * host_issue / a.steps,
-            "ray_steps_per_sec_per_gpu": value / world,
-            "roofline": {"bound": "hbm", "note": "north_star's HBM accounting; the gathers are cache-served (traffic << "
-                         "algorithmic bytes, so frac can exceed 1) and the kernel is VALU-issue bound -- DESIGN.md 4.1",
-                         "kernel": "shadow_fwd_quad_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(),
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": shadow_ms,
-                         "kernel_ray_steps_per_sec": B * Ll * Hh * Ww * Nn / (shadow_ms * 1e-3),
-                         "measured_copy_GBs": measured_copy_bandwidth_gbs(dev)},
-        }
-        if graph_error:
-            out["config"]["graph_capture_failed"] = graph_error
-        vi = pmc_valu_insts()
-        if vi:   # what actually bounds the kernel (DESIGN.md 4.1): VALU issue, not HBM
-            out["roofline"]["valu"] = {"insts_per_launch": vi, "insts_per_nominal_ray_step": vi / (B * Ll * Hh * Ww * Nn),
-                                       "achieved_insts_per_s": vi / (shadow_ms * 1e-3), "peak_insts_per_s": VALU_ISSUE_PEAK,
-                                       "frac": vi / (shadow_ms * 1e-3) / VALU_ISSUE_PEAK,
-                                       "note": "wave64 VALU instructions (rocprofv3 SQ_INSTS_VALU, headline config) per "
-                                               "un-overlapped launch against 1024 SIMDs x 1 issue / 4 cycles"} if headline else None
-        if single is not None:
-            out["roofline"]["note"] += ("; avg_launch_ms is the kernel's un-overlapped duration (100 launches on one "
-                                        "stream right after the timed region, HIP events around the kernel)")
-            if overlapped_ms is not None:
-                out["roofline"]["note"] += "; with %d streams in flight an event pair spans %.4f ms" % (a.streams, overlapped_ms)
-                out["roofline"]["avg_launch_ms_overlapped"] = overlapped_ms
-            out["single_stream"] = single
-        if world == 1 and not a.no_cpu_baseline and headline:
-            out["cpu_baseline"] = cpu_baseline()
-            out["cpu_baseline_c_openmp"] = cpu_baseline_c()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void k(unsigned long long *cycles, double *sin
     const double c = seed * 1.000001;
     const float cf = (float)c;
     const int ci = (int)threadIdx.x | 3;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #define F2(INS, j) asm volatile(INS " %0, %0, %1" : "+v"(f[j]) : "v"(cf));
@@ -155,13 +156,16 @@ __global__ __launch_bounds__(256) void k(unsigned long long *cycles, double *sin
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
         s += a[j] + (double)f[j] + (double)i[j];
     sink[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if ((threadIdx.x & 63) == 0)
-        cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) {
+        cycles[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2] = t1 - t0;
+        cycles[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 1] = r1 - r0;
+    }
 }
 
 template <int OP>
@@ -182,15 +186,18 @@ static void run(unsigned long long *d_cyc, double *d_sink, int cus, double wall_
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
-        std::vector<unsigned long long> h(blocks * 4);
+        std::vector<unsigned long long> h(blocks * 4 * 2);
         hipMemcpy(h.data(), d_cyc, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost);
-        double mean = 0.0;
-        for (auto v : h)
-            mean += (double)v;
-        mean /= (double)h.size();
+        double mean = 0.0, mean_real = 0.0;
+        for (size_t q = 0; q < h.size(); q += 2) {
+            mean += (double)h[q];
+            mean_real += (double)h[q + 1];
+        }
+        mean /= (double)(h.size() / 2);
+        mean_real /= (double)(h.size() / 2);
         const double per_instr = mean / ((double)iters * 16.0 * w);
         const double wall_cyc = ms * 1e-3 * wall_ghz * 1e9 / ((double)iters * 16.0 * w);
-        printf("  w=%d: %5.2f (wall %5.2f)", w, per_instr, wall_cyc);
+        printf("  w=%d: %5.2f (wall %5.2f, memtime %4.0f MHz)", w, per_instr, wall_cyc, mean / mean_real * 100.0);
         hipEventDestroy(e0);
         hipEventDestroy(e1);
     }
@@ -215,12 +222,12 @@ int main()
     const double ghz = khz / 1e6;
     unsigned long long *d_cyc;
     double *d_sink;
-    hipMalloc(&d_cyc, (size_t)cus * 8 * 4 * sizeof(unsigned long long));
+    hipMalloc(&d_cyc, (size_t)cus * 8 * 4 * 2 * sizeof(unsigned long long));
     hipMalloc(&d_sink, (size_t)cus * 8 * 256 * sizeof(double));
     printf("%s: %d CUs, nominal %.2f GHz.  Columns: s_memtime cycles per wave64 instruction per SIMD at w waves/SIMD\n"
            "(16 independent chains per wave, ~1.05 M instructions per wave; 'wall' = the same from the event time at the\n"
-           "nominal clock -- larger when the chip clocks below nominal).  NB s_memtime counts at a FIXED 100 MHz on\n"
-           "gfx9 if the two columns differ by ~24x; then trust 'wall'.\n", prop.name, cus, ghz);
+           "nominal clock -- larger when the chip clocks below nominal); 'memtime MHz' = s_memtime ticks per second, from the\n"
+           "constant 100 MHz s_memrealtime counter read beside it.\n", prop.name, cus, ghz);
     run_all<0>(d_cyc, d_sink, cus, ghz);
     return 0;
 }
