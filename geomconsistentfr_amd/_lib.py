@@ -71,6 +71,8 @@ _SIGNATURES = {
     "gcfr_render_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _d, _d, _d, _d, _f, _i, _f, _p, _p, _p, _p, _p,
                              _p, _p, _p, _p, _p]),
     "gcfr_light_prep_bwd": (_i, [_p, _i, _i, _f, _f, _p, _p, _p, _p]),
+    "gcfr_inference_images_u8": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "gcfr_fix_border_u8": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
 }
 
 

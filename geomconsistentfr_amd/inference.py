@@ -44,7 +44,7 @@ def camera_matrix(focal: float, H: int = 256, W: int = 256, device="cpu") -> tor
 
 
 def _as_batch(images) -> torch.Tensor:
-    x = torch.as_tensor(np.asarray(images), dtype=torch.float32)
+    x = images.to(torch.float32) if torch.is_tensor(images) else torch.as_tensor(np.asarray(images), dtype=torch.float32)
     return x[None] if x.dim() == 3 else x
 
 
@@ -66,11 +66,24 @@ def relight_batch(model: RelightNetSingleImage, images, masks_u8, lights, ambien
 @torch.no_grad()
 def relight_single_image(model: RelightNetSingleImage, image, mask_u8, light, ambient: float = 0.5,
                          focal: float = 1570.0, device="cuda") -> np.ndarray:
-    """S1:569-620 for one image: returns the composite (H,W,3) uint8 RGB (rendered face pasted into the input)."""
-    out = relight_batch(model, image, mask_u8, np.asarray(light, np.float32)[None], ambient, focal, device)
-    comp = pp.composite_into_input(np.asarray(image, np.float64), out[5][0].cpu().numpy(),
-                                   np.asarray(mask_u8, np.float64) / 255.0)
-    return pp.to_uint8(comp)
+    """S1:569-620 for one image: returns the composite (H,W,3) uint8 RGB (rendered face pasted into the input),
+    composited and quantised on the device (gcfr_inference_images_u8); `fix_border=True` also applies
+    fix_border_artifacts_CVPR2022.m there."""
+    return relight_images(model, image, mask_u8, np.asarray(light, np.float32)[None], ambient, focal, device)[0]
+
+
+@torch.no_grad()
+def relight_images(model: RelightNetSingleImage, images, mask_u8, lights, ambient: float = 0.5, focal: float = 1570.0,
+                   device="cuda", fix_border: bool = False) -> np.ndarray:
+    """Batch form of S1:569-620 (+ the MATLAB border fix): (B,H,W,3) uint8 RGB composites.  Forward, compositing,
+    quantisation and the border fix all run on the device; one device-to-host copy of B*H*W*3 bytes at the end."""
+    x = _as_batch(images).to(device)
+    out = relight_batch(model, x, mask_u8, lights, ambient, focal, device)
+    mask = torch.as_tensor(np.asarray(mask_u8), dtype=torch.uint8, device=device)
+    imgs = pp.inference_images_device(x, out[5], mask)["rendered_image"]
+    if fix_border:
+        imgs = pp.fix_border_artifacts_device(imgs, mask)
+    return imgs.cpu().numpy()
 
 
 @torch.no_grad()
@@ -78,7 +91,7 @@ def lighting_transfer(model: RelightNetLightingTransfer, input_image, reference_
                       focal: float = 700.0, device="cuda") -> Dict[str, np.ndarray]:
     """SLT:535-579: pass 1 on the reference image with a zero target light reads the estimated light and ambient
     (SLT:543); pass 2 relights the input image with them (SLT:545).  Returns the six images SLT:574-579 writes
-    (float [0,255]) plus the estimated light."""
+    (uint8 RGB / single channel, composited and quantised on the device) plus the estimated light."""
     xin, xref = _as_batch(input_image).to(device), _as_batch(reference_image).to(device)
     _, H, W, _ = xin.shape
     K = camera_matrix(focal, H, W, device)
@@ -88,9 +101,10 @@ def lighting_transfer(model: RelightNetLightingTransfer, input_image, reference_
     est = model(xref, 200, K, mask, zero_l, zero_a)
     est_light, est_amb = est[10], est[11]
     out = model(xin, 200, K, mask, est_light.reshape(1, 3, 1, 1).float(), est_amb.reshape(1, 1, 1).float())
-    imgs = pp.diagnostic_images(np.asarray(input_image, np.float64), out[0][0].cpu().numpy(), out[1].cpu().numpy(), 0,
-                                out[2][0].cpu().numpy(), out[5][0].cpu().numpy(), out[8][0].cpu().numpy(),
-                                out[9][0].cpu().numpy(), np.asarray(mask_u8, np.float64) / 255.0)
+    m_u8 = torch.as_tensor(np.asarray(mask_u8), dtype=torch.uint8, device=device)
+    dev_imgs = pp.inference_images_device(xin, out[5], m_u8, albedo=out[0], depth=out[1], shadow_mask_weights=out[2],
+                                          final_shading=out[8], surface_normals=out[9])
+    imgs = {k: v[0].cpu().numpy() for k, v in dev_imgs.items()}                # uint8, what SLT:574-579 writes
     imgs["estimated_light"] = est_light.reshape(3).cpu().numpy()
     imgs["estimated_ambient"] = est_amb.reshape(1).cpu().numpy()
     return imgs

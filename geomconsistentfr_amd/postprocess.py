@@ -1,4 +1,9 @@
-"""Callers and data formats either side of the render block -- host side, numpy.
+"""Callers and data formats either side of the render block.
+
+Device path (HIP kernels of csrc/gcfr_postprocess.hip, no CPU fallback): `inference_images_device`,
+`fix_border_artifacts_device` -- what the inference mirrors use, so a relit batch leaves the GPU as bytes.
+Host side, numpy (file formats, offline metrics, and the host statements of the two device functions that
+the parity tests compare them with):
 
 What the reference's inference scripts do with the block's outputs, and how its training script reads
 its inputs, restated as functions (the scripts themselves -- argv parsing, hard-coded paths, PNG
@@ -38,7 +43,8 @@ def composite_into_input(input_image: np.ndarray, rendered: np.ndarray, mask: np
     (the reference divides the 4-level skin mask by 255).  Returns (H,W,3) float in [0,255]."""
     m3 = _mask3(mask)
     out = np.asarray(input_image, dtype=np.float64) * 255.0
-    ren = 255.0 * np.transpose(np.asarray(rendered, dtype=np.float64), (1, 2, 0)) * m3
+    # 255.0*rendered_images[k] is an f32 product in the scripts (numpy keeps the array's dtype), widened by the f64 mask
+    ren = (np.float32(255.0) * np.transpose(np.asarray(rendered, dtype=np.float32), (1, 2, 0))).astype(np.float64) * m3
     sel = m3 > 0
     out[sel] = ren[sel]
     return out
@@ -52,17 +58,86 @@ def diagnostic_images(input_image, albedo, depth_batch, index, shadow_mask_weigh
     albedo (3,H,W), shadow_mask_weights (H,W), rendered (3,H,W), final_shading (H,W), surface_normals (3,H,W)."""
     m3 = _mask3(mask)
     m1 = m3[..., 0]
-    d = -np.asarray(depth_batch, dtype=np.float64)
+    f32, k255 = np.float32, np.float32(255.0)
+    d = -np.asarray(depth_batch, dtype=f32)                       # the scripts' arrays are f32 until the f64 mask
     d = (d - d.min()) / (d.max() - d.min())
-    hwc = lambda a: np.transpose(np.asarray(a, dtype=np.float64), (1, 2, 0))
+    hwc = lambda a: np.transpose(np.asarray(a, dtype=f32), (1, 2, 0))
+    wide = lambda a: a.astype(np.float64)
     return {
         "rendered_image": composite_into_input(input_image, rendered, mask),
-        "shadow_mask": 255.0 * np.asarray(shadow_mask_weights, dtype=np.float64) * m1,
-        "albedo": 255.0 * hwc(albedo) * m3,
-        "depth": 255.0 * d[index, 0] * m1,
-        "shading": 255.0 * np.asarray(final_shading, dtype=np.float64) * m1,
-        "surface_normals": (255.0 * (hwc(surface_normals) + 1.0) / 2.0) * m3,
+        "shadow_mask": wide(k255 * np.asarray(shadow_mask_weights, dtype=f32)) * m1,
+        "albedo": wide(k255 * hwc(albedo)) * m3,
+        "depth": wide(k255 * d[index, 0]) * m1,
+        "shading": wide(k255 * np.asarray(final_shading, dtype=f32)) * m1,
+        "surface_normals": wide(k255 * (hwc(surface_normals) + f32(1.0)) / f32(2.0)) * m3,
     }
+
+
+# ------------------------------------------------------------------------------------------------
+# device path (csrc/gcfr_postprocess.hip)
+# ------------------------------------------------------------------------------------------------
+def inference_images_device(input_images, rendered, mask_u8, albedo=None, depth=None, shadow_mask_weights=None,
+                            final_shading=None, surface_normals=None):
+    """The images S1:614-620 / S8:603-608 / SLT:574-579 write, as uint8 device tensors (RGB, HWC), straight from the
+    forward's device outputs: `rendered_image` always, the five diagnostic maps for whichever inputs are given.
+    input_images (B,H,W,3) f32 in [0,1]; rendered / albedo / surface_normals (B,3,H,W); depth (B,1,H,W) or (B,H,W);
+    shadow_mask_weights / final_shading (B,H,W); mask_u8 (1|B,H,W) or (H,W) uint8 skin mask as stored on disk (the kernel
+    forms the scripts' f64 mask/255.0 itself)."""
+    import torch
+    from . import _lib
+    L_ = _lib.load()
+    x = input_images
+    if not x.is_cuda:
+        raise _lib.GcfrError("geomconsistentfr_amd has no CPU path: tensors must be on a ROCm device")
+    f = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+    x, rendered = f(x), f(rendered)
+    B, H, W, _ = x.shape
+    if mask_u8.dtype != torch.uint8:
+        raise _lib.GcfrError("mask_u8 must be the uint8 skin mask (0..255)")
+    m = mask_u8.to(x.device).contiguous().reshape(-1, H, W)
+    albedo, shadow_mask_weights, final_shading, surface_normals = f(albedo), f(shadow_mask_weights), f(final_shading), f(surface_normals)
+    drange = None
+    if depth is not None:
+        depth = f(depth).reshape(B, H, W)
+        neg = -depth
+        drange = torch.stack([neg.amin(), neg.amax()]).contiguous()              # stays on the device: no sync
+    u8 = lambda *shape: torch.empty(shape, dtype=torch.uint8, device=x.device)
+    out = {"rendered_image": u8(B, H, W, 3)}
+    if shadow_mask_weights is not None:
+        out["shadow_mask"] = u8(B, H, W)
+    if albedo is not None:
+        out["albedo"] = u8(B, H, W, 3)
+    if depth is not None:
+        out["depth"] = u8(B, H, W)
+    if final_shading is not None:
+        out["shading"] = u8(B, H, W)
+    if surface_normals is not None:
+        out["surface_normals"] = u8(B, H, W, 3)
+    p = lambda t: None if t is None else t.data_ptr()
+    with torch.cuda.device(x.device):
+        _lib.check(L_.gcfr_inference_images_u8(
+            x.data_ptr(), rendered.data_ptr(), p(albedo), p(depth), p(drange), p(shadow_mask_weights), p(final_shading),
+            p(surface_normals), m.data_ptr(), m.shape[0], B, H, W, out["rendered_image"].data_ptr(), p(out.get("shadow_mask")),
+            p(out.get("albedo")), p(out.get("depth")), p(out.get("shading")), p(out.get("surface_normals")),
+            torch.cuda.current_stream(x.device).cuda_stream), "gcfr_inference_images_u8")
+    return out
+
+
+def fix_border_artifacts_device(img_u8, face_mask_u8):
+    """fix_border_artifacts_CVPR2022.m on the device: img_u8 (B,H,W,3) uint8, face_mask_u8 (1|B,H,W) or (H,W) uint8
+    skin mask as stored on disk.  Returns a new (B,H,W,3) uint8 tensor."""
+    import torch
+    from . import _lib
+    if not img_u8.is_cuda:
+        raise _lib.GcfrError("geomconsistentfr_amd has no CPU path: tensors must be on a ROCm device")
+    img = img_u8.contiguous()
+    B, H, W, _ = img.shape
+    mk = face_mask_u8.to(img.device, torch.uint8).contiguous().reshape(-1, H, W)
+    out = torch.empty_like(img)
+    with torch.cuda.device(img.device):
+        _lib.check(_lib.load().gcfr_fix_border_u8(img.data_ptr(), mk.data_ptr(), mk.shape[0], B, H, W, out.data_ptr(),
+                                                  torch.cuda.current_stream(img.device).cuda_stream), "gcfr_fix_border_u8")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -250,6 +250,43 @@ int gcfr_light_prep_bwd(const float *light_raw, int32_t n, int32_t clamp_z, floa
                         float light_distance, const float *grad_unit, const double *grad_light_pt,
                         float *grad_light_raw, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Inference-side consumers of the block's outputs: what the test scripts do between the forward
+ * and cv2.imwrite, and the MATLAB border fix -- on the device, so a relit batch leaves it as bytes.
+ * ------------------------------------------------------------------------------------------- */
+
+/*
+ * The images the inference scripts write per face, quantised as cv2.imwrite quantises a float image
+ * (round half to even, clip to [0, 255]); RGB, HWC -- the bytes that end up in the PNG.
+ * Replaces test_relight_single_image.py:601-620 (rendered image only) and
+ * test_raytracing_relighting_CelebAHQ_DSSIM_8x.py:583-608 / ..._lighting_transfer.py:560-579 (all six).
+ *   input_hwc     (B,H,W,3) f32 in [0,1]   the photograph, as the scripts hold it (training_images)
+ *   rendered      (B,3,H,W) f32            rendered_images                   -> out_rendered (B,H,W,3): the relit face
+ *                                          pasted into the photograph where mask > 0
+ *   albedo        (B,3,H,W) f32 or NULL    -> out_albedo  (B,H,W,3) = 255 albedo mask
+ *   depth         (B,H,W) f32 or NULL      -> out_depth   (B,H,W)   = 255 (-depth - lo)/(hi - lo) mask, with
+ *   depth_range   DEVICE {lo, hi} f32      = min / max of -depth over the whole batch (S8:589-590)
+ *   shadow_w, final_shading (B,H,W) f32 or NULL -> out_shadow, out_shading (B,H,W) = 255 x mask
+ *   normals       (B,3,H,W) f32 or NULL    -> out_normals (B,H,W,3) = 255 (n + 1)/2 mask
+ *   mask          (MB,H,W) u8               the skin mask as read from disk; the kernel forms the scripts' f64
+ *                                          mask/255.0 (S1:580) itself; MB = 1 or B
+ * Any out_* except out_rendered may be NULL.
+ */
+int gcfr_inference_images_u8(const float *input_hwc, const float *rendered, const float *albedo, const float *depth,
+                             const float *depth_range, const float *shadow_w, const float *final_shading,
+                             const float *normals, const uint8_t *mask, int32_t mask_batch, int32_t B, int32_t H,
+                             int32_t W, uint8_t *out_rendered, uint8_t *out_shadow, uint8_t *out_albedo,
+                             uint8_t *out_depth, uint8_t *out_shading, uint8_t *out_normals, void *stream);
+
+/*
+ * fix_border_artifacts_CVPR2022.m:1-18: pixels on the border of the face mask (0 < 7x7 box sum of the rounded
+ * mask < 30, zero padding) take the 3x3 median (zero padding) of their channel.
+ *   img_hwc (B,H,W,3) u8;  face_mask_u8 (MB,H,W) u8 skin mask as stored on disk (0 ... 255);  out_hwc (B,H,W,3) u8,
+ *   must not alias img_hwc.
+ */
+int gcfr_fix_border_u8(const uint8_t *img_hwc, const uint8_t *face_mask_u8, int32_t mask_batch, int32_t B, int32_t H,
+                       int32_t W, uint8_t *out_hwc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,8 @@ def test_composite_into_input_matches_a_per_pixel_restatement():
     for r in range(H):
         for c in range(W):
             for ch in range(3):
-                exp = 255.0 * ren[ch, r, c] * mask[r, c] if mask[r, c] > 0 else inp[r, c, ch] * 255.0   # S1:616-619
+                # S1:616-619: 255.0*rendered is an f32 product (rendered_images is an f32 array), widened by the f64 mask
+                exp = float(np.float32(255.0) * np.float32(ren[ch, r, c])) * mask[r, c] if mask[r, c] > 0 else inp[r, c, ch] * 255.0
                 assert got[r, c, ch] == exp
 
 
@@ -34,9 +35,9 @@ def test_diagnostic_images_follow_s8():
     out = pp.diagnostic_images(rng.random((H, W, 3)), rng.random((3, H, W)), depth, 1, rng.random((H, W)),
                                rng.random((3, H, W)), rng.random((H, W)), rng.standard_normal((3, H, W)), mask)
     assert set(out) == {"rendered_image", "shadow_mask", "albedo", "depth", "shading", "surface_normals"}
-    d = -depth
+    d = -depth.astype(np.float32)                                             # the forward's outputs are f32 arrays
     d = (d - d.min()) / (d.max() - d.min())                                   # S8:589-590: over the batch
-    np.testing.assert_allclose(out["depth"], 255.0 * d[1, 0] * mask)
+    np.testing.assert_array_equal(out["depth"], (np.float32(255.0) * d[1, 0]).astype(np.float64) * mask)
     assert out["surface_normals"].shape == (H, W, 3) and out["shadow_mask"].shape == (H, W)
     assert np.all(out["albedo"][mask == 0] == 0)
 
