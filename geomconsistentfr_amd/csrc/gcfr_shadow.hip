@@ -780,6 +780,14 @@ __device__ inline ImageStats reduce_image_stats(ArgPtr a, int b, int lane, bool 
 #ifndef GCFR_TILE_INLINE
 #define GCFR_TILE_INLINE __forceinline__
 #endif
+// lane id from the hardware (two VALU), opaque to the optimiser: a value derived from it has no live range before this point
+__device__ inline int fresh_lane_id()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, int SPLIT, bool ALL_ONES = false>
 __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy, const int tx,
                                            const ImageStats &st)
@@ -1280,7 +1288,11 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         }
     }
 
-    const float den = __builtin_sqrtf(((BCx * BCx + BCy * BCy) + BCz * BCz) + kEps4);
+    // (BCx laundered: otherwise the prologue's BCx^2 + BCy^2 is kept in a register across the whole sample loop for this
+    //  one use -- the last value the six-wave build spilled)
+    float BCx_e = BCx;
+    asm volatile("" : "+v"(BCx_e));
+    const float den = __builtin_sqrtf(((BCx_e * BCx_e + BCy * BCy) + BCz * BCz) + kEps4);
     float d = __builtin_sqrtf(bestS) / den;
     // torch.min (T8:514) returns the FIRST index of the minimal distance: see first_tied_sample.
     if (WANT_ARGMIN) {
@@ -1324,7 +1336,20 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     const bool inside = (Cx >= ep->bx_lo) && (Cx <= ep->bx_hi) && (Cy >= ep->by_lo) && (Cy <= ep->by_hi);
     if (inside)
         d = d + ep->bonus;
-    if (valid) {
+    // The pixel's row / column / validity are RE-DERIVED here from a fresh lane id instead of being kept live across the
+    // sample loop: at the forced six waves per SIMD (80 VGPRs) they were exactly what the register allocator spilled
+    // (r, c and the 64-bit pixel index: 16-20 B of scratch per lane, stored before the loop and reloaded after it --
+    // cheap in time, but the scratch arena of every resident wave is written back to HBM once per launch: +15 MB).
+    {
+        const int lane_e = fresh_lane_id();
+        const int r_e = qy * TILE_H + lane_e / TILE_W, c_e = tx * TILE_W + (lane_e % TILE_W);
+        const bool valid_e = (r_e < H) && (c_e < W);
+        r = valid_e ? r_e : H - 1;
+        c = valid_e ? c_e : W - 1;
+        if (!valid_e)
+            return;
+    }
+    {
         const size_t pix = (size_t)r * W + c;
         const size_t o = (size_t)bl * P + pix;
         ep->min_dist[o] = d;
