@@ -329,7 +329,7 @@ __attribute__((amdgpu_waves_per_eu(FUSED ? GCFR_BWD_WAVES_PER_EU : 4))) void sha
     double nx, ny, nz;
     if (FUSED) {  // the f32 unit normal the forward epilogue fed to shade_pixel()
         float n[3];
-        unit_normal<true>(a.nrm, zimg, r, c, n);
+        unit_normal(a.nrm, zimg, r, c, n);
         nx = n[0];
         ny = n[1];
         nz = n[2];
@@ -513,7 +513,7 @@ __attribute__((amdgpu_waves_per_eu(GCFR_BWD1_WAVES_PER_EU, GCFR_BWD1_WAVES_PER_E
                 n[1] = a.normals[((size_t)b * 3 + 1) * P + pp];
                 n[2] = a.normals[((size_t)b * 3 + 2) * P + pp];
             } else {
-                unit_normal<true>(a.nrm, zimg, r, c, n);
+                unit_normal(a.nrm, zimg, r, c, n);
             }
             float nn = __builtin_sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
             nn = nn > 1e-12f ? nn : 1e-12f;
@@ -627,7 +627,7 @@ __attribute__((amdgpu_waves_per_eu(GCFR_BWD1_WAVES_PER_EU, GCFR_BWD1_WAVES_PER_E
                 }
             }
         }
-        const double ax = ((double)c - a.nrm.cx) * fast_rcp64(a.nrm.fx), ay = ((double)r - a.nrm.cy) * fast_rcp64(a.nrm.fy);
+        const double ax = ((double)c - a.nrm.cx) * a.nrm.inv_fx, ay = ((double)r - a.nrm.cy) * a.nrm.inv_fy;
         atomicAdd(gz + p, (float)((ax * Sx + ay * Sy + Sz) + gzb));
     }
     // The four bilinear-corner atomics of the argmin samples were 78 of this kernel's 167 us: neighbouring pixels march
@@ -861,8 +861,7 @@ extern "C" int gcfr_render_bwd(const float *depth, const float *albedo, const fl
     a.nrm.depth = depth;
     a.nrm.H = H;
     a.nrm.W = W;
-    a.nrm.fx = fx;
-    a.nrm.fy = fy;
+    set_focal(a.nrm, fx, fy);
     a.nrm.cx = cx;
     a.nrm.cy = cy;
     a.nrm.z_offset = z_offset;

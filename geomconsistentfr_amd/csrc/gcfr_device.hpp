@@ -143,7 +143,15 @@ struct NormalsArgs {
     double fx, fy, cx, cy;
     float z_offset;
     int32_t negate_y;
+    double inv_fx, inv_fy;  // 1/fx, 1/fy, IEEE divisions done once on the host (set_focal)
 };
+inline void set_focal(NormalsArgs &a, double fx, double fy)
+{
+    a.fx = fx;
+    a.fy = fy;
+    a.inv_fx = 1.0 / fx;
+    a.inv_fy = 1.0 / fy;
+}
 
 // Sobel weights (already / 8) indexed [dr+1][dc+1]
 __device__ constexpr double kSobelU[3][3] = {{-0.125, 0.0, 0.125}, {-0.25, 0.0, 0.25}, {-0.125, 0.0, 0.125}};
@@ -154,8 +162,8 @@ struct Grad3 {
 };
 
 // 1/x to full f64 precision (<= 1 ulp) in 5 instructions instead of the ~17 of an IEEE division: v_rcp_f64 seed (about
-// 2^-26) and two Newton steps.  BACKWARD kernels only -- gradients are compared under tolerances, never bit for
-// bit -- and only for normal, non-zero x (norms clamped to >= 1e-12, focal lengths, distances).
+// 2^-26) and two Newton steps.  Normals (forward and backward) and backward kernels only -- quantities compared under
+// tolerances, never bit for bit -- and only for normal, non-zero x (norms clamped to >= 1e-12, distances).
 __device__ inline double fast_rcp64(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
@@ -165,7 +173,7 @@ __device__ inline double fast_rcp64(double x)
 }
 
 // sqrt(x) to ~1 ulp of f64 in 8 instructions instead of the ~30 of the IEEE routine: v_rsq_f64 seed and two coupled
-// Newton steps (Goldschmidt).  BACKWARD kernels only, x normal and > 0 (squared norms with a +1e-4 / >= 1e-24 floor).
+// Newton steps (Goldschmidt).  Normals and backward kernels only, x normal and > 0 (squared norms with a floor).
 __device__ inline double fast_sqrt64(double x)
 {
     double y = __builtin_amdgcn_rsq(x);       // ~2^-26
@@ -179,65 +187,70 @@ __device__ inline double fast_sqrt64(double x)
 }
 
 // dP/du and dP/dv at pixel (r,c); neighbours are clamped to the image (replicate padding).
-// FAST = false: the forward's arithmetic, (c - cx) / fx * d with an IEEE division (what the march epilogue and the
-// stand-alone forward kernel share, so both produce the same bits).  FAST = true (backward recomputation): the
-// divisions become multiplications by 1/fx, 1/fy -- at most an ulp of f64 away, far below the f32 normal it feeds.
-template <bool FAST>
+// One arithmetic for the forward (march epilogue, stand-alone kernel) and the backward's recomputation, so all of them
+// see the same bits.  The reference's chain is f64 by promotion (kornia: (u - cx)/fx * d, an F.conv2d whose summation
+// order is unspecified, cross, normalise) and its result is compared under a tolerance after rounding to f32; what
+// matters here is instruction count -- this runs once per pixel in the march epilogue, where round 2 counted 260 f64
+// instructions per pixel (six IEEE divisions, three more and an IEEE sqrt in the normalisation, 108 multiply-adds of
+// which a third multiplied by the Sobel kernels' zeros): a quarter of the march's per-tile fixed cost.  Now: the
+// pixel-to-ray factors are (c - cx) * (1/fx) with the reciprocal from the host, the zero taps are skipped -- except the
+// centre's 0 * d, kept so that a NaN / inf depth at the pixel itself still poisons its normal as the convolution's
+// zero tap does (every other neighbour has a non-zero weight in du or dv, and the cross product mixes both) -- and the
+// sums are fused multiply-adds: ~115 f64 instructions, within a few ulp of f64 of the old form.
 __device__ inline Grad3 point_gradients(const NormalsArgs &a, const float *z, int r, int c)
 {
     Grad3 g = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-    const double inv_fx = FAST ? fast_rcp64(a.fx) : 0.0, inv_fy = FAST ? fast_rcp64(a.fy) : 0.0;
+    int rr[3], cc[3];
+    double ax[3], ay[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        rr[j] = min(max(r + j - 1, 0), a.H - 1);
+        cc[j] = min(max(c + j - 1, 0), a.W - 1);
+        ax[j] = ((double)cc[j] - a.cx) * a.inv_fx;
+        ay[j] = ((double)rr[j] - a.cy) * a.inv_fy;
+    }
 #pragma unroll
     for (int dr = -1; dr <= 1; ++dr) {
 #pragma unroll
         for (int dc = -1; dc <= 1; ++dc) {
-            const int rr = min(max(r + dr, 0), a.H - 1), cc = min(max(c + dc, 0), a.W - 1);
-            const double d = (double)(z[(size_t)rr * a.W + cc] + a.z_offset);  // depth + 1610 in f32 (T8:353)
-            const double X = FAST ? ((double)cc - a.cx) * inv_fx * d : ((double)cc - a.cx) / a.fx * d;
-            const double Y = FAST ? ((double)rr - a.cy) * inv_fy * d : ((double)rr - a.cy) / a.fy * d;
+            const double d = (double)(z[(size_t)rr[dr + 1] * a.W + cc[dc + 1]] + a.z_offset);  // depth + 1610 in f32 (T8:353)
             const double ku = kSobelU[dr + 1][dc + 1], kv = kSobelV[dr + 1][dc + 1];
-            if (FAST) {  // fused multiply-adds: half the instructions, an ulp of f64 away from the forward's sums
+            if (ku == 0.0 && kv == 0.0) {  // the centre tap (compile-time after unrolling)
+                g.du[2] = __builtin_fma(0.0, d, g.du[2]);
+                continue;
+            }
+            const double X = ax[dc + 1] * d, Y = ay[dr + 1] * d;
+            if (ku != 0.0) {
                 g.du[0] = __builtin_fma(ku, X, g.du[0]);
                 g.du[1] = __builtin_fma(ku, Y, g.du[1]);
                 g.du[2] = __builtin_fma(ku, d, g.du[2]);
+            }
+            if (kv != 0.0) {
                 g.dv[0] = __builtin_fma(kv, X, g.dv[0]);
                 g.dv[1] = __builtin_fma(kv, Y, g.dv[1]);
                 g.dv[2] = __builtin_fma(kv, d, g.dv[2]);
-                continue;
             }
-            g.du[0] += ku * X;
-            g.du[1] += ku * Y;
-            g.du[2] += ku * d;
-            g.dv[0] += kv * X;
-            g.dv[1] += kv * Y;
-            g.dv[2] += kv * d;
         }
     }
     return g;
 }
 
-// Unit normal of pixel (r,c) as f32, y negated if requested (T8:353-354) -- shared by normals_fwd_kernel and
-// the march kernel's fused epilogue so that both produce the same bits.
-template <bool FAST = false>
+// Unit normal of pixel (r,c) as f32, y negated if requested (T8:353-354) -- shared by normals_fwd_kernel, the march
+// kernel's fused epilogue and the backward kernels' recomputation.  |n| by v_rsq_f64 + Newton and one reciprocal
+// instead of an IEEE sqrt and three IEEE divisions (~1 ulp of f64 each, then rounded to f32).
 __device__ inline void unit_normal(const NormalsArgs &a, const float *z, int r, int c, float (&n)[3])
 {
-    const Grad3 g = point_gradients<FAST>(a, z, r, c);
-    const double nx = g.du[1] * g.dv[2] - g.du[2] * g.dv[1];
-    const double ny = g.du[2] * g.dv[0] - g.du[0] * g.dv[2];
-    const double nz = g.du[0] * g.dv[1] - g.du[1] * g.dv[0];
-    const double n2sum = nx * nx + ny * ny + nz * nz;
-    double nn = FAST ? (n2sum > 1e-24 ? fast_sqrt64(n2sum) : 1e-12) : sqrt(n2sum);
+    const Grad3 g = point_gradients(a, z, r, c);
+    const double nx = __builtin_fma(g.du[1], g.dv[2], -(g.du[2] * g.dv[1]));
+    const double ny = __builtin_fma(g.du[2], g.dv[0], -(g.du[0] * g.dv[2]));
+    const double nz = __builtin_fma(g.du[0], g.dv[1], -(g.du[1] * g.dv[0]));
+    const double n2sum = __builtin_fma(nz, nz, __builtin_fma(ny, ny, nx * nx));
+    double nn = n2sum > 1e-24 ? fast_sqrt64(n2sum) : 1e-12;  // (NaN: 1e-12, and the products below stay NaN)
     nn = nn > 1e-12 ? nn : 1e-12;
-    if (FAST) {
-        const double inv = fast_rcp64(nn);
-        n[0] = (float)(nx * inv);
-        n[1] = (float)(a.negate_y ? -(ny * inv) : (ny * inv));
-        n[2] = (float)(nz * inv);
-    } else {
-        n[0] = (float)(nx / nn);
-        n[1] = (float)(a.negate_y ? -(ny / nn) : (ny / nn));  // T8:354
-        n[2] = (float)(nz / nn);
-    }
+    const double inv = fast_rcp64(nn);
+    n[0] = (float)(nx * inv);
+    n[1] = (float)(a.negate_y ? -(ny * inv) : (ny * inv));  // T8:354
+    n[2] = (float)(nz * inv);
 }
 
 // Backward of unit_normal() for one pixel, first half: (g0,g1,g2) = dLoss/d(unit normal output, y already negated)
@@ -249,7 +262,7 @@ __device__ inline StencilGrad normals_bwd_terms(const NormalsArgs &a, const floa
                                                 double g1_in, double g2)
 {
 #pragma clang fp contract(fast)  // backward-only arithmetic: fused multiply-adds allowed (the TU default is off)
-    const Grad3 g = point_gradients<true>(a, z, r, c);
+    const Grad3 g = point_gradients(a, z, r, c);
     const double cx_ = g.du[1] * g.dv[2] - g.du[2] * g.dv[1];
     const double cy_ = g.du[2] * g.dv[0] - g.du[0] * g.dv[2];
     const double cz_ = g.du[0] * g.dv[1] - g.du[1] * g.dv[0];
@@ -290,7 +303,7 @@ template <class Pred>
 __device__ inline void normals_bwd_scatter(const NormalsArgs &a, const StencilGrad &sg, float *gz, int r, int c, Pred want)
 {
 #pragma clang fp contract(fast)
-    const double inv_fx = fast_rcp64(a.fx), inv_fy = fast_rcp64(a.fy);
+    const double inv_fx = a.inv_fx, inv_fy = a.inv_fy;
 #pragma unroll
     for (int dr = -1; dr <= 1; ++dr) {
 #pragma unroll

@@ -58,7 +58,8 @@ static int normals_launch(bool backward, const float *depth, const float *grad_n
         return GCFR_ERR_INVALID_ARGUMENT;
     if (backward ? (!grad_normals || !grad_depth) : !normals)
         return GCFR_ERR_INVALID_ARGUMENT;
-    NormalsArgs a{depth, normals, grad_normals, grad_depth, H, W, fx, fy, cx, cy, z_offset, negate_y};
+    NormalsArgs a{depth, normals, grad_normals, grad_depth, H, W, fx, fy, cx, cy, z_offset, negate_y, 0.0, 0.0};
+    set_focal(a, fx, fy);
     const size_t P = (size_t)H * W;
     const dim3 grid((unsigned)((P + 255) / 256), (unsigned)B);
     if (backward)

@@ -718,7 +718,7 @@ __device__ inline int lo32(double v)
 // Work counters of the counting build (-DGCFR_COUNTERS; tools/count_work.py): wave-uniform tallies, added to
 // gcfr_options.counters once per tile.  Compiled out of the product build.
 enum { kCntTiles, kCntGroupsNominal, kCntGroupsVisited, kCntBoundTests, kCntBodies, kCntLaneSamples, kCntEarlyExit,
-       kCntTieRemarch, kCntSamplesInRange, kCntBoundsGivenUp, kCntUsed };
+       kCntTieRemarch, kCntSamplesInRange, kCntBoundsGivenUp, kCntSteals, kCntStolenGroups, kCntUsed };
 #ifdef GCFR_COUNTERS
 #define GCFR_COUNT(i, n) (cnt[i] += (unsigned)(n))
 #else
@@ -734,6 +734,39 @@ struct ImageStats {
 __device__ inline ImageStats reduce_image_stats(ArgPtr a, int b, int lane, bool want_z)
 {
     const int n = n_stat_chunks(a->H, a->W);
+    if (n <= 8) {
+        // Up to 512 x 256 pixels: the handful of chunk records is folded on the SCALAR unit (constant-address-space loads of
+        // uniform addresses are s_loads, the minima s_min_i32) -- the vector form below costs every tile ~100 VALU
+        // instructions (seven 64-lane DPP reductions), 4 % of the march's instruction count at B=8 x 256^2.
+        typedef const __attribute__((address_space(4))) int *ConstI32Ptr;
+        const ConstI32Ptr sb = (ConstI32Ptr)(unsigned long long)a->bbox + 4 * (size_t)(a->mask_batch == 1 ? 0 : b) * n;
+        const ConstI32Ptr sz = (ConstI32Ptr)(unsigned long long)a->zrange + 2 * (size_t)b * n;
+        const ConstI32Ptr so = (ConstI32Ptr)(unsigned long long)a->mones + (size_t)(a->mask_batch == 1 ? 0 : b) * n;
+        int m0 = kBBoxInit, m1 = kBBoxInit, m2 = kBBoxInit, m3 = kBBoxInit, z0 = 0x7fffffff, z1 = 0x7fffffff, ones = 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < n) {
+                m0 = min(m0, sb[4 * j + 0]);
+                m1 = min(m1, sb[4 * j + 1]);
+                m2 = min(m2, sb[4 * j + 2]);
+                m3 = min(m3, sb[4 * j + 3]);
+                ones = min(ones, so[j]);
+                if (want_z) {
+                    z0 = min(z0, sz[2 * j + 0]);
+                    z1 = min(z1, sz[2 * j + 1]);
+                }
+            }
+        }
+        ImageStats st;
+        st.r_min = m0;
+        st.c_min = m1;
+        st.r_max = -m2;
+        st.c_max = -m3;
+        st.gz_lo_s = z0;
+        st.gz_nhi_s = z1;
+        st.mask_all_ones = ones;
+        return st;
+    }
     const int4 *pb = (const int4 *)a->bbox + (size_t)(a->mask_batch == 1 ? 0 : b) * n;
     const int2 *pz = (const int2 *)a->zrange + (size_t)b * n;
     const int *po = a->mones + (size_t)(a->mask_batch == 1 ? 0 : b) * n;
@@ -788,11 +821,61 @@ __device__ inline int fresh_lane_id()
     return l;
 }
 
+// SPLIT = 3, work stealing inside the workgroup (shadow_fwd_quad_steal_kernel).  The workgroup's four tiles are four
+// queues of sample groups in LDS.  A wave first marches its OWN tile, claiming kStealChunk groups at a time (a fetch-add;
+// consecutive claims continue the prefetch pipeline, so an unshared tile marches exactly as in the grid schedule);
+// when its tile is exhausted it looks at the other three, and if one still has at least kMinSteal unclaimed groups it
+// repeats that tile's prologue (the per-pixel ray set-up, ~400 VALU) and joins in, claiming from the same front --
+// from the back it would march what the owner's early termination is about to declare dead.
+// Every worker of a tile publishes its running minimum in LDS (ds_min_u32 on the bits of a non-negative float) and
+// bounds its depth-bound skip and its termination test by the smallest value anyone has published -- any distance
+// already found for a pixel bounds its final minimum, so a group skipped against it could not have won: the minimum
+// is the one the sequential march finds.  Every group is claimed exactly once (a worker whose termination test fires
+// claims the whole unclaimed rest as dead with a fetch-max); a worker leaving a tile adds the groups it claimed to the
+// tile's `done` count, and the one that completes the count runs the tile's epilogue on the merged minimum.  Inference variant only (no argmin: a
+// minimum needs no order, the first index of the minimal distance does).
+#ifndef GCFR_STEAL_TILES
+#define GCFR_STEAL_TILES 16
+#endif
+constexpr int kStealTiles = GCFR_STEAL_TILES;  // tiles = waves per workgroup
+struct StealShared {
+    int next[kStealTiles];               // first unclaimed group of the tile (claims are fetch-adds; may run past total)
+    int done[kStealTiles], total[kStealTiles];  // groups accounted for / groups of the tile's pruned sample range
+    unsigned min_bits[kStealTiles][64];  // running minimum of S per pixel (f32 bits; S >= 0 or +inf, never NaN)
+    unsigned anym[kStealTiles][64];      // some sample of the pixel was masked
+};
+#ifndef GCFR_STEAL_CHUNK
+#define GCFR_STEAL_CHUNK 4
+#endif
+#ifndef GCFR_MIN_STEAL
+#define GCFR_MIN_STEAL 8
+#endif
+[[maybe_unused]] constexpr int kStealChunk = GCFR_STEAL_CHUNK, kMinSteal = GCFR_MIN_STEAL;  // groups per claim (even), groups left that justify a second prologue
+static_assert(kStealChunk % 2 == 0, "claims must keep the two-buffer pipeline's parity");
+__device__ __forceinline__ StealShared &steal_shared()
+{
+    __shared__ StealShared s;
+    return s;
+}
+
 template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, int SPLIT, bool ALL_ONES = false>
 __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy, const int tx,
-                                           const ImageStats &st)
+                                           const ImageStats &st, const int ti = 0, const bool owner = true,
+                                           const bool tile_ok = true)
 {
     constexpr int TILE_H = 64 / TILE_W;
+    constexpr bool STEAL = SPLIT == 3;
+    static_assert(!(STEAL && WANT_ARGMIN), "work stealing merges minima, not first indices");
+    if (STEAL && owner && !tile_ok) {  // a wave without a tile of its own: empty queue, then it may steal
+        StealShared &ss0 = steal_shared();
+        if ((threadIdx.x & 63) == 0) {
+            ss0.next[ti] = 0;
+            ss0.total[ti] = 0;
+            ss0.done[ti] = 0;
+        }
+        __syncthreads();
+        return;
+    }
     const int H = a->H, W = a->W, L = a->L;
     // Wave-uniform read-only inputs are read through the CONSTANT address space: in the persistent schedule the
     // previous tile's stores and the queue atomic precede these loads in program order, so through a plain global
@@ -1098,6 +1181,8 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     // the bound the skip / termination tests compare against: the lane's own running minimum, or (COOP) the
     // smallest one any of the four waves has published for this pixel -- stale values are larger, hence safe
     auto bound_min = [&]() -> float {
+        if (STEAL)
+            return fminf(bestS, __builtin_bit_cast(float, *(volatile unsigned *)&steal_shared().min_bits[ti][lane]));
         if (!COOP)
             return bestS;
         const float m01 = fminf(run_min[lane], run_min[64 + lane]), m23 = fminf(run_min[128 + lane], run_min[192 + lane]);
@@ -1197,6 +1282,8 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
           }
           if (COOP)
               run_min[wave * 64 + lane] = bestS;  // publish (racy by design: any value ever written is a valid bound)
+          if (STEAL)
+              atomicMin(&steal_shared().min_bits[ti][lane], __builtin_bit_cast(unsigned, bestS));
         }
         if (check_finished && use_zb && k0 + DEPTH < k_end) {  // early termination, see Dcap
             const float tn = (float)tt[k0 + DEPTH];
@@ -1215,6 +1302,80 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 
     Prefetched bufA, bufB;
     bufA.z = bufB.z = f32x4{0.0f, 0.0f, -__builtin_inff(), __builtin_inff()};
+    if (STEAL) {
+        StealShared &ss = steal_shared();
+        const int g_total = k_end > k_begin ? (k_end - k_begin + DEPTH - 1) / DEPTH : 0;
+        if (owner) {
+            if (lane == 0) {
+                ss.next[ti] = 0;
+                ss.total[ti] = g_total;
+                ss.done[ti] = 0;
+            }
+            ss.min_bits[ti][lane] = 0x7f800000u;
+            ss.anym[ti][lane] = 0u;
+            __syncthreads();  // (the only barrier: every wave of the workgroup passes here once, as owner)
+        }
+        // claim the next kStealChunk groups of the tile, [c_lo, c_hi)
+        auto claim = [&](int &c_lo, int &c_hi) -> bool {
+            int c = 0;
+            if (lane == 0)
+                c = atomicAdd(&ss.next[ti], kStealChunk);
+            c = __builtin_amdgcn_readfirstlane(c);
+            if (c >= g_total)
+                return false;
+            c_lo = c;
+            c_hi = min(c + kStealChunk, g_total);
+            return true;
+        };
+        int mine = 0;
+        if (!owner)
+            GCFR_COUNT(kCntSteals, 1);
+        int k0 = k_begin, k_stop = k_begin;
+        bool primed = false;
+        for (;;) {
+            if (k0 >= k_stop) {  // (chunks are an even number of groups: only ever true at the top of a pair)
+                int c_lo, c_hi;
+                if (!claim(c_lo, c_hi))
+                    break;
+                mine += c_hi - c_lo;
+                if (!owner)
+                    GCFR_COUNT(kCntStolenGroups, c_hi - c_lo);
+                const int k_new = k_begin + c_lo * DEPTH;
+                if (!primed || k_new != k0) {  // not the continuation of the previous chunk: restart the pipeline
+                    k0 = k_new;
+                    prefetch(k0, bufA);
+                    primed = true;
+                }
+                k_stop = min(k_begin + c_hi * DEPTH, k_end);
+            }
+            bool fin = !group(k0, bufA, bufB, false);
+            if (!fin && k0 + DEPTH < k_stop)
+                fin = !group(k0 + DEPTH, bufB, bufA, true);
+            if (fin) {
+                // no later sample can be taken (whoever finds that out): everything still unclaimed is dead
+                int old = g_total;
+                if (lane == 0)
+                    old = atomicMax(&ss.next[ti], g_total);
+                old = __builtin_amdgcn_readfirstlane(old);
+                mine += max(0, g_total - old);
+                break;
+            }
+            k0 += 2 * DEPTH;
+        }
+        // leave the tile: merge, account, and the worker that completes the count finishes the tile
+        atomicMin(&ss.min_bits[ti][lane], __builtin_bit_cast(unsigned, bestS));
+        if (any_masked)
+            ss.anym[ti][lane] = 1u;
+        int prev = 0;
+        if (lane == 0)
+            prev = __hip_atomic_fetch_add(&ss.done[ti], mine, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        prev = __builtin_amdgcn_readfirstlane(prev);
+        const bool last = (owner || mine > 0) && (prev + mine == g_total);
+        if (!last)
+            return;
+        bestS = __builtin_bit_cast(float, *(volatile unsigned *)&ss.min_bits[ti][lane]);
+        any_masked = any_masked || (*(volatile unsigned *)&ss.anym[ti][lane] != 0u);
+    } else {
     const int k_first = k_begin + (COOP ? wave * DEPTH : 0);
     if (k_first < k_end)
         prefetch(k_first, bufA);
@@ -1225,6 +1386,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
             break;
         if (!group(k0 + GSTRIDE, bufB, bufA, true))  // the termination test runs every other group (it costs ~18 VALU)
             break;
+    }
     }
 
     bool coop_tie = false;  // COOP + argmin: some wave holds an earlier sample that may round to the same distance
@@ -1367,8 +1529,8 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
                 NormalsArgs na = {};  // (field by field: the source lives in the constant address space)
                 na.H = H;
                 na.W = W;
-                na.fx = ep->nrm.fx;
-                na.fy = ep->nrm.fy;
+                na.inv_fx = ep->nrm.inv_fx;
+                na.inv_fy = ep->nrm.inv_fy;
                 na.cx = ep->nrm.cx;
                 na.cy = ep->nrm.cy;
                 na.z_offset = ep->nrm.z_offset;
@@ -1428,6 +1590,9 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 #endif
 #ifndef GCFR_MARCH_ARGMIN_WAVES_PER_EU
 #define GCFR_MARCH_ARGMIN_WAVES_PER_EU 5
+#endif
+#ifndef GCFR_STEAL_WAVES_PER_EU
+#define GCFR_STEAL_WAVES_PER_EU 4
 #endif
 
 // Grid schedule: one workgroup = four horizontally adjacent tiles (one per wave), 3-D grid x = tile-quad column,
@@ -1626,6 +1791,45 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_ksplit_kernel(ShadowQuadA
 }
 
 #ifdef GCFR_EXPERIMENTAL_SCHEDULES
+// work stealing inside the workgroup (SPLIT = 3, see StealShared): one workgroup = kStealTiles waves = kStealTiles
+// tiles; 1-D grid of G * BL workgroups, G = ceil(tiles per image / kStealTiles), BL = (image, light) pairs.
+// Workgroup id = j * BL + r; its wave w owns tile u = w * G + j (row-major tile list, each tile row rotated by five
+// columns per row) of pair (r + w) mod BL: the workgroup's tiles are spread evenly over the height and the width of the
+// image AND over the batch, so every workgroup carries the same mix of heavy (face, grazing light) and light (border,
+// overhead light) tiles -- its duration is the mix's mean, not its heaviest member.  After its own tile a wave keeps
+// joining the tile with the most unclaimed groups until none has kMinSteal left.
+template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
+__global__ __launch_bounds__(64 * kStealTiles)
+__attribute__((amdgpu_waves_per_eu(GCFR_STEAL_WAVES_PER_EU, GCFR_STEAL_WAVES_PER_EU))) void shadow_fwd_quad_steal_kernel(ShadowQuadArgs)
+{
+    const ArgPtr a = kernel_args();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int tiles_x = a->tiles_x, n_tiles = tiles_x * a->tiles_y, BL = a->B * a->L;
+    const int G = (n_tiles + kStealTiles - 1) / kStealTiles;
+    const int j = (int)blockIdx.x / BL, r = (int)blockIdx.x - j * BL;
+    StealShared &ss = steal_shared();
+    int ti = wave;
+    for (bool own = true;; own = false) {
+        if (!own) {  // the tile with the most unclaimed groups, if that justifies a second prologue
+            const int left = lane < kStealTiles ? *(volatile int *)&ss.total[lane] - *(volatile int *)&ss.next[lane] : 0;
+            const int most = -wave_min_i32(-left);
+            if (most < kMinSteal)
+                break;
+            ti = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(left == most)));
+        }
+        const int bl = (r + ti) % BL;
+        const int u = ti * G + j;
+        const int ty = u / tiles_x;
+        const int tx = (u - ty * tiles_x + 5 * ty) % tiles_x;
+        const ImageStats st = reduce_image_stats(a, bl / a->L, lane, a->zb != nullptr);
+        if (st.mask_all_ones != 0)  // (wave-uniform; the workgroup's one barrier is reached from either variant)
+            march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, 3, true>(a, bl, ty, tx, st, ti, own, u < n_tiles);
+        else
+            march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, 3, false>(a, bl, ty, tx, st, ti, own, u < n_tiles);
+    }
+}
+
 // cooperative march (SPLIT = 2): one workgroup per tile, throughput variant -- one sample at a time, forced occupancy;
 // grid x = tile column, y = tile row, z = (image, light)
 template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
@@ -1718,7 +1922,7 @@ static int resolve_options(const gcfr_options *opt, Knobs &k)
     const int tw = opt->tile_w, g = opt->group;
     if ((tw != 0 && tw != 8 && tw != 16 && tw != 32 && tw != 64) || (g != 0 && g != 1 && g != 2 && g != 4) ||
         opt->ksplit < -1 || opt->ksplit > 1 || opt->depth_bound_skip < -1 || opt->depth_bound_skip > 1 ||
-        opt->schedule < -1 || opt->schedule > 4 || opt->tile_order < -1 || opt->tile_order > 4)
+        opt->schedule < -1 || opt->schedule > 5 || opt->tile_order < -1 || opt->tile_order > 4)
         return GCFR_ERR_INVALID_ARGUMENT;
 #ifndef GCFR_EXPERIMENTAL_SCHEDULES
     if (opt->schedule > 0)
@@ -1772,7 +1976,7 @@ static int device_cu_count()
     return n;
 }
 
-enum Schedule { kGrid = kSchedGrid, kQueue = kSchedQueue, kStrided = kSchedStrided, kGridOrdered = kSchedGridOrdered, kCoop = 4, kKSplit };
+enum Schedule { kGrid = kSchedGrid, kQueue = kSchedQueue, kStrided = kSchedStrided, kGridOrdered = kSchedGridOrdered, kCoop = 4, kSteal = 5, kKSplit };
 
 template <int TILE_W, int DEPTH, bool FUSE>
 static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argmin, Schedule sch, dim3 grid,
@@ -1806,6 +2010,13 @@ static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argm
                 GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, false, false, DEPTH, FUSE);
         }
 #ifdef GCFR_EXPERIMENTAL_SCHEDULES
+    } else if (sch == kSteal) {
+        if constexpr (TILE_W == 16 && DEPTH == 4) {  // (the one shape the stealing kernel is built for)
+            if (even_half)
+                hipLaunchKernelGGL((shadow_fwd_quad_steal_kernel<TILE_W, true, DEPTH, FUSE>), grid, dim3(64 * kStealTiles), 0, st, a);
+            else
+                hipLaunchKernelGGL((shadow_fwd_quad_steal_kernel<TILE_W, false, DEPTH, FUSE>), grid, dim3(64 * kStealTiles), 0, st, a);
+        }
     } else if (sch == kCoop) {
         if (even_half) {
             if (want_argmin)
@@ -1869,7 +2080,12 @@ static void launch_quad(ShadowQuadArgs a, bool even_half, bool want_argmin, int 
         const unsigned gx = (sch == kKSplit || sch == kCoop) ? (unsigned)a.tiles_x : (unsigned)((a.tiles_x + 3) / 4);
         for (int z0 = 0; z0 < total_bl; z0 += 65535) {  // grid z is limited to 65535 (image, light) pairs per launch
             a.bl_offset = z0;
-            one(dim3(gx, (unsigned)a.tiles_y, (unsigned)((total_bl - z0) < 65535 ? (total_bl - z0) : 65535)));
+            const unsigned gz = (unsigned)((total_bl - z0) < 65535 ? (total_bl - z0) : 65535);
+            if (sch == kSteal) {  // 1-D grid over all (image, light) pairs at once
+                one(dim3((unsigned)(((a.tiles_x * a.tiles_y + kStealTiles - 1) / kStealTiles) * total_bl)));
+                break;
+            }
+            one(dim3(gx, (unsigned)a.tiles_y, gz));
         }
     }
     if (kn.ev_stop)
@@ -1965,7 +2181,9 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         // waves of its workgroup (finer, more uniform pieces; a quarter-range wave starts the depth-bound skip
         // without a running minimum, so it loses from B = 4 up).  Otherwise the persistent tile queue.
         const bool ksplit = (kn.ksplit < 0) ? (tiles_total <= 2048 && N >= 16) : (kn.ksplit == 1);
-        const Schedule sch = ksplit ? kKSplit : (Schedule)(kn.schedule < 0 ? kSchedGrid : kn.schedule);
+        Schedule sch = ksplit ? kKSplit : (Schedule)(kn.schedule < 0 ? kSchedGrid : kn.schedule);
+        if (sch == kSteal && (argmin != nullptr || TILE_W != 16 || kn.group != 4))
+            sch = kGrid;  // (work stealing: inference variant, 16x4 tiles, groups of four)
         a.tile_order = kn.tile_order < 0 ? 0 : kn.tile_order;
         a.epi.min_dist = min_dist;
         a.epi.argmin = argmin;
@@ -2105,8 +2323,7 @@ extern "C" int gcfr_render_from_depth_fwd(const float *light_raw, int32_t clamp_
     fs.lights.clamp_min = clamp_min;
     fs.lights.light_distance = light_distance;
     fs.normals = nullptr;  // computed in the epilogue
-    fs.nrm.fx = fx;
-    fs.nrm.fy = fy;
+    set_focal(fs.nrm, fx, fy);
     fs.nrm.cx = cx;
     fs.nrm.cy = cy;
     fs.nrm.z_offset = z_offset;

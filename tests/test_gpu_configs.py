@@ -171,6 +171,11 @@ def test_soak_slice_is_bit_exact():
         assert r["pixels_compared"] > (2_000_000 if opt is None else 300_000)
         assert r["lit_mask_mismatches"] == 0 and r["argmin_differences"] == 0, r
         assert r["max_abs_err_min_dist"] == 0.0, r
+    # the inference kernels (no argmin): the grid and the work-stealing schedule
+    for opt in (_lib.options(schedule=0),) + ((_lib.options(schedule=5), _lib.options(schedule=5, depth_bound_skip=0)) if _experimental() else ()):
+        r = soak_parity.run_soak(120, seed=77, options=opt, want_argmin=False)
+        assert r["pixels_compared"] > 1_000_000
+        assert r["lit_mask_mismatches"] == 0 and r["max_abs_err_min_dist"] == 0.0, r
 
 
 def _adversarial_surfaces(Hs, Ws, rng):

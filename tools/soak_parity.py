@@ -55,7 +55,7 @@ def random_case(rng, H, W):
     return depth, mask.astype(np.uint8), l.astype(np.float32)
 
 
-def run_soak(n_cases, seed=0, options=None, sizes=None):
+def run_soak(n_cases, seed=0, options=None, sizes=None, want_argmin=True):
     """`n_cases` random (depth, mask, light) cases in batches of 8: HIP workspace kernel vs the C oracle.
     Returns the tallies (pixels compared, lit/masked disagreements, worst min-distance error, argmin differences)."""
     rng = np.random.default_rng(seed)
@@ -79,10 +79,10 @@ def run_soak(n_cases, seed=0, options=None, sizes=None):
         prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N, light_distance=ld)
         _, pt = light_prep(torch.from_numpy(lights).to(dev), prm)
         md, am = shadow_min_distance(torch.from_numpy(depth).to(dev), torch.from_numpy(mask).to(dev),
-                                     pt.reshape(B, 1, 3), prm, options=options)
+                                     pt.reshape(B, 1, 3), prm, options=options, want_argmin=want_argmin)
         _, pt_o = c_oracle.light_prep(lights, clamp_z_min=0.0, light_distance=ld)
         md_o, am_o = c_oracle.shadow_min_distance(depth, mask, pt_o[:, None, :], c_oracle.sample_table(0.025, 0.8 / N, N))
-        md, am = md.cpu().numpy(), am.cpu().numpy()
+        md, am = md.cpu().numpy(), (am.cpu().numpy() if am is not None else am_o)   # (kernels without argmin: distances only)
         lit_o, lit = md_o < 1e5, md < 1e5
         n_lit_mismatch += int((lit_o != lit).sum())
         both = lit & lit_o
