@@ -1140,7 +1140,22 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     // needs no mask gathers at all -- the prefetch then only locates the group's first and last cell for the bounds
     // record.  A compile-time variant of the whole tile function, chosen per tile by the caller: as a run-time
     // branch inside the prefetch it cost the common case 6 % (the sample loop's schedule falls apart around it).
-    auto prefetch = [&](int kfirst, Prefetched &p) {
+    // The sample-table values of the group the next prefetch addresses are read one group EARLIER still, into SGPRs
+    // (tq): an s_load issued right before its use stalls the wave for a scalar-cache round trip, twice per group as the
+    // compiler scheduled it, and a wave that skips a group in ~250 cycles has nothing to hide that behind.
+    double tq[DEPTH];
+    double tc0 = 0.0, tc3 = 0.0;  // first / last table value of the group the next group() call consumes (SGPRs
+                                  // are at 101 of ~106: carrying all four, so that the bodies need no s_load, spills)
+    auto load_tq = [&](int kfirst) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j)
+            tq[j] = tt[clampk(kfirst + j)];
+    };
+    auto pos_tq = [&](int j, double &sx, double &sy) {
+        sx = x64 + tq[j] * dx64;  // T8:472 / 480 (f64, mul and add rounded separately)
+        sy = y64 + tq[j] * dy64;
+    };
+    auto prefetch = [&](Prefetched &p) {  // (the group whose table values tq holds)
         int cj[DEPTH], rj[DEPTH];
         if (ALL_ONES) {
 #pragma unroll
@@ -1148,9 +1163,9 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
                 p.m[j] = 1u;
             if (use_zb) {
                 double px, py;
-                sample_pos(clampk(kfirst), px, py);
+                pos_tq(0, px, py);
                 (void)mask_offset(px, py, cj[0], rj[0]);
-                sample_pos(clampk(kfirst + DEPTH - 1), px, py);
+                pos_tq(DEPTH - 1, px, py);
                 (void)mask_offset(px, py, cj[DEPTH - 1], rj[DEPTH - 1]);
                 p.z = zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1]);
             }
@@ -1159,7 +1174,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
             double px, py;
-            sample_pos(clampk(kfirst + j), px, py);
+            pos_tq(j, px, py);
             p.m[j] = buf_load_u8(mr, mask_offset(px, py, cj[j], rj[j]));
         }
         if (use_zb)
@@ -1189,7 +1204,11 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         return fminf(bestS, fminf(m01, m23));
     };
     auto group = [&](int k0, const Prefetched &cur, Prefetched &nxt, bool check_finished) -> bool {
-        prefetch(k0 + GSTRIDE, nxt);
+        const double ta64 = tc0, tb64 = tc3;  // first / last table value of THIS group (tq of the previous call)
+        tc0 = tq[0];
+        tc3 = tq[DEPTH - 1];
+        prefetch(nxt);                 // group k0 + GSTRIDE
+        load_tq(k0 + 2 * GSTRIDE);     // ... and the table values of the one after it
         GCFR_COUNT(kCntGroupsVisited, 1);
         bool none = true;
 #pragma unroll
@@ -1200,7 +1219,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         bool run_body = __builtin_amdgcn_ballot_w64(!none) != 0ull;
         if (run_body && use_zb) {
             GCFR_COUNT(kCntBoundTests, 1);
-            const float ta = (float)tt[k0], tb = (float)tt[clampk(k0 + DEPTH - 1)];
+            const float ta = (float)ta64, tb = (float)tb64;  // tt[k0], tt[clampk(k0 + DEPTH - 1)]
             const float Ta = c1 * ta, Tb = c1 * tb;
             const float Tlo = fminf(Ta, Tb), Thi = fmaxf(Ta, Tb);
             // surface band at the sample position s(t) = (x, y) + t d:  z in A0 + t A1 + [c_lo, c_hi], so
@@ -1286,7 +1305,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
               atomicMin(&steal_shared().min_bits[ti][lane], __builtin_bit_cast(unsigned, bestS));
         }
         if (check_finished && use_zb && k0 + DEPTH < k_end) {  // early termination, see Dcap
-            const float tn = (float)tt[k0 + DEPTH];
+            const float tn = (float)(COOP ? tt[k0 + DEPTH] : tc0);  // tt[k0 + DEPTH]: the next group's first value
             const float gd = __builtin_fmaf(c1, tn, -Dcap);
             const float bS = bound_min();
             const bool finished = ((gd > 0.0f) && (gd * gd * 0.998f > bS) && (bS < safeS)) ||
@@ -1343,7 +1362,11 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
                 const int k_new = k_begin + c_lo * DEPTH;
                 if (!primed || k_new != k0) {  // not the continuation of the previous chunk: restart the pipeline
                     k0 = k_new;
-                    prefetch(k0, bufA);
+                    load_tq(k0);
+                    tc0 = tq[0];
+                    tc3 = tq[DEPTH - 1];
+                    prefetch(bufA);
+                    load_tq(k0 + DEPTH);
                     primed = true;
                 }
                 k_stop = min(k_begin + c_hi * DEPTH, k_end);
@@ -1377,8 +1400,13 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         any_masked = any_masked || (*(volatile unsigned *)&ss.anym[ti][lane] != 0u);
     } else {
     const int k_first = k_begin + (COOP ? wave * DEPTH : 0);
-    if (k_first < k_end)
-        prefetch(k_first, bufA);
+    if (k_first < k_end) {
+        load_tq(k_first);
+        tc0 = tq[0];
+        tc3 = tq[DEPTH - 1];
+        prefetch(bufA);
+        load_tq(k_first + GSTRIDE);
+    }
     for (int k0 = k_first; k0 < k_end; k0 += 2 * GSTRIDE) {
         if (!group(k0, bufA, bufB, false))
             break;
