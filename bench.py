@@ -446,6 +446,10 @@ def run_render(a, rank, world, dev, dist):
         "ray_steps_per_sec_per_gpu": value / world,
         "single_stream": single,
         "latency_one_batch_ms": single["ms_per_step"],
+        # `value` is a throughput with `hip_streams` batches in flight (faces_in_flight below), not the rate of one batch
+        # of `faces_per_gpu` on its own -- that one is `single_stream` (VERDICT r01 asked for both to be named)
+        "faces_in_flight_per_gpu": B * n_streams,
+        "throughput_in_flight": {"faces_in_flight_per_gpu": B * n_streams, "ray_steps_per_sec": value},
         "roofline": roof,
     }
     if graph_error:
