@@ -103,10 +103,13 @@ def main():
     ap.add_argument("--cases", type=int, default=240)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--tune", type=str, default="", help="comma list of gcfr_options knobs, e.g. schedule=0,tile_w=16")
+    ap.add_argument("--no-argmin", action="store_true", help="the inference kernels (six waves / SIMD, no argmin output)")
     a = ap.parse_args()
     from geomconsistentfr_amd import _lib
     knobs = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)}
-    print(json.dumps(run_soak(a.cases, a.seed, _lib.options(**knobs) if knobs else None)))
+    r = run_soak(a.cases, a.seed, _lib.options(**knobs) if knobs else None, want_argmin=not a.no_argmin)
+    r.update(library=_lib.load().gcfr_version().decode(), knobs=knobs, argmin_kernel=not a.no_argmin)
+    print(json.dumps(r))
 
 
 if __name__ == "__main__":
