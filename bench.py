@@ -56,7 +56,7 @@ LIGHTS18 = np.array([[.7518, 0, .6594], [.6893, .3991, .6047], [.5145, 0, .8575]
                      [0, .2, .98]], np.float32)                                                # 7 synthetic
 
 
-def synth_faces_sized(B, seed0, size, n_lights, mask_kind="ellipse"):
+def synth_faces_sized(B, seed0, size, n_lights, mask_kind="ellipse", light_seed0=None):
     """Config-5 style inputs: `size` x `size` faces (surface scaled), `n_lights` lights per face."""
     r, c = np.mgrid[0:size, 0:size]
     s = size / 256.0
@@ -74,13 +74,15 @@ def synth_faces_sized(B, seed0, size, n_lights, mask_kind="ellipse"):
         gy, gx = np.gradient(d)
         n = np.stack([-gx, gy, np.ones_like(d)])
         normals.append((n / np.linalg.norm(n, axis=0)).astype(np.float32))
-    light = np.stack([np.roll(LIGHTS18, seed0 + i, axis=0)[:n_lights] for i in range(B)])
+    ls0 = seed0 if light_seed0 is None else light_seed0
+    light = np.stack([np.roll(LIGHTS18, ls0 + i, axis=0)[:n_lights] for i in range(B)])
     amb = np.full((B, n_lights), 0.5, np.float32)
     return np.stack(depth), np.stack(mask), np.stack(albedo), np.stack(normals), light, amb
 
 
-def synth_faces(B, seed0):
-    """Deterministic synthetic faces: jittered ellipsoid + nose + ripple."""
+def synth_faces(B, seed0, light_seed0=None):
+    """Deterministic synthetic faces: jittered ellipsoid + nose + ripple.
+    Face i takes light (light_seed0 + i) mod 11 of the reference's eleven shipped directions (light_seed0 = seed0 unless given)."""
     r, c = np.mgrid[0:H, 0:W]
     x, y = c - 128.0, r - 128.0
     lights11 = np.array([[.7518, 0, .6594], [.6893, .3991, .6047], [.5145, 0, .8575], [-.5843, 0, .8115],
@@ -98,7 +100,7 @@ def synth_faces(B, seed0):
         gy, gx = np.gradient(d)
         n = np.stack([-gx, gy, np.ones_like(d)])
         normals.append((n / np.linalg.norm(n, axis=0)).astype(np.float32))
-        light.append(lights11[(seed0 + i) % 11])
+        light.append(lights11[((seed0 if light_seed0 is None else light_seed0) + i) % 11])
         amb.append(np.float32(0.5))
     return (np.stack(depth), np.stack(mask), np.stack(albedo), np.stack(normals), np.stack(light),
             np.asarray(amb, np.float32))
@@ -302,36 +304,53 @@ def run_render(a, rank, world, dev, dist):
     B = a.faces
     headline = (a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse" and a.depth_noise == 0.0
                 and B == FACES_PER_GPU and not knobs and not (a.direct or a.unfused or a.from_depth))
-    if a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse":
-        prm = RenderParams()
-        depth, mask, albedo, normals, light, amb = synth_faces(B, seed0=rank * 1_000_000)
-    else:
-        prm = RenderParams(n_samples=a.samples, dt=0.8 / a.samples)
-        depth, mask, albedo, normals, light, amb = synth_faces_sized(B, rank * 1_000_000, a.size, a.lights, a.mask)
-    if a.depth_noise > 0.0:
-        depth = depth + (a.depth_noise * np.random.default_rng(7).random(depth.shape)).astype(np.float32)
+    n_streams = max(1, a.streams)
     Hh = Ww = a.size
     Ll, Nn = a.lights, a.samples
-    d_depth, d_mask, d_albedo, d_normals, d_light, d_amb = [torch.from_numpy(x).to(dev) for x in
-                                                            (depth, mask, albedo, normals, light, amb)]
+    default_shape = a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse"
+    prm = RenderParams() if default_shape else RenderParams(n_samples=a.samples, dt=0.8 / a.samples)
+
+    def device_batch(j):
+        """the j-th batch of B synthetic faces of this rank.  Every stream renders its OWN faces (geometry, mask, albedo:
+        batches in flight are different data, as in serving) under the SAME light assignment as batch 0 (face i takes
+        light i of the list), so that every batch is the workload BASELINE.md section 4 defines and not a harder or
+        easier mix of grazing and overhead lights."""
+        seed0 = rank * 1_000_000 + j * B
+        if default_shape:
+            depth, mask, albedo, normals, light, amb = synth_faces(B, seed0=seed0, light_seed0=rank * 1_000_000)
+        else:
+            depth, mask, albedo, normals, light, amb = synth_faces_sized(B, seed0, a.size, a.lights, a.mask,
+                                                                         light_seed0=rank * 1_000_000)
+        if a.depth_noise > 0.0:
+            depth = depth + (a.depth_noise * np.random.default_rng(7 + j).random(depth.shape)).astype(np.float32)
+        t = [torch.from_numpy(x).to(dev) for x in (depth, mask, albedo, normals, light, amb)]
+        t[1] = R.mask_to_u8(t[1]).reshape(-1, Hh, Ww).contiguous()
+        return t
+
+    batches = [device_batch(j) for j in range(n_streams)]
+    d_depth, d_mask_u8, d_albedo, d_normals, d_light, d_amb = batches[0]
+    d_mask = d_mask_u8
     ev = HipEvents()
     cam = (1570.0 * Hh / 256.0, 1570.0 * Hh / 256.0, Ww / 2.0, Hh / 2.0, 1610.0)
-    d_mask_u8 = R.mask_to_u8(d_mask).reshape(-1, Hh, Ww).contiguous()
-    d_light3, d_amb2 = d_light.reshape(B, Ll, 3).contiguous(), d_amb.reshape(B, Ll).contiguous()
-    plan_inputs = (d_depth, d_mask_u8, d_light3, d_amb2, None if a.from_depth else d_normals, d_albedo)
+
+    def inputs_of(bt):
+        dd, mm, al, nr, li, am = bt
+        return (dd, mm, li.reshape(B, Ll, 3).contiguous(), am.reshape(B, Ll).contiguous(), None if a.from_depth else nr, al)
+
+    stream_inputs = [inputs_of(bt) for bt in batches]
+    plan_inputs = stream_inputs[0]
 
     def new_plan():
         return R.RenderFwdPlan(B, Ll, Hh, Ww, prm, dev, want_argmin=False, mask_batch=d_mask_u8.shape[0],
                                camera=cam if a.from_depth else None, options=base_opt)
 
-    n_streams = max(1, a.streams)
     use_plans = not (a.eager or a.direct or a.unfused)
     plans = [new_plan() for _ in range(n_streams)] if use_plans else None
     use_graph, graph_error = use_plans and not a.no_graph, None
     if use_graph:
         try:
-            for p_ in plans:
-                p_.capture(*plan_inputs)
+            for p_, inp in zip(plans, stream_inputs):
+                p_.capture(*inp)
         except Exception as e:      # a runtime that cannot capture: same kernels, issued call by call
             graph_error, use_graph = repr(e), False
             torch.cuda.synchronize()
@@ -353,7 +372,7 @@ def run_render(a, rank, world, dev, dist):
             if use_graph:
                 plans[i % n_streams].replay()
             elif use_plans:
-                plans[i % n_streams](*plan_inputs)
+                plans[i % n_streams](*stream_inputs[i % n_streams])
             else:
                 eager_step(base_opt)
 
@@ -439,6 +458,7 @@ def run_render(a, rank, world, dev, dist):
                                 % (B, Hh, Ww, Ll, Nn, a.mask, a.depth_noise, knobs or "default", n_streams)),
                    "faces_per_gpu": B, "H": Hh, "W": Ww, "lights_per_face": Ll, "n_samples": Nn,
                    "parallelism": "dp%d" % world, "hip_streams": n_streams, "batches_in_flight": n_streams,
+                   "distinct_face_batches": n_streams,
                    "host_path": ("RenderFwdPlan, hipGraph replay" if use_graph else "RenderFwdPlan (preallocated outputs)")
                    if use_plans else "render_fwd (eager)"},
         "faces_per_sec": world * B * Ll * a.steps / elapsed,
