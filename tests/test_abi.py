@@ -42,6 +42,11 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert L.gcfr_shadow_workspace_bytes(8, 256, 256) == 8 * 257 * 257 * 16 + 8 * 4 * 16 + 8 * (33 * 33 + 1) * 16 + 8 * 4 * 8 + 65 * 4 + 12 + 8 * 4 * 4
     assert L.gcfr_light_prep(None, 1, 1, 0.0, 4013.0, None, None, None) == -1
     assert L.gcfr_shade_fwd(None, None, None, None, None, None, 1, 1, 8, 8, 0.5, None, None, None, None, None) == -1
+    # the inference image side: null planes, a diagnostic output without its input, mask batch neither 1 nor B, in-place border fix
+    assert L.gcfr_inference_images_u8(None, None, None, None, None, None, None, None, None, 1, 1, 8, 8, None, None, None, None, None, None, None) == -1
+    assert L.gcfr_inference_images_u8(16, 16, None, None, None, None, None, None, 16, 1, 1, 8, 8, 16, 16, None, None, None, None, None) == -1
+    assert L.gcfr_inference_images_u8(16, 16, None, None, None, None, None, None, 16, 2, 3, 8, 8, 16, None, None, None, None, None, None) == -1
+    assert L.gcfr_fix_border_u8(16, 16, 1, 1, 8, 8, 16, None) == -1
 
 
 def test_options_struct_defaults_and_layout():
