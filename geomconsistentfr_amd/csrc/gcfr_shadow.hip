@@ -1611,8 +1611,10 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 // 95-99 VGPRs = 5 waves/SIMD): with the group body evaluated one sample at a time (GCFR_BODY_CHUNK = 1) the
 // inference variant fits six waves per SIMD, which beats the 119-VGPR / 4-wave build that kept four gathers in
 // flight per body by 8 % at B=8 on four streams and by 11 % at B=64.  The argmin variant carries three more loop
-// registers and is best at five waves.  7 or 8 waves spill 76 / 104 B and lose 30 ... 45 %
-// (tools/build_variant.sh + tools/ab.sh, tools/exp_grazing.py).
+// registers and is best at five waves (at six: 28 B of scratch for -3 %).  Neither spills at its occupancy
+// (tests/test_kernel_resources.py).  More waves do not pay even when they nearly fit -- end of round 2: 7 waves / 72
+// VGPRs / 12 B of scratch -12 %, 8 waves / 40 B -30 % -- because the texture addressers and the L1 are the second
+// resource near their limit (Roofline).  (tools/build_variant.sh + tools/ab.sh, tools/exp_grazing.py)
 #ifndef GCFR_MARCH_WAVES_PER_EU
 #define GCFR_MARCH_WAVES_PER_EU 6
 #endif
