@@ -33,11 +33,11 @@ class Options(ctypes.Structure):
 
 
 def options(tile_w=0, group=0, ksplit=-1, depth_bound_skip=-1, schedule=-1, tile_order=-1, event_start=None,
-            event_stop=None, counters=None) -> Options:
+            event_stop=None, counters=None, reserved=0) -> Options:
     o = Options()
     load().gcfr_options_default(ctypes.byref(o))
     o.tile_w, o.group, o.ksplit, o.depth_bound_skip = tile_w, group, ksplit, depth_bound_skip
-    o.schedule, o.tile_order = schedule, tile_order
+    o.schedule, o.tile_order, o.reserved = schedule, tile_order, reserved
     o.event_start, o.event_stop, o.counters = event_start, event_stop, counters
     return o
 

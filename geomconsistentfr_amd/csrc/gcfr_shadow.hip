@@ -582,6 +582,28 @@ __device__ inline void build_stats_block(int chunk, int b, const float *__restri
     }
 }
 
+// The board of schedule 6 (helping across the chip; see march_tile, SPLIT = 4): reset by the prepass, used by the march.
+constexpr int kHelpSlots = 1024, kHelpEmpty = 0, kHelpPosted = 1, kHelpTaken = 2, kHelpReclaimed = 3;
+#ifndef GCFR_HELP_BODIES
+#define GCFR_HELP_BODIES 4
+#endif
+#ifndef GCFR_HELP_MIN_GROUPS
+#define GCFR_HELP_MIN_GROUPS 6
+#endif
+[[maybe_unused]] constexpr int kHelpBodies = GCFR_HELP_BODIES, kHelpMinGroups = GCFR_HELP_MIN_GROUPS;
+struct HelpSlot {
+    int state, arrivals;
+    int bl, qy, tx;          // the tile
+    int k_mid, k_far;        // the posted samples [k_mid, k_far)
+    int poster_duty;         // what the second arriver goes on to complete: -1 the tile itself, s >= 0 the taker's side of slot s
+    unsigned warm[64];       // the poster's running minima (f32 bits) when it posted: valid bounds for the taker
+    unsigned part[2][64];    // partial results {poster's side, taker's side}: f32 bits of min S | any_masked << 31
+};
+struct HelpArea {
+    int n_posted, pad[15];
+    HelpSlot slot[kHelpSlots];
+};
+
 // Prepass, one launch.  Grid x = [depth-bounds tiles | statistics chunks | repack blocks], y = image:
 //   (d) the depth-bounds tiles (head of the grid: their short dependent-load chains start first),
 //   (c) per-chunk partial mask bounding boxes and depth ranges (build_stats_block),
@@ -596,7 +618,7 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
                                                          float4 *__restrict__ zb, int zb_blocks, int stat_blocks,
                                                          int want_z, int vec_ok, int N,
                                                          const double *__restrict__ t_table, int group,
-                                                         int *__restrict__ tflag)
+                                                         int *__restrict__ tflag, HelpArea *__restrict__ help)
 {
     const int Wp = W + 1, Hp = H + 1;
     const int b = blockIdx.y;
@@ -627,6 +649,14 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
         if (threadIdx.x == 0) {
             tflag[0] = all_ok ? 1 : 0;
             tflag[kQueueSlot] = 0;  // the persistent march's tile queue (an atomic counter), reset for this call
+        }
+    }
+    if (help && qb == 1 && b == 0) {  // an empty board for this call's march (schedule 6)
+        if (threadIdx.x == 0)
+            help->n_posted = 0;
+        for (int i = threadIdx.x; i < kHelpSlots; i += blockDim.x) {
+            help->slot[i].state = kHelpEmpty;
+            help->slot[i].arrivals = 0;
         }
     }
     if (pl.light_raw && qb == 0) {
@@ -679,11 +709,13 @@ struct ShadowQuadArgs {
     const float *light_pt;  // (B,L,3)
     const double *t_table;  // (N)
     unsigned long long *counters;  // GCFR_COUNTERS builds: work counts, see gcfr_options
+    HelpArea *help;         // the board of posted half-tiles (schedule 6), reset by the prepass
     int32_t mask_batch, B, L, H, W, N;
     int32_t tiles_x, tiles_y;  // tiles per image row / column
     int32_t total_tiles;       // B * L * tiles_x * tiles_y (persistent schedule)
     int32_t tile_order;        // persistent schedule: see gcfr_options
     int32_t bl_offset;         // grid schedule: first (image, light) index of this launch (grid z is limited to 65535)
+    int32_t help_bodies, help_min_groups;  // schedule 6: post after this many executed groups / with this many left
     MarchEpilogueArgs epi;
 };
 
@@ -821,6 +853,72 @@ __device__ inline int fresh_lane_id()
     return l;
 }
 
+// SPLIT = 4, helping across the chip (shadow_fwd_quad_help_kernel; gcfr_options.schedule 6).  One launch of the grid
+// schedule ends when its heaviest tile does, long after half of the SIMDs have gone idle; stealing
+// inside the workgroup (SPLIT = 3) cannot help, because the idle SIMDs sit on other CUs.  Here a wave that has
+// executed kHelpBodies sample groups of its tile and still has kHelpMinGroups to go POSTS the far half of what is left
+// in a small board in global memory (its range, the tile's coordinates and its running minima as a warm start) and
+// carries on with the near half; a wave that has finished its own tile TAKES a posted half, re-runs that tile's
+// prologue and marches the half (and may post again).  Nobody ever waits: each posted half is a rendezvous of two
+// arrivals -- whoever completes the poster's side and whoever completes the taker's side each publish their partial
+// minima and fetch-add `arrivals`; the first to arrive simply leaves, the second merges both partials and inherits
+// the poster's duty (another rendezvous one level up, or, at the root, the tile's epilogue).  A half nobody took by
+// the time its poster is done is taken back with one compare-and-swap and marched by the poster itself.  Minima
+// merge in any order, so min_dist is the sequential march's bit for bit (inference variant only: no argmin).
+// MEASURED AND REJECTED (experimental builds only, profiles/r02_schedule_experiments.md section J): every hop of the
+// protocol is a memory-side round trip of 2-3 us across XCDs, a help needs six or more, and the launch it is meant to
+// shorten lasts 72 us -- the more halves are posted, the slower the launch (135 ... 230 us).
+#define GCFR_GLOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GCFR_GSTORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// Ordering on the board WITHOUT fences.  The chip is eight XCDs with an L2 each: an agent-scope release / acquire
+// fence (__threadfence, or acquire / release orders on the atomics) writes back and invalidates the issuing XCD's whole
+// L2 -- every wave there loses its cached texels (measured: the helping march 7x slower than the grid).  Every access
+// to the board is therefore a RELAXED agent-scope atomic -- such loads and stores bypass the non-coherent levels and
+// act at the memory side -- and "data before flag" is kept by waiting for the data stores' acknowledgements
+// (s_waitcnt vmcnt(0)) before the flag is touched; readers touch the flag first (a returning RMW) and read the data
+// after it has returned.
+__device__ __forceinline__ void help_order()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0);
+    asm volatile("" ::: "memory");
+}
+// (whole wave) take one of the newest posted halves that is still up for grabs, or -1.  No shared take counter: a
+// read-modify-write on ONE address completes every ~20 ns chip-wide, and 8192 finishing waves bumping one counter would
+// by themselves outlast the launch (measured: 34 ms).  Each lane reads the state of one of the newest 64 ... 256 slots
+// (plain L2 reads), the wave picks a pseudo-random posted one and lane 0 claims it with a compare-and-swap on that
+// slot alone; up to three candidates per window, then it gives up -- a half nobody takes goes back to its poster.
+__device__ inline int help_take(HelpArea *ha, int lane, unsigned salt)
+{
+    const int np = min(__builtin_amdgcn_readfirstlane(GCFR_GLOAD(&ha->n_posted)), kHelpSlots);
+    for (int w = 0; w < 4; ++w) {
+        const int hi = np - 64 * w;
+        if (hi <= 0)
+            break;
+        const int idx = hi - 1 - lane;  // lane 0: the newest of this window
+        const int st = idx >= 0 ? GCFR_GLOAD(&ha->slot[idx].state) : kHelpEmpty;
+        unsigned long long m = __builtin_amdgcn_ballot_w64(st == kHelpPosted);
+        for (int tries = 0; m != 0ull && tries < 3; ++tries) {
+            const int kth = (int)((salt + 7u * (unsigned)tries) % (unsigned)__builtin_popcountll(m));
+            unsigned long long mm = m;
+            for (int i = 0; i < kth; ++i)
+                mm &= mm - 1ull;
+            const int l = (int)__builtin_ctzll(mm);
+            const int cand = hi - 1 - l;
+            int got = 0;
+            if (lane == 0) {
+                int e = kHelpPosted;
+                got = __hip_atomic_compare_exchange_strong(&ha->slot[cand].state, &e, kHelpTaken, __ATOMIC_RELAXED,
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+            }
+            if (__builtin_amdgcn_readfirstlane(got))
+                return cand;
+            m &= ~(1ull << l);
+        }
+    }
+    return -1;
+}
+
 // SPLIT = 3, work stealing inside the workgroup (shadow_fwd_quad_steal_kernel).  The workgroup's four tiles are four
 // queues of sample groups in LDS.  A wave first marches its OWN tile, claiming kStealChunk groups at a time (a fetch-add;
 // consecutive claims continue the prefetch pipeline, so an unshared tile marches exactly as in the grid schedule);
@@ -864,8 +962,8 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
                                            const bool tile_ok = true)
 {
     constexpr int TILE_H = 64 / TILE_W;
-    constexpr bool STEAL = SPLIT == 3;
-    static_assert(!(STEAL && WANT_ARGMIN), "work stealing merges minima, not first indices");
+    constexpr bool STEAL = SPLIT == 3, HELP = SPLIT == 4;
+    static_assert(!((STEAL || HELP) && WANT_ARGMIN), "work stealing / helping merge minima, not first indices");
     if (STEAL && owner && !tile_ok) {  // a wave without a tile of its own: empty queue, then it may steal
         StealShared &ss0 = steal_shared();
         if ((threadIdx.x & 63) == 0) {
@@ -1203,6 +1301,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         const float m01 = fminf(run_min[lane], run_min[64 + lane]), m23 = fminf(run_min[128 + lane], run_min[192 + lane]);
         return fminf(bestS, fminf(m01, m23));
     };
+    int help_bodies = 0;  // (HELP) sample groups of this tile this wave has executed
     auto group = [&](int k0, const Prefetched &cur, Prefetched &nxt, bool check_finished) -> bool {
         const double ta64 = tc0, tb64 = tc3;  // first / last table value of THIS group (tq of the previous call)
         tc0 = tq[0];
@@ -1240,6 +1339,8 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         constexpr int GCFR_BODY_CHUNK = KSPLIT ? DEPTH : 1;  // (KSPLIT here: SPLIT == 1 only)
         if (run_body) {
           GCFR_COUNT(kCntBodies, 1);
+          if (HELP)
+              ++help_bodies;
 #ifdef GCFR_PRIO_AFTER
           // Longest-job-first at the issue port: a wave that keeps executing bodies is one of the few heavy ones whose
           // length sets the launch time; VALU issue is arbitrated by priority, so raising it lets the heavy wave run
@@ -1398,6 +1499,115 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
             return;
         bestS = __builtin_bit_cast(float, *(volatile unsigned *)&ss.min_bits[ti][lane]);
         any_masked = any_masked || (*(volatile unsigned *)&ss.anym[ti][lane] != 0u);
+    } else if (HELP) {
+        HelpArea *const ha = a->help;
+        int duty = ti;  // -1: this wave answers for the tile itself; s >= 0: for the taker's side of slot s
+        if (duty >= 0) {  // a taken half: its range, and the poster's running minima as a warm start
+            HelpSlot *hs = &ha->slot[duty];
+            k_begin = max(k_begin, __builtin_amdgcn_readfirstlane(GCFR_GLOAD(&hs->k_mid)));
+            k_end = min(k_end, __builtin_amdgcn_readfirstlane(GCFR_GLOAD(&hs->k_far)));
+            bestS = __builtin_bit_cast(float, GCFR_GLOAD(&hs->warm[lane]));
+        }
+        auto pack = [&]() { return __builtin_bit_cast(unsigned, bestS) | (any_masked ? 0x80000000u : 0u); };
+        // publish this side's partial result, arrive; true = the other side arrived first and its partial was merged
+        auto rendezvous = [&](HelpSlot *hs, int side) -> bool {
+            GCFR_GSTORE(&hs->part[side][lane], pack());
+            help_order();
+            int arr = 0;
+            if (lane == 0)
+                arr = __hip_atomic_fetch_add(&hs->arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            arr = __builtin_amdgcn_readfirstlane(arr);
+            if (arr == 0)
+                return false;
+            help_order();
+            const unsigned o = GCFR_GLOAD(&hs->part[side ^ 1][lane]);
+            bestS = fminf(bestS, __builtin_bit_cast(float, o & 0x7fffffffu));
+            any_masked = any_masked || (o >> 31) != 0u;
+            return true;
+        };
+        int child = -1, child_mid = 0, child_far = 0;
+        int k_lo = k_begin;
+        for (;;) {
+            bool fin = false;
+            if (k_lo < k_end) {
+                load_tq(k_lo);
+                tc0 = tq[0];
+                tc3 = tq[DEPTH - 1];
+                prefetch(bufA);
+                load_tq(k_lo + DEPTH);
+                for (int k0 = k_lo; k0 < k_end; k0 += 2 * DEPTH) {
+                    if (!group(k0, bufA, bufB, false)) {
+                        fin = true;
+                        break;
+                    }
+                    if (k0 + DEPTH >= k_end)
+                        break;
+                    if (!group(k0 + DEPTH, bufB, bufA, true)) {
+                        fin = true;
+                        break;
+                    }
+                    // a heavy tile with a long way to go: post the far half of what is left
+                    const int k_next = k0 + 2 * DEPTH;
+                    if (child < 0 && help_bodies >= a->help_bodies && k_end - k_next >= a->help_min_groups * DEPTH) {
+                        int pidx = kHelpSlots;
+                        if (lane == 0)
+                            pidx = __hip_atomic_fetch_add(&ha->n_posted, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pidx = __builtin_amdgcn_readfirstlane(pidx);
+                        if (pidx < kHelpSlots) {
+                            const int k_mid = k_next + (((k_end - k_next) / DEPTH) >> 1) * DEPTH;
+                            HelpSlot *cs = &ha->slot[pidx];
+                            if (lane == 0) {
+                                GCFR_GSTORE(&cs->bl, bl);
+                                GCFR_GSTORE(&cs->qy, qy);
+                                GCFR_GSTORE(&cs->tx, tx);
+                                GCFR_GSTORE(&cs->k_mid, k_mid);
+                                GCFR_GSTORE(&cs->k_far, k_end);
+                                GCFR_GSTORE(&cs->poster_duty, duty);
+                            }
+                            GCFR_GSTORE(&cs->warm[lane], __builtin_bit_cast(unsigned, bestS));
+                            help_order();
+                            if (lane == 0)
+                                GCFR_GSTORE(&cs->state, (int)kHelpPosted);
+                            child = pidx;
+                            child_mid = k_mid;
+                            child_far = k_end;
+                            k_end = k_mid;
+                            help_bodies = 0;
+                        } else {
+                            help_bodies = -(1 << 20);  // the board is full: stop trying
+                        }
+                    }
+                }
+            }
+            k_lo = k_end;  // (this range is done)
+            if (child >= 0) {  // the half posted from this range
+                HelpSlot *cs = &ha->slot[child];
+                int st = kHelpPosted;
+                if (lane == 0)
+                    (void)__hip_atomic_compare_exchange_strong(&cs->state, &st, kHelpReclaimed, __ATOMIC_RELAXED,
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                st = __builtin_amdgcn_readfirstlane(st);  // (the value found: kHelpPosted = nobody came, taken back)
+                if (st == kHelpPosted) {
+                    child = -1;
+                    if (!fin) {  // march it here after all (finished early: no later sample can be taken, it is dead)
+                        k_lo = child_mid;
+                        k_end = child_far;
+                        continue;
+                    }
+                } else {
+                    child = -1;
+                    if (!rendezvous(cs, 0))
+                        return;  // the taker's side finishes later and carries this wave's duty on
+                }
+            }
+            if (duty < 0)
+                break;  // the tile's result is complete in this wave: epilogue
+            HelpSlot *ps = &ha->slot[duty];
+            const int up = __builtin_amdgcn_readfirstlane(GCFR_GLOAD(&ps->poster_duty));
+            if (!rendezvous(ps, 1))
+                return;  // the poster's side finishes later
+            duty = up;
+        }
     } else {
     const int k_first = k_begin + (COOP ? wave * DEPTH : 0);
     if (k_first < k_end) {
@@ -1780,7 +1990,7 @@ __device__ __forceinline__ void march_grid_ordered(ArgPtr a)
 
 #endif  // GCFR_EXPERIMENTAL_SCHEDULES
 
-enum { kSchedGrid = 0, kSchedQueue = 1, kSchedStrided = 2, kSchedGridOrdered = 3 };
+enum { kSchedGrid = 0, kSchedQueue = 1, kSchedStrided = 2, kSchedGridOrdered = 3, kSchedHelp = 6 };
 
 template <int SCHED, int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE>
 __device__ __forceinline__ void march_dispatch()
@@ -1821,6 +2031,43 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_ksplit_kernel(ShadowQuadA
 }
 
 #ifdef GCFR_EXPERIMENTAL_SCHEDULES
+// Helping across the chip (SPLIT = 4, gcfr_options.schedule 6; see march_tile): the grid schedule's workgroups -- wave
+// w of workgroup (x, y, z) owns tile (4 x + w, y) of pair z -- whose waves, once their own tile is done, keep taking
+// posted half-tiles from the board until it is empty.
+#ifndef GCFR_HELP_WAVES_PER_EU
+#define GCFR_HELP_WAVES_PER_EU 6
+#endif
+template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(GCFR_HELP_WAVES_PER_EU, GCFR_HELP_WAVES_PER_EU))) void shadow_fwd_quad_help_kernel(ShadowQuadArgs)
+{
+    const ArgPtr a = kernel_args();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    int bl = a->bl_offset + (int)blockIdx.z, qy = (int)blockIdx.y, tx = (int)blockIdx.x * 4 + wave, duty = -1;
+    bool have = tx < a->tiles_x;
+    for (;;) {
+        if (!have) {
+            HelpArea *ha = a->help;
+            const unsigned salt = ((unsigned)blockIdx.x * 4u + (unsigned)wave + 64u * (unsigned)blockIdx.y) * 2654435761u +
+                                  (unsigned)__builtin_amdgcn_s_memtime();
+            const int s = help_take(ha, lane, __builtin_amdgcn_readfirstlane((int)(salt >> 8)));
+            if (s < 0)
+                break;
+            bl = __builtin_amdgcn_readfirstlane(GCFR_GLOAD(&ha->slot[s].bl));
+            qy = __builtin_amdgcn_readfirstlane(GCFR_GLOAD(&ha->slot[s].qy));
+            tx = __builtin_amdgcn_readfirstlane(GCFR_GLOAD(&ha->slot[s].tx));
+            duty = s;
+        }
+        have = false;
+        const ImageStats st = reduce_image_stats(a, bl / a->L, lane, a->zb != nullptr);
+        if (st.mask_all_ones != 0)
+            march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, 4, true>(a, bl, qy, tx, st, duty);
+        else
+            march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, 4, false>(a, bl, qy, tx, st, duty);
+    }
+}
+
 // work stealing inside the workgroup (SPLIT = 3, see StealShared): one workgroup = kStealTiles waves = kStealTiles
 // tiles; 1-D grid of G * BL workgroups, G = ceil(tiles per image / kStealTiles), BL = (image, light) pairs.
 // Workgroup id = j * BL + r; its wave w owns tile u = w * G + j (row-major tile list, each tile row rotated by five
@@ -1939,6 +2186,7 @@ struct Knobs {
     int zbound = 1;      // depth-bound group skip (exact): 1 on, 0 off
     int schedule = -1;   // 0 grid, 1 persistent tile queue, -1 auto
     int tile_order = -1; // persistent schedule: 0, 1, 2, -1 auto
+    int reserved = 0;    // schedule 6 tuning: bodies | min_groups << 8 (0 = defaults)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     unsigned long long *counters = nullptr;
 };
@@ -1952,7 +2200,7 @@ static int resolve_options(const gcfr_options *opt, Knobs &k)
     const int tw = opt->tile_w, g = opt->group;
     if ((tw != 0 && tw != 8 && tw != 16 && tw != 32 && tw != 64) || (g != 0 && g != 1 && g != 2 && g != 4) ||
         opt->ksplit < -1 || opt->ksplit > 1 || opt->depth_bound_skip < -1 || opt->depth_bound_skip > 1 ||
-        opt->schedule < -1 || opt->schedule > 5 || opt->tile_order < -1 || opt->tile_order > 4)
+        opt->schedule < -1 || opt->schedule > 6 || opt->tile_order < -1 || opt->tile_order > 4)
         return GCFR_ERR_INVALID_ARGUMENT;
 #ifndef GCFR_EXPERIMENTAL_SCHEDULES
     if (opt->schedule > 0)
@@ -1964,6 +2212,7 @@ static int resolve_options(const gcfr_options *opt, Knobs &k)
     k.zbound = opt->depth_bound_skip < 0 ? 1 : opt->depth_bound_skip;
     k.schedule = opt->schedule;
     k.tile_order = opt->tile_order;
+    k.reserved = opt->reserved;
     k.ev_start = (hipEvent_t)opt->event_start;
     k.ev_stop = (hipEvent_t)opt->event_stop;
     k.counters = (unsigned long long *)opt->counters;
@@ -1979,7 +2228,7 @@ extern "C" void gcfr_options_default(gcfr_options *opt)
     opt->ksplit = opt->depth_bound_skip = opt->schedule = opt->tile_order = -1;
 }
 
-// workspace layout: [quad texels | partial boxes | depth-bounds records | partial depth ranges | tflag, queue | all-ones flags]
+// workspace layout: [quad texels | partial boxes | depth-bounds records | partial depth ranges | tflag, queue | all-ones flags | help board]
 extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
 {
     if (B <= 0 || H <= 0 || W <= 0)
@@ -1987,7 +2236,11 @@ extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
     const size_t n_stat = (size_t)n_stat_chunks(H, W);
     return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4) + (size_t)B * n_stat * 4 * sizeof(int) +
            (size_t)B * (size_t)zb_max_tiles(H, W) * sizeof(float4) + (size_t)B * n_stat * 2 * sizeof(int) +
-           (kQueueSlot + 1) * sizeof(int) + 12 + (size_t)B * n_stat * sizeof(int);
+           (kQueueSlot + 1) * sizeof(int) + 12 + (size_t)B * n_stat * sizeof(int)
+#ifdef GCFR_EXPERIMENTAL_SCHEDULES
+           + 16 + sizeof(HelpArea)  // the board of schedule 6
+#endif
+        ;
 }
 
 // Number of compute units of the current device (immutable hardware fact; queried once per device and process).
@@ -2006,7 +2259,7 @@ static int device_cu_count()
     return n;
 }
 
-enum Schedule { kGrid = kSchedGrid, kQueue = kSchedQueue, kStrided = kSchedStrided, kGridOrdered = kSchedGridOrdered, kCoop = 4, kSteal = 5, kKSplit };
+enum Schedule { kGrid = kSchedGrid, kQueue = kSchedQueue, kStrided = kSchedStrided, kGridOrdered = kSchedGridOrdered, kCoop = 4, kSteal = 5, kHelp = kSchedHelp, kKSplit };
 
 template <int TILE_W, int DEPTH, bool FUSE>
 static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argmin, Schedule sch, dim3 grid,
@@ -2040,6 +2293,13 @@ static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argm
                 GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, false, false, DEPTH, FUSE);
         }
 #ifdef GCFR_EXPERIMENTAL_SCHEDULES
+    } else if (sch == kHelp) {
+        if constexpr (TILE_W == 16 && DEPTH == 4) {  // (the one shape the helping kernel is built for)
+            if (even_half)
+                GCFR_LAUNCH(shadow_fwd_quad_help_kernel, true, DEPTH, FUSE);
+            else
+                GCFR_LAUNCH(shadow_fwd_quad_help_kernel, false, DEPTH, FUSE);
+        }
     } else if (sch == kSteal) {
         if constexpr (TILE_W == 16 && DEPTH == 4) {  // (the one shape the stealing kernel is built for)
             if (even_half)
@@ -2178,13 +2438,19 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         int *zrange = (int *)(zb + (size_t)B * zb_max_tiles(H, W));  // (B, n_stat, 2)
         int *tflag = zrange + (size_t)B * n_stat * 2;                 // [0] table flag, [kQueueSlot] tile queue
         int *mones = tflag + kQueueSlot + 4;                          // (B, n_stat) all-ones flags of the mask chunks
+#ifdef GCFR_EXPERIMENTAL_SCHEDULES
+        HelpArea *help = (HelpArea *)(((uintptr_t)(mones + (size_t)B * n_stat) + 15u) & ~(uintptr_t)15u);  // schedule 6
+#else
+        HelpArea *help = nullptr;
+#endif
         const bool use_zb = kn.zbound && N >= 2;
         const int quad_blocks = (texels + 255) / 256;
         const int zb_blocks = use_zb ? (zb_max_tiles(H, W) + 3) / 4 : 0;  // sized for the finest stride
         const int vec_ok = ((W & 15) == 0) && (((uintptr_t)depth & 15u) == 0) && (((uintptr_t)mask_u8 & 15u) == 0);
         hipLaunchKernelGGL(build_quad_kernel, dim3(zb_blocks + (int)n_stat + quad_blocks, B), dim3(256), 0, st, depth,
                            (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox, zrange, mones, zb, zb_blocks,
-                           (int)n_stat, use_zb ? 1 : 0, vec_ok, N, t_table, kn.group, tflag);
+                           (int)n_stat, use_zb ? 1 : 0, vec_ok, N, t_table, kn.group, tflag,
+                           kn.schedule == kSchedHelp ? help : nullptr);
         ShadowQuadArgs a = {};
         a.zb = use_zb ? zb : nullptr;
         a.zrange = zrange;
@@ -2197,6 +2463,9 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         a.light_pt = light_pt;
         a.t_table = t_table;
         a.counters = kn.counters;
+        a.help = help;
+        a.help_bodies = (kn.reserved & 0xff) ? (kn.reserved & 0xff) : kHelpBodies;
+        a.help_min_groups = ((kn.reserved >> 8) & 0xff) ? ((kn.reserved >> 8) & 0xff) : kHelpMinGroups;
         a.mask_batch = mask_batch;
         a.B = B;
         a.L = L;
@@ -2212,8 +2481,8 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         // without a running minimum, so it loses from B = 4 up).  Otherwise the persistent tile queue.
         const bool ksplit = (kn.ksplit < 0) ? (tiles_total <= 2048 && N >= 16) : (kn.ksplit == 1);
         Schedule sch = ksplit ? kKSplit : (Schedule)(kn.schedule < 0 ? kSchedGrid : kn.schedule);
-        if (sch == kSteal && (argmin != nullptr || TILE_W != 16 || kn.group != 4))
-            sch = kGrid;  // (work stealing: inference variant, 16x4 tiles, groups of four)
+        if ((sch == kSteal || sch == kHelp) && (argmin != nullptr || TILE_W != 16 || kn.group != 4))
+            sch = kGrid;  // (work stealing / helping: inference variant, 16x4 tiles, groups of four)
         a.tile_order = kn.tile_order < 0 ? 0 : kn.tile_order;
         a.epi.min_dist = min_dist;
         a.epi.argmin = argmin;

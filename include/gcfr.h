@@ -52,14 +52,15 @@ typedef struct gcfr_options {
     int32_t ksplit;            /* split each tile's sample range over the 4 waves of a workgroup: 0, 1, -1 = auto by launch size */
     int32_t depth_bound_skip;  /* exact depth-bound group skip: 0, 1, -1 = auto (on) */
     int32_t schedule;          /* how tiles reach waves: 0 (= -1, auto) the 3-D grid, one workgroup per four adjacent tiles,
-                                  image-major.  1 ... 5 select the alternatives round 2 measured and rejected (persistent
+                                  image-major.  1 ... 6 select the alternatives round 2 measured and rejected (persistent
                                   waves with an atomic tile queue / strided assignment, a 1-D grid in `tile_order`, four
-                                  cooperating waves per tile, work stealing between the 16 waves of a workgroup;
+                                  cooperating waves per tile, work stealing between the 16 waves of a workgroup, helping across the
+                                  chip through a board in global memory;
                                   profiles/r02_schedule_experiments.md): they exist only in a
                                   library built with -DGCFR_EXPERIMENTAL_SCHEDULES (gcfr_version() then contains
                                   "+schedules"), otherwise GCFR_ERR_INVALID_ARGUMENT */
     int32_t tile_order;        /* queue order of the experimental schedules 1-3 (0 ... 4), ignored by the grid; -1 = auto */
-    int32_t reserved;
+    int32_t reserved;          /* 0.  (Experimental builds: thresholds of schedule 6, bodies | min_groups << 8.) */
     void *event_start;         /* hipEvent_t recorded on `stream` immediately before the march kernel, or NULL */
     void *event_stop;          /* hipEvent_t recorded immediately after it, or NULL */
     uint64_t *counters;        /* DEVICE array of GCFR_N_COUNTERS + 4 * (number of tiles) u64: the march kernel adds its work

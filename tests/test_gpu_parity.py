@@ -522,3 +522,44 @@ def test_work_stealing_schedule_gives_the_grid_bits():
         for k in outs[0]:
             if torch.is_tensor(outs[0][k]):
                 assert torch.equal(outs[0][k], outs[1][k]), (k, B, Hs, Ws)
+
+
+def test_helping_schedule_gives_the_grid_bits():
+    """gcfr_options.schedule = 6 (experimental builds; measured and rejected): heavy tiles post the far half of their remaining samples on a board in
+    global memory, waves that have finished take them; partial minima meet in two-party rendezvous, the last arriver
+    finishes the tile.  min_dist and everything the fused epilogue derives from it equal the grid schedule's bits, on
+    every launch (who helps whom differs from run to run)."""
+    from geomconsistentfr_amd import RenderParams, _lib
+    from geomconsistentfr_amd.block import light_prep, render_fwd, shadow_min_distance
+    if not _lib.has_experimental_schedules():
+        pytest.skip("schedule 6 exists in -DGCFR_EXPERIMENTAL_SCHEDULES builds only (profiles/r02_schedule_experiments.md, J)")
+    rng = np.random.default_rng(6)
+    for (B, Hs, Ws, N, L) in [(8, 256, 256, 160, 1), (3, 66, 130, 48, 2), (2, 130, 70, 37, 3), (1, 512, 512, 320, 2), (5, 96, 128, 80, 1)]:
+        r, c = np.mgrid[0:Hs, 0:Ws]
+        dome = 90.0 * np.sqrt(np.clip(1.0 - ((c - 0.5 * Ws) / (0.48 * Ws)) ** 2 - ((r - 0.5 * Hs) / (0.5 * Hs)) ** 2, 0.0, None))
+        depth = np.stack([(dome * (0.5 + 0.5 * (b % 3)) + (30.0 if b % 2 else 1.0) * rng.random((Hs, Ws))).astype(np.float32) for b in range(B)])
+        ell = ((((c - 0.5 * Ws) / (0.42 * Ws)) ** 2 + ((r - 0.5 * Hs) / (0.45 * Hs)) ** 2) < 1)
+        kinds = [ell, np.ones_like(ell), rng.random((Hs, Ws)) > 0.4, np.zeros_like(ell), ell & (rng.random((Hs, Ws)) > 0.05)]
+        mask = np.stack([kinds[(b + Hs) % len(kinds)] for b in range(B)]).astype(np.uint8)
+        lights = rng.standard_normal((B, L, 3)).astype(np.float32)
+        lights[:, 0, 2] = np.abs(lights[:, 0, 2]) * 0.05                     # grazing: long marches, the heavy tiles
+        lights[-1, -1] = (0.001, -0.002, 1.0)
+        prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
+        _, pt = light_prep(to_dev(lights), prm)
+        for zb in (1, 0):
+            ref, _ = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, want_argmin=False,
+                                         options=_lib.options(schedule=0, depth_bound_skip=zb))
+            for rep in range(4):
+                md, _ = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, want_argmin=False,
+                                            options=_lib.options(schedule=6, depth_bound_skip=zb))
+                bad = (md != ref).nonzero()
+                assert torch.equal(md, ref), (B, Hs, Ws, zb, rep, bad[:5].tolist())
+        alb = to_dev(rng.random((B, 3, Hs, Ws)).astype(np.float32))
+        nrm = rng.standard_normal((B, 3, Hs, Ws)).astype(np.float32)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        amb = to_dev((0.3 + 0.4 * rng.random((B, L))).astype(np.float32))
+        outs = [render_fwd(to_dev(depth), to_dev(mask), to_dev(lights), amb, to_dev(nrm), alb, prm, want_argmin=False,
+                           options=_lib.options(schedule=sc)) for sc in (0, 6, 6)]
+        for k in outs[0]:
+            if torch.is_tensor(outs[0][k]):
+                assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k]), (k, B, Hs, Ws)
