@@ -1107,6 +1107,8 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         k_begin = nb;
         k_end = ne;
     }
+    if (k_begin >= k_end)
+        use_zb = false;  // no ray of this tile reaches the mask's box: nothing to march, so no bounds set-up either
     GCFR_COUNT(kCntTiles, 1);
     GCFR_COUNT(kCntGroupsNominal, (N - k_lo + DEPTH - 1) / DEPTH);
     GCFR_COUNT(kCntSamplesInRange, k_end > k_begin ? k_end - k_begin : 0);
