@@ -1210,11 +1210,6 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     // distance body is skipped -- masked samples only contribute "1e6" (T8:512), which `any_masked`
     // records.  The skip is wave-uniform (ballot -> scalar branch) and exact; on face-shaped masks more
     // than half of all wave-steps take it (rays that have left the face, background tiles).
-    auto sample_pos = [&](int k, double &sx, double &sy) {
-        const double t = tt[k];  // wave-uniform -> s_load
-        sx = x64 + t * dx64;            // T8:472 / 480 (f64, mul and add rounded separately)
-        sy = y64 + t * dy64;
-    };
     auto mask_offset = [&](double sx, double sy, int &col_r, int &row_r) -> int {  // T8:472-477, 510
         if (EVEN_HALF) {
             col_r = lo32(sx + Mx);  // rint(sx) + W/2
@@ -1362,8 +1357,12 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
             f32x4 qv[DEPTH];
 #pragma unroll
             for (int j = h0; j < h0 + GCFR_BODY_CHUNK && j < DEPTH; ++j) {
-                double sx, sy;
-                sample_pos(clampk(k0 + j), sx, sy);
+                // the group's first and last table value are already in SGPRs (ta64 / tb64): no s_load, no wait (+1.2 %
+                // for the fused kernels; the march-only kernels, one register short at six waves, spill 16 B with it
+                // and lose 3 %: they keep the loads)
+                constexpr bool CARRIED = FUSE_SHADE || WANT_ARGMIN;
+                const double tj = (CARRIED && j == 0) ? ta64 : ((CARRIED && j == DEPTH - 1) ? tb64 : (double)tt[clampk(k0 + j)]);
+                const double sx = x64 + tj * dx64, sy = y64 + tj * dy64;  // T8:472 / 480 (mul and add rounded separately)
                 ux[j] = (sx + halfW) - 0.0001;  // unrounded position (T8:480-487)
                 uy[j] = (halfH - sy) - 0.0001;
                 fxd[j] = __builtin_floor(ux[j]);
