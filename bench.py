@@ -258,184 +258,415 @@ class HipEvents:
         assert self.hip.hipEventElapsedTime(self.ct.byref(ms), e0, e1) == 0
         return ms.value
 
-
-def setup_distributed(a):
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 and a.gpus > 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                         "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d" % (a.gpus, a.gpus))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
-    return rank, world, dev, dist
+    def destroy(self, e):
+        self.hip.hipEventDestroy(e)
 
 
-def fence(dist):
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+# ------------------------------------------------------------------------------------------------
+# process layout: `python bench.py --gpus N` spawns its own N ranks (one per GPU) when it was not started by
+# torch.distributed.run; under torch.distributed.run (RANK / WORLD_SIZE set) it is one of the ranks.
+# ------------------------------------------------------------------------------------------------
+def self_launch(a):
+    """Re-exec this script as N ranks under torch.distributed.run on 127.0.0.1 (a free port), rank r -> GPU r.
+    Returns the launcher's exit code; rank 0's JSON line passes through on stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["GCFR_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
-def max_over_ranks(dist, dev, seconds):
-    if dist is None:
-        return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+class Ranks:
+    """torch.distributed plumbing of one rank: `nccl` (= RCCL) when every rank has its own GPU; `gloo` when the ranks
+    share GPUs (--oversubscribe: launcher / barrier / max-over-ranks rehearsal on a box with fewer GPUs -- RCCL refuses
+    two ranks on one device) or when there is no GPU at all (--dry-run on CPU)."""
+
+    def __init__(self, a):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        self.n_dev = n_dev
+        if not a.dry_run:
+            assert n_dev > 0, "bench.py needs a GPU (the product has no CPU path)"
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world)))
+        self.shared_gpus = n_dev < local_world
+        if self.shared_gpus and n_dev > 0 and not (a.oversubscribe or a.dry_run):
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (add --oversubscribe to rehearse the launch "
+                             "path with several ranks per GPU over gloo)" % (self.world, n_dev))
+        self.dev = torch.device("cuda", self.local_rank % n_dev) if n_dev else torch.device("cpu")
+        if n_dev:
+            torch.cuda.set_device(self.dev)
+        self.dist, self.backend = None, None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            self.backend = "gloo" if (self.shared_gpus or not n_dev) else "nccl"
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)   # nccl == RCCL on ROCm
+            else:
+                dist.init_process_group("gloo")
+            self.dist = dist
+        self.cdev = self.dev if self.backend == "nccl" else torch.device("cpu")   # where collective payloads live
+
+    def fence(self):
+        if self.n_dev:
+            torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.n_dev:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, value):
+        """[value of rank 0, ..., value of rank N-1] on every rank"""
+        if self.dist is None:
+            return [float(value)]
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.cdev)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    def counted_ranks(self):
+        """number of ranks that took part in a SUM all-reduce of ones that really ran on the collective backend"""
+        if self.dist is None:
+            return 1
+        t = torch.ones(1, dtype=torch.float32, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        if self.n_dev:
+            torch.cuda.synchronize()
+        return int(round(float(t.item())))
+
+    def describe(self):
+        n = self.counted_ranks()
+        return {"n_gpus": self.world, "rccl_ranks": n if self.backend == "nccl" else (1 if self.dist is None else None),
+                "ranks": n,
+                "collective_backend": {"nccl": "nccl (RCCL)", "gloo": "gloo (%d ranks share %d GPU(s): launch-path "
+                                       "rehearsal, not a scaling number)" % (self.world, self.n_dev), None: "none (1 rank)"}[self.backend],
+                "self_launched": os.environ.get("GCFR_BENCH_SELF_LAUNCHED") == "1"}
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def regions_needed(steps, est_ms_per_step):
+    """A fenced region shorter than ~200 ms is dominated by its fixed fence / drain cost and is ONE sample (round 2's
+    record rested on a 1.03 ms region): repeat it >= 25 times, bounded to ~2 s in total."""
+    region_ms = steps * est_ms_per_step
+    if region_ms >= 200.0:
+        return 1
+    return int(max(25, min(200, 2000.0 / max(region_ms, 1e-3))))
 
 
 # ------------------------------------------------------------------------------------------------
 # workload "render": BASELINE configs[1]
 # ------------------------------------------------------------------------------------------------
-def run_render(a, rank, world, dev, dist):
-    from geomconsistentfr_amd import RenderParams, _lib
-    from geomconsistentfr_amd import block as R
+def ffhq_faces(B, first):
+    """`--data ffhq`: the three checkpoint-derived FFHQ depth maps and skin masks of the golden fixtures
+    (tests/golden/inputs.npz: sample_test_images_FFHQ/{00295,00110,00508}.png through the reference's lighting-transfer
+    network + shipped checkpoint, oracle/make_golden.py) tiled to B faces: face g = first + i uses fixture g mod 3,
+    mirrored left-right on every other pass through the three (a mirrored face is a face); the fixture albedo;
+    normals by finite differences of the depth (the render block takes normals as an input)."""
+    g = os.path.join(ROOT, "tests", "golden")
+    inp = np.load(os.path.join(g, "inputs.npz"))
+    alb0 = np.load(os.path.join(g, "albedo.npz"))["albedo"]
+    depths, masks = inp["depths"][1:4], inp["masks"][2:5]
+    lights11 = LIGHTS18[:11]
+    depth, mask, albedo, normals, light, amb = [], [], [], [], [], []
+    for i in range(B):
+        gi = first + i
+        d, m, al = depths[gi % 3], masks[gi % 3], alb0
+        if (gi // 3) % 2 == 1:
+            d, m, al = d[:, ::-1], m[:, ::-1], al[:, :, ::-1]
+        d = np.ascontiguousarray(d, np.float32)
+        depth.append(d)
+        mask.append(np.ascontiguousarray(m, np.uint8))
+        albedo.append(np.ascontiguousarray(al, np.float32))
+        gy, gx = np.gradient(d.astype(np.float64))
+        n = np.stack([-gx, gy, np.ones_like(gx)])
+        normals.append((n / np.linalg.norm(n, axis=0)).astype(np.float32))
+        light.append(lights11[i % 11])
+        amb.append(np.float32(0.5))
+    return (np.stack(depth), np.stack(mask), np.stack(albedo), np.stack(normals), np.stack(light),
+            np.asarray(amb, np.float32))
 
-    knobs = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)}
-    base_opt = _lib.options(**knobs) if knobs else None
-    B = a.faces
-    headline = (a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse" and a.depth_noise == 0.0
-                and B == FACES_PER_GPU and not knobs and not (a.direct or a.unfused or a.from_depth))
-    n_streams = max(1, a.streams)
-    Hh = Ww = a.size
-    Ll, Nn = a.lights, a.samples
-    default_shape = a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse"
-    prm = RenderParams() if default_shape else RenderParams(n_samples=a.samples, dt=0.8 / a.samples)
 
-    def device_batch(j):
-        """the j-th batch of B synthetic faces of this rank.  Every stream renders its OWN faces (geometry, mask, albedo:
-        batches in flight are different data, as in serving) under the SAME light assignment as batch 0 (face i takes
-        light i of the list), so that every batch is the workload BASELINE.md section 4 defines and not a harder or
-        easier mix of grazing and overhead lights."""
+class RenderRig:
+    """One render workload on one rank: `streams` batches of B faces resident in HBM, one RenderFwdPlan (own outputs and
+    workspace) per batch, each captured into a hipGraph; `timed(steps, streams)` issues `steps` steps round-robin and
+    returns the fenced wall time (max over ranks)."""
+
+    def __init__(self, rk, B, size=256, lights=1, samples=160, mask="ellipse", depth_noise=0.0, data="synthetic",
+                 streams=4, from_depth=False, want_argmin=False, knobs=None, graph=True, mode="plan"):
+        from geomconsistentfr_amd import RenderParams, _lib
+        from geomconsistentfr_amd import block as R
+        self.rk, self.R, self._lib = rk, R, _lib
+        self.B, self.size, self.L, self.N = B, size, lights, samples
+        self.mask, self.depth_noise, self.data = mask, depth_noise, data
+        self.from_depth, self.want_argmin, self.mode = from_depth, want_argmin, mode
+        self.knobs = knobs or {}
+        self.base_opt = _lib.options(**self.knobs) if self.knobs else None
+        self.n_streams = max(1, streams)
+        dev = self.dev = rk.dev
+        self.default_shape = size == 256 and lights == 1 and samples == 160
+        self.prm = RenderParams() if self.default_shape else RenderParams(n_samples=samples, dt=0.8 / samples)
+        self.cam = (1570.0 * size / 256.0, 1570.0 * size / 256.0, size / 2.0, size / 2.0, 1610.0)
+        self.batches = [self._device_batch(j) for j in range(self.n_streams)]
+        self.inputs = [self._inputs_of(bt) for bt in self.batches]
+        self.use_plans = mode == "plan"
+        self.plans = [self._new_plan() for _ in range(self.n_streams)] if self.use_plans else None
+        self.use_graph, self.graph_error = self.use_plans and graph, None
+        if self.use_graph:
+            try:
+                for p_, inp in zip(self.plans, self.inputs):
+                    p_.capture(*inp)
+            except Exception as e:      # a runtime that cannot capture: same kernels, issued call by call
+                self.graph_error, self.use_graph = repr(e), False
+                torch.cuda.synchronize()
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
+
+    # -- data ----------------------------------------------------------------------------------
+    def _device_batch(self, j):
+        """the j-th batch of B faces of this rank.  Every stream renders its OWN faces (geometry, mask, albedo: batches
+        in flight are different data, as in serving) under the SAME light assignment as batch 0 (face i takes light i of
+        the list), so that every batch is the workload BASELINE.md section 4 defines and not a harder or easier mix of
+        grazing and overhead lights."""
+        B, rank = self.B, self.rk.rank
         seed0 = rank * 1_000_000 + j * B
-        if default_shape:
+        if self.data == "ffhq":
+            assert self.default_shape, "--data ffhq: the fixtures are 256x256 faces, one light, 160 samples"
+            depth, mask, albedo, normals, light, amb = ffhq_faces(B, first=3 * rank + j * B)
+            if self.mask == "ones":
+                mask = np.ones_like(mask)
+        elif self.data == "train_depth":
+            return self._train_depth_batch(seed0)
+        elif self.default_shape and self.mask == "ellipse":
             depth, mask, albedo, normals, light, amb = synth_faces(B, seed0=seed0, light_seed0=rank * 1_000_000)
         else:
-            depth, mask, albedo, normals, light, amb = synth_faces_sized(B, seed0, a.size, a.lights, a.mask,
+            depth, mask, albedo, normals, light, amb = synth_faces_sized(B, seed0, self.size, self.L, self.mask,
                                                                          light_seed0=rank * 1_000_000)
-        if a.depth_noise > 0.0:
-            depth = depth + (a.depth_noise * np.random.default_rng(7 + j).random(depth.shape)).astype(np.float32)
-        t = [torch.from_numpy(x).to(dev) for x in (depth, mask, albedo, normals, light, amb)]
-        t[1] = R.mask_to_u8(t[1]).reshape(-1, Hh, Ww).contiguous()
+        if self.depth_noise > 0.0:
+            depth = depth + (self.depth_noise * np.random.default_rng(7 + j).random(depth.shape)).astype(np.float32)
+        t = [torch.from_numpy(np.ascontiguousarray(x)).to(self.dev) for x in (depth, mask, albedo, normals, light, amb)]
+        t[1] = self.R.mask_to_u8(t[1]).reshape(-1, self.size, self.size).contiguous()
         return t
 
-    batches = [device_batch(j) for j in range(n_streams)]
-    d_depth, d_mask_u8, d_albedo, d_normals, d_light, d_amb = batches[0]
-    d_mask = d_mask_u8
-    ev = HipEvents()
-    cam = (1570.0 * Hh / 256.0, 1570.0 * Hh / 256.0, Ww / 2.0, Hh / 2.0, 1610.0)
+    def _train_depth_batch(self, seed0):
+        """what the training step's march sees at the start of training: depth = 100 x the output of a freshly
+        initialised RelightNet on the synthetic training images (rough, little for the bounds to skip), its predicted
+        light / ambient / albedo, the batch's fill masks; normals from depth in the epilogue, argmin variant."""
+        from geomconsistentfr_amd.relightnet import RelightNet
+        from geomconsistentfr_amd.train import synthetic_batch
+        torch.manual_seed(1234 + seed0)
+        model = RelightNet().float().to(self.dev)
+        batch = synthetic_batch(self.B, seed0, device=self.dev)
+        with torch.no_grad():
+            albedo, depth, SL = model.features(batch["images"], 0)
+        B = self.B
+        mask = self.R.mask_to_u8(batch["masks_fill"].reshape(B, 256, 256))
+        light = SL[:, 0, 0, 1:4].reshape(B, 3).float().contiguous()
+        amb = SL[:, 0, 0, 0].reshape(B).float().contiguous()
+        del model
+        return [depth.reshape(B, 256, 256).float().contiguous(), mask, albedo.float().contiguous(), None, light, amb]
 
-    def inputs_of(bt):
+    def _inputs_of(self, bt):
         dd, mm, al, nr, li, am = bt
-        return (dd, mm, li.reshape(B, Ll, 3).contiguous(), am.reshape(B, Ll).contiguous(), None if a.from_depth else nr, al)
+        return (dd, mm, li.reshape(self.B, self.L, 3).contiguous(), am.reshape(self.B, self.L).contiguous(),
+                None if self.from_depth else nr, al)
 
-    stream_inputs = [inputs_of(bt) for bt in batches]
-    plan_inputs = stream_inputs[0]
+    def _new_plan(self):
+        return self.R.RenderFwdPlan(self.B, self.L, self.size, self.size, self.prm, self.dev, want_argmin=self.want_argmin,
+                                    mask_batch=self.batches[0][1].shape[0], camera=self.cam if self.from_depth else None,
+                                    options=self.base_opt)
 
-    def new_plan():
-        return R.RenderFwdPlan(B, Ll, Hh, Ww, prm, dev, want_argmin=False, mask_batch=d_mask_u8.shape[0],
-                               camera=cam if a.from_depth else None, options=base_opt)
-
-    use_plans = not (a.eager or a.direct or a.unfused)
-    plans = [new_plan() for _ in range(n_streams)] if use_plans else None
-    use_graph, graph_error = use_plans and not a.no_graph, None
-    if use_graph:
-        try:
-            for p_, inp in zip(plans, stream_inputs):
-                p_.capture(*inp)
-        except Exception as e:      # a runtime that cannot capture: same kernels, issued call by call
-            graph_error, use_graph = repr(e), False
-            torch.cuda.synchronize()
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
-
-    def eager_step(opt):
-        if a.direct or a.unfused:
+    # -- issue ---------------------------------------------------------------------------------
+    def eager_step(self, opt):
+        R, B, Ll, prm = self.R, self.B, self.L, self.prm
+        d_depth, d_mask, d_albedo, d_normals, d_light, d_amb = self.batches[0]
+        if self.mode in ("direct", "unfused"):
             _, pt = R.light_prep(d_light, prm)
             md, _ = R.shadow_min_distance(d_depth, d_mask, pt.reshape(B, Ll, 3), prm, want_argmin=False,
-                                          use_workspace=not a.direct, options=opt)
+                                          use_workspace=self.mode != "direct", options=opt)
             return R.shade(d_normals, d_depth, d_albedo, pt.reshape(B, Ll, 3), d_amb.reshape(B, Ll), md, prm)
         return R.render_fwd(d_depth, d_mask, d_light.reshape(B, Ll, 3), d_amb.reshape(B, Ll),
-                            None if a.from_depth else d_normals, d_albedo, prm, want_argmin=False,
-                            camera=cam if a.from_depth else None, options=opt)
+                            None if self.from_depth else d_normals, d_albedo, prm, want_argmin=self.want_argmin,
+                            camera=self.cam if self.from_depth else None, options=opt)
 
-    def issue(i):
-        """enqueue step i (no events): graph replay, plan call or eager call on stream i % S"""
-        with torch.cuda.stream(streams[i % n_streams]):
-            if use_graph:
-                plans[i % n_streams].replay()
-            elif use_plans:
-                plans[i % n_streams](*stream_inputs[i % n_streams])
+    def issue(self, i, n_streams):
+        """enqueue step i (no events): graph replay, plan call or eager call on stream i % n_streams"""
+        s = i % n_streams
+        with torch.cuda.stream(self.streams[s]):
+            if self.use_graph:
+                self.plans[s].replay()
+            elif self.use_plans:
+                self.plans[s](*self.inputs[s])
             else:
-                eager_step(base_opt)
+                self.eager_step(self.base_opt)
 
-    def timed_run(n_steps, stream_count):
-        """n_steps steps round-robin over the first `stream_count` streams, fenced on both sides"""
-        nonlocal n_streams
-        saved, n_streams = n_streams, stream_count
-        fence(dist)
+    def timed(self, n_steps, n_streams=None):
+        """n_steps steps round-robin over the first `n_streams` streams, fenced on both sides -> (seconds: max over
+        ranks, this rank's seconds, host issue seconds)"""
+        n_streams = n_streams or self.n_streams
+        self.rk.fence()
         t0 = time.perf_counter()
         for i in range(n_steps):
-            issue(i)
+            self.issue(i, n_streams)
         host = time.perf_counter() - t0
-        fence(dist)
+        self.rk.fence()
         dt = time.perf_counter() - t0
-        n_streams = saved
-        return max_over_ranks(dist, dev, dt), host
+        return self.rk.max_over_ranks(dt), dt, host
 
-    for i in range(a.warmup):
-        issue(i)
-    elapsed, host_issue = timed_run(a.steps, n_streams)
+    def timed_regions(self, n_steps, n_streams=None, est_ms=None):
+        """the fenced region of exactly `n_steps` steps, repeated when it is too short to be one trustworthy sample
+        (regions_needed); returns (median seconds, stats dict, own-rank median seconds, host issue seconds)"""
+        first, own0, host0 = self.timed(n_steps, n_streams)
+        n = regions_needed(n_steps, est_ms if est_ms is not None else 1e3 * first / n_steps)
+        if n == 1:
+            return first, {"n": 1, "seconds": [first]}, own0, host0
+        runs = [self.timed(n_steps, n_streams) for _ in range(n)]
+        secs = sorted(r[0] for r in runs)
+        med = float(np.median(secs))
+        own = float(np.median([r[1] for r in runs]))
+        host = float(np.median([r[2] for r in runs]))
+        return med, {"n": n, "median_ms_per_step": 1e3 * med / n_steps, "min_ms_per_step": 1e3 * secs[0] / n_steps,
+                     "max_ms_per_step": 1e3 * secs[-1] / n_steps, "first_region_ms_per_step": 1e3 * first / n_steps,
+                     "region_ms_median": 1e3 * med,
+                     "note": "a region of `steps` steps lasts < 200 ms: it was repeated %d times (each fenced by barrier + "
+                             "synchronize on both sides, max over ranks); value / ms_per_step are the MEDIAN region" % n}, own, host
 
-    # the dominant kernel's un-overlapped launch duration: plan calls (not graph replays) on ONE stream, each with
-    # its own event pair recorded by the library immediately before / after the march kernel on that stream
-    def kernel_launch_ms(n=100):
+    def kernel_launch_ms(self, ev, n=100):
+        """the march kernel's un-overlapped launch duration: plan calls (not graph replays) on ONE stream, each with
+        its own event pair recorded by the library immediately before / after the march kernel on that stream"""
         pairs = []
         torch.cuda.synchronize()
-        with torch.cuda.stream(streams[0]):
+        with torch.cuda.stream(self.streams[0]):
             for _ in range(n):
                 e0, e1 = ev.new(), ev.new()
-                opt = _lib.options(**knobs, event_start=e0, event_stop=e1)
+                opt = self._lib.options(**self.knobs, event_start=e0, event_stop=e1)
                 pairs.append((e0, e1, opt))
-                if use_plans:
-                    plans[0].options = opt
-                    plans[0](*plan_inputs)
-                    plans[0].options = base_opt
+                if self.use_plans:
+                    self.plans[0].options = opt
+                    self.plans[0](*self.inputs[0])
+                    self.plans[0].options = self.base_opt
                 else:
-                    eager_step(opt)
+                    self.eager_step(opt)
         torch.cuda.synchronize()
-        return float(np.mean([ev.elapsed_ms(e0, e1) for e0, e1, _ in pairs]))
+        ms = [ev.elapsed_ms(e0, e1) for e0, e1, _ in pairs]
+        for e0, e1, _ in pairs:
+            ev.destroy(e0)
+            ev.destroy(e1)
+        return float(np.mean(ms)), float(np.min(ms)), float(np.max(ms))
 
-    shadow_ms = kernel_launch_ms()
+    @property
+    def ray_steps_per_step(self):
+        return self.B * self.L * self.size * self.size * self.N
+
+
+SPEC_CYCLES = {"ADD_F32": 2, "MUL_F32": 2, "FMA_F32": 2, "INT32": 2, "OTHER": 2, "ADD_F64": 4, "MUL_F64": 4, "FMA_F64": 4,
+               "CVT": 4, "INT64": 4, "TRANS_F32": 8, "TRANS_F64": 16}
+
+
+def library_srchash():
+    try:
+        from geomconsistentfr_amd import build as hb
+        with open(hb.HASH_PATH) as f:
+            return f.read().strip()
+    except Exception:
+        return None
+
+
+def run_render(a, rk):
+    knobs = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)}
+    B = a.faces
+    mode = "direct" if a.direct else ("unfused" if a.unfused else ("eager" if a.eager else "plan"))
+    headline = (a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse" and a.depth_noise == 0.0
+                and a.data == "synthetic" and B == FACES_PER_GPU and not knobs and mode == "plan" and not a.from_depth
+                and not a.argmin)
+    rig = RenderRig(rk, B, a.size, a.lights, a.samples, a.mask, a.depth_noise, a.data, a.streams, a.from_depth,
+                    a.argmin, knobs, graph=not a.no_graph, mode=mode)
+    n_streams, world, rank = rig.n_streams, rk.world, rk.rank
+    ev = HipEvents()
+    for i in range(a.warmup):
+        rig.issue(i, n_streams)
+    elapsed, regions, own_elapsed, host_issue = rig.timed_regions(a.steps)
+    per_rank_s = rk.gather(own_elapsed)
+    shadow_ms, shadow_ms_min, shadow_ms_max = rig.kernel_launch_ms(ev)
     single_steps = max(50, min(a.steps, 1000))
-    single_elapsed, _ = timed_run(single_steps, 1) if n_streams > 1 else (elapsed * single_steps / a.steps, None)
-    ray_steps_per_step_rank = B * Ll * Hh * Ww * Nn
-    value = world * ray_steps_per_step_rank * a.steps / elapsed
+    if n_streams > 1:
+        single_elapsed, single_regions, _, _ = rig.timed_regions(single_steps, 1)
+    else:
+        single_elapsed, single_regions = elapsed * single_steps / a.steps, regions
+    rsps = rig.ray_steps_per_step
+    value = world * rsps * a.steps / elapsed
     single = {"ms_per_step": 1e3 * single_elapsed / single_steps,
-              "ray_steps_per_sec": world * ray_steps_per_step_rank * single_steps / single_elapsed,
+              "ray_steps_per_sec": world * rsps * single_steps / single_elapsed, "regions": single_regions,
               "note": "the same steps one at a time on ONE stream (hipGraph replay): the latency of one batch"}
+    layout = rk.describe()                                                    # (a collective: every rank calls it)
+
+    # secondary workloads, measured in the same run (1 rank only, headline only; short): the data the headline is NOT
+    worst = None
+    if headline and world == 1 and not a.no_worst_case:
+        worst = {}
+        for key, kw in (("ones_mask", dict(mask="ones")), ("depth_noise_400", dict(depth_noise=400.0)),
+                        ("ffhq", dict(data="ffhq")),
+                        ("train_depth_b32", dict(data="train_depth", B=32, from_depth=True, want_argmin=True, streams=1))):
+            try:
+                kw = dict(kw)
+                r2 = RenderRig(rk, kw.pop("B", B), streams=kw.pop("streams", a.streams), **kw)
+                for i in range(20):
+                    r2.issue(i, r2.n_streams)
+                steps2 = 200 if r2.B <= 8 else 60
+                sec, reg, _, _ = r2.timed_regions(steps2)
+                kms = r2.kernel_launch_ms(ev, 30)[0]
+                worst[key] = {"ray_steps_per_sec": r2.ray_steps_per_step * steps2 / sec, "ms_per_step": 1e3 * sec / steps2,
+                              "march_kernel_ms": kms, "faces_per_step": r2.B, "batches_in_flight": r2.n_streams,
+                              "steps": steps2, "regions": reg["n"]}
+                if r2.n_streams > 1:
+                    sec1, _, _, _ = r2.timed_regions(steps2, 1)
+                    worst[key]["single_stream_ray_steps_per_sec"] = r2.ray_steps_per_step * steps2 / sec1
+                del r2
+            except Exception as e:                                                # never lose the headline to a side measurement
+                worst[key] = {"error": repr(e)}
+        worst["note"] = ("same kernels, same run: all-ones masks (nothing is ever masked), uniform depth noise of amplitude 400 "
+                         "(what an untrained network emits: the depth bounds never separate ray and surface), the three "
+                         "checkpoint-derived FFHQ fixture faces tiled to the batch (--data ffhq), and the training step's "
+                         "march -- batch 32, argmin variant, normals fused, depth of a freshly initialised RelightNet")
     if rank != 0:
         return None
-    algo_bytes = ray_steps_per_step_rank * ALGO_BYTES_PER_RAY_STEP          # per launch (one rank)
+    algo_bytes = rsps * ALGO_BYTES_PER_RAY_STEP                              # per launch (one rank)
     achieved_gbs = algo_bytes / (shadow_ms * 1e-3) / 1e9
     pm = pmc_summary()
     hbm_line = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": algo_bytes, "measured_copy_GBs": measured_copy_bandwidth_gbs(dev),
+                "algorithmic_bytes_per_launch": algo_bytes, "measured_copy_GBs": measured_copy_bandwidth_gbs(rk.dev),
                 "note": "north_star's accounting: 17.4 algorithmic B per NOMINAL ray-step (SURVEY 8d) / launch duration; the "
                         "gathers are cache-served and most nominal ray-steps are provably skipped, so this is not a "
                         "fraction of a limit (it exceeds 1) -- the binding roofline is the VALU one"}
     fwd = pm.get("kernels", {}).get("fwd")
     if headline and fwd:
         roof = valu_roofline(fwd, shadow_ms)
+        roof["avg_launch_ms_min_max"] = [shadow_ms_min, shadow_ms_max]
+        # the same instruction mix priced at the guide's SPEC issue rates (MI355X_MICROARCH.md: SIMD-32, 2 cycles per wave64
+        # f32 / int op, 4 per f64 / cvt; transcendentals quarter rate) instead of the measured sustained costs
+        spec_cycles = sum(fwd["valu"]["by_class"].get(k, 0.0) * c for k, c in SPEC_CYCLES.items())
+        roof["frac_spec"] = spec_cycles / (N_SIMD * NOMINAL_HZ * shadow_ms * 1e-3)
+        roof["spec_issue_cycles_per_launch"] = spec_cycles
         roof["hbm"] = hbm_line
-        roof["kernel_ray_steps_per_sec"] = ray_steps_per_step_rank / (shadow_ms * 1e-3)
+        roof["kernel_ray_steps_per_sec"] = rsps / (shadow_ms * 1e-3)
         if "work" in fwd:
             roof["executed_fraction_of_nominal_ray_steps"] = fwd["work"]["executed_fraction_of_nominal"]
             roof["valu_wave_insts_per_executed_wave_step"] = fwd["work"]["valu_wave_insts_per_executed_wave_step"]
@@ -443,25 +674,36 @@ def run_render(a, rank, world, dev, dist):
             roof["l1_frac_of_peak_under_rocprofv3"] = fwd["l1"]["frac"]
         # the same mix against the overlapped rate: what the chip's VALU does when `streams` launches share it
         roof["frac_at_throughput"] = fwd["valu"]["issue_cycles_per_launch"] / (N_SIMD * NOMINAL_HZ * elapsed / a.steps)
+        roof["frac_spec_at_throughput"] = spec_cycles / (N_SIMD * NOMINAL_HZ * elapsed / a.steps)
+        # instruction counts / traffic come from the committed PMC passes (rocprofv3 cannot run inside the timed run):
+        # they are only valid for the library they were collected on
+        lib_hash, pmc_hash = library_srchash(), pm.get("library_srchash")
+        roof["pmc_library_srchash"], roof["library_srchash"] = pmc_hash, lib_hash
+        roof["stale"] = (pmc_hash is None) or (lib_hash is None) or (pmc_hash != lib_hash)
     else:       # no PMC mix for this workload / kernel selection: HBM accounting only
-        roof = dict(hbm_line, kernel="shadow_fwd_quad_kernel" if not a.direct else "shadow_fwd_kernel",
-                    avg_launch_ms=shadow_ms, traffic=None,
-                    kernel_ray_steps_per_sec=ray_steps_per_step_rank / (shadow_ms * 1e-3))
+        roof = dict(hbm_line, kernel="shadow_fwd_quad_kernel" if mode != "direct" else "shadow_fwd_kernel",
+                    avg_launch_ms=shadow_ms, traffic=None, kernel_ray_steps_per_sec=rsps / (shadow_ms * 1e-3))
+    desc = ("batch=%d %s 256x256 faces per GPU, 1 light each, 160 march steps, forward-only shadow+shade; %d batch(es) in flight"
+            % (B, "synthetic" if a.data == "synthetic" else "FFHQ-fixture", n_streams))
     out = {
-        "metric": "ray_steps_per_sec", "value": value, "unit": "ray-steps/s", "n_gpus": world,
+        "metric": "ray_steps_per_sec", "value": value, "unit": "ray-steps/s", **{k: layout[k] for k in ("n_gpus", "rccl_ranks")},
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+f32", "data": "synthetic",
-        "config": {"workload": ("BASELINE configs[1]: batch=%d synthetic 256x256 faces per GPU, 1 light each, 160 march "
-                                "steps, forward-only shadow+shade; %d batch(es) in flight" % (B, n_streams)) if headline else
-                               ("non-headline: batch=%d synthetic %dx%d faces per GPU, %d light(s) each, %d march steps, mask=%s, "
-                                "depth noise %g, knobs %s, forward-only shadow+shade; %d batch(es) in flight"
-                                % (B, Hh, Ww, Ll, Nn, a.mask, a.depth_noise, knobs or "default", n_streams)),
-                   "faces_per_gpu": B, "H": Hh, "W": Ww, "lights_per_face": Ll, "n_samples": Nn,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+f32",
+        "data": "synthetic" if a.data != "ffhq" else "ffhq-fixtures (3 checkpoint-derived faces tiled)",
+        "config": {"workload": ("BASELINE configs[1]: " + desc) if headline else
+                               ("non-headline: batch=%d %s %dx%d faces per GPU, %d light(s) each, %d march steps, mask=%s, "
+                                "depth noise %g, knobs %s, %s%sforward-only shadow+shade; %d batch(es) in flight"
+                                % (B, a.data, a.size, a.size, a.lights, a.samples, a.mask, a.depth_noise, knobs or "default",
+                                   "argmin variant, " if a.argmin else "", "normals fused, " if a.from_depth else "", n_streams)),
+                   "faces_per_gpu": B, "H": a.size, "W": a.size, "lights_per_face": a.lights, "n_samples": a.samples,
                    "parallelism": "dp%d" % world, "hip_streams": n_streams, "batches_in_flight": n_streams,
                    "distinct_face_batches": n_streams,
-                   "host_path": ("RenderFwdPlan, hipGraph replay" if use_graph else "RenderFwdPlan (preallocated outputs)")
-                   if use_plans else "render_fwd (eager)"},
-        "faces_per_sec": world * B * Ll * a.steps / elapsed,
+                   "host_path": ("RenderFwdPlan, hipGraph replay" if rig.use_graph else "RenderFwdPlan (preallocated outputs)")
+                   if rig.use_plans else "render_fwd (eager)"},
+        "process_layout": layout,
+        "per_rank": [{"rank": r, "seconds": s, "ray_steps_per_sec": rsps * a.steps / s} for r, s in enumerate(per_rank_s)],
+        "regions": regions,
+        "faces_per_sec": world * B * a.lights * a.steps / elapsed,
         "host_issue_ms_per_step": 1e3 * host_issue / a.steps,
         "ray_steps_per_sec_per_gpu": value / world,
         "single_stream": single,
@@ -472,8 +714,10 @@ def run_render(a, rank, world, dev, dist):
         "throughput_in_flight": {"faces_in_flight_per_gpu": B * n_streams, "ray_steps_per_sec": value},
         "roofline": roof,
     }
-    if graph_error:
-        out["config"]["graph_capture_failed"] = graph_error
+    if worst is not None:
+        out["worst_case"] = worst
+    if rig.graph_error:
+        out["config"]["graph_capture_failed"] = rig.graph_error
     if world == 1 and not a.no_cpu_baseline and headline:
         out["cpu_baseline"] = cpu_baseline()
         out["cpu_baseline_c_openmp"] = cpu_baseline_c()
@@ -483,7 +727,8 @@ def run_render(a, rank, world, dev, dist):
 # ------------------------------------------------------------------------------------------------
 # workload "train": BASELINE configs[2] (1 GPU) / configs[3] (8 GPUs, DDP over RCCL)
 # ------------------------------------------------------------------------------------------------
-def run_train(a, rank, world, dev, dist):
+def run_train(a, rk):
+    rank, world, dev, dist = rk.rank, rk.world, rk.dev, rk.dist
     from geomconsistentfr_amd import _lib
     from geomconsistentfr_amd import block as R
     from geomconsistentfr_amd.train import TrainConfig, Trainer, synthetic_batch
@@ -495,12 +740,15 @@ def run_train(a, rank, world, dev, dist):
     epoch = 200                                                               # every epoch-gated skip on (T8:245-283)
     for j in range(max(a.warmup, 6)):                                        # MIOpen find mode tunes on first use
         tr.step(batch, epoch, j, log=False)
-    fence(dist)
+    rk.fence()
     t0 = time.perf_counter()
     for j in range(a.steps):
         tr.step(batch, epoch, j, log=False)                                  # D step every 5th (T8:624), G step always
-    fence(dist)
-    elapsed = max_over_ranks(dist, dev, time.perf_counter() - t0)
+    rk.fence()
+    own_elapsed = time.perf_counter() - t0
+    elapsed = rk.max_over_ranks(own_elapsed)
+    per_rank_s = rk.gather(own_elapsed)
+    layout = rk.describe()
 
     # the render block's own kernels on this batch, measured live on the current stream: forward (prepass + march with
     # fused normals + shading, argmin variant) and the fused backward, from the tensors of a real step's forward
@@ -563,8 +811,10 @@ def run_train(a, rank, world, dev, dist):
     #  depth noise 2 -- not of this step's masked gradient and untrained-network depth; profiles/pmc_summary.json has
     #  them with their own launch times: backward 0.40, training march 0.66 of the VALU issue capacity)
     return {
-        "metric": "ray_steps_per_sec", "value": value, "unit": "ray-steps/s", "n_gpus": world, "steps": a.steps,
-        "warmup": max(a.warmup, 6), "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+        "metric": "ray_steps_per_sec", "value": value, "unit": "ray-steps/s", "n_gpus": world,
+        "rccl_ranks": layout["rccl_ranks"], "process_layout": layout,
+        "per_rank": [{"rank": r, "seconds": s_, "faces_per_sec": B * a.steps / s_} for r, s_ in enumerate(per_rank_s)],
+        "steps": a.steps, "warmup": max(a.warmup, 6), "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 network (MIOpen) + f64/f32 render block", "data": "synthetic",
         "config": {"workload": "BASELINE configs[%d]: batch=%d per GPU, full training step (RelightNet forward with the fused HIP "
                                "render block, PatchGAN step every 5th iteration, seven losses, backward through the fused HIP "
@@ -581,20 +831,40 @@ def run_train(a, rank, world, dev, dist):
     }
 
 
+def run_dry(a, rk):
+    """--dry-run: the process layout only (rendezvous, one collective, the JSON line) -- what a CPU-only container can
+    check of `bench.py --gpus N` (tests/test_bench_launch.py); no kernels, no numbers."""
+    layout = rk.describe()
+    per_rank = rk.gather(rk.rank)
+    if rk.rank != 0:
+        return None
+    return {"dry_run": True, "metric": "ray_steps_per_sec", "value": None, "unit": "ray-steps/s", **layout,
+            "ranks_seen": per_rank, "workload": a.workload}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks = GPUs of this node; started without torch.distributed.run, bench.py spawns the N ranks itself")
     ap.add_argument("--steps", type=int, default=None, help="default: 3000 (render), 20 (train)")
     ap.add_argument("--warmup", type=int, default=None, help="default: 50 (render), 6 (train)")
     ap.add_argument("--workload", choices=["render", "train"], default="render",
                     help="render = BASELINE configs[1] (batch 8, forward); train = configs[2]/[3] (batch 32, full step)")
     ap.add_argument("--faces", type=int, default=FACES_PER_GPU, help="faces per GPU per step (configs[1]: 8; train: 32)")
+    ap.add_argument("--data", choices=["synthetic", "ffhq", "train_depth"], default="synthetic",
+                    help="ffhq = the three checkpoint-derived FFHQ fixture faces (tests/golden/inputs.npz) tiled to the batch; "
+                         "train_depth = depth / light / albedo of a freshly initialised RelightNet (use with --from-depth --argmin)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-worst-case", action="store_true", help="skip the secondary workloads of the headline line")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="allow more ranks than GPUs (ranks share GPUs, collectives over gloo): rehearses the launch path")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous + one collective + JSON only (runs without a GPU)")
     ap.add_argument("--direct", action="store_true", help="A/B: direct-gather kernel (no workspace prepass)")
     ap.add_argument("--unfused", action="store_true", help="A/B: three separate entry points instead of gcfr_render_fwd")
     ap.add_argument("--from-depth", action="store_true",
                     help="also compute the normals (T8:353-354) inside the march epilogue instead of reading them "
                          "(SURVEY 8d's 17.4 B/ray-step accounting counts normals as a 12 B/pixel input, the default)")
+    ap.add_argument("--argmin", action="store_true", help="the training-time march (argmin tracked, 5 waves/SIMD)")
     ap.add_argument("--streams", type=int, default=4,
                     help="batches in flight: successive steps go round-robin to this many HIP streams, one RenderFwdPlan (own "
                          "outputs and workspace) per stream.  One launch cannot fill the chip to its end -- its duration is "
@@ -621,12 +891,15 @@ def main():
         a.steps = 3000 if a.workload == "render" else 20
     if a.warmup is None:
         a.warmup = 50 if a.workload == "render" else 6
-    rank, world, dev, dist = setup_distributed(a)
-    out = (run_render if a.workload == "render" else run_train)(a, rank, world, dev, dist)
-    if rank == 0:
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))                     # this process becomes the launcher of N ranks
+    rk = Ranks(a)
+    if rk.world != a.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (a.gpus, rk.world))
+    out = run_dry(a, rk) if a.dry_run else (run_render if a.workload == "render" else run_train)(a, rk)
+    if rk.rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    rk.close()
 
 
 if __name__ == "__main__":

@@ -15,6 +15,7 @@ from . import build as _build
 _LIB = None
 
 GCFR_OK = 0
+ABI_VERSION = 3      # include/gcfr.h GCFR_ABI_VERSION this binding was written against
 _ERRORS = {-1: "GCFR_ERR_INVALID_ARGUMENT", -2: "GCFR_ERR_LAUNCH"}
 
 _p, _i, _f, _d = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_double
@@ -54,6 +55,7 @@ def opt_ref(o):
 
 _SIGNATURES = {
     "gcfr_version": (ctypes.c_char_p, []),
+    "gcfr_abi_version": (_i, []),
     "gcfr_sample_table": (_i, [_d, _d, _i, _p]),
     "gcfr_light_prep": (_i, [_p, _i, _i, _f, _f, _p, _p, _p]),
     "gcfr_shadow_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i]),
@@ -71,7 +73,7 @@ _SIGNATURES = {
     "gcfr_render_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _d, _d, _d, _d, _f, _i, _f, _p, _p, _p, _p, _p,
                              _p, _p, _p, _p, _p]),
     "gcfr_light_prep_bwd": (_i, [_p, _i, _i, _f, _f, _p, _p, _p, _p]),
-    "gcfr_inference_images_u8": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "gcfr_inference_images_u8": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p]),
     "gcfr_fix_border_u8": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
 }
 
@@ -106,7 +108,20 @@ def load():
                 if not os.path.exists(path):
                     raise GcfrError("libgcfr_hip.so is not built (%s) and there is no CPU fallback: run "
                                     "`python -c 'import __graft_entry__ as g; g.build()'`" % e)
+                import warnings
+                warnings.warn("libgcfr_hip.so is older than its sources and could not be rebuilt (%s): loading the stale "
+                              "library (its ABI revision is checked below)" % e, RuntimeWarning)
     L = ctypes.CDLL(path)
+    # ABI revision first: a stale library exports every symbol by name, and would be called with shifted arguments
+    try:
+        L.gcfr_abi_version.restype = _i
+        L.gcfr_abi_version.argtypes = []
+        have = int(L.gcfr_abi_version())
+    except AttributeError:
+        have = None
+    if have != ABI_VERSION:
+        raise GcfrError("%s implements ABI revision %s, this binding needs %d (include/gcfr.h GCFR_ABI_VERSION): rebuild "
+                        "with `python -c 'import __graft_entry__ as g; g.build()'`" % (path, have, ABI_VERSION))
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError here = the library does not export the declared ABI
         fn.restype = res

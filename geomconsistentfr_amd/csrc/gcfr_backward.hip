@@ -638,8 +638,15 @@ __attribute__((amdgpu_waves_per_eu(GCFR_BWD1_WAVES_PER_EU, GCFR_BWD1_WAVES_PER_E
     // of their own.
     {
         const int lane = threadIdx.x & 63;
-        const int kx = corners.idx[1] - corners.idx[0], ky = (corners.idx[2] != corners.idx[0]) ? 1 : 0;
-        const int key = (live && have_corners) ? (corners.idx[0] | (kx << 28) | (ky << 29)) : (-1 - lane);
+        // Run identity: idx[0] plus three FLAGS that fix the other corners given idx[0] -- right neighbour differs, it is the
+        // wrapped column (idx[1] < idx[0]: fx = -1 -> W-1, gx = 0; T8:488-491), lower neighbour differs (fy = -1 wraps the
+        // same way, and then gy = 0 is implied by idx[0]'s row).  Round 2 packed the DIFFERENCE idx[1] - idx[0] into the key
+        // as if it were 0 or 1: on the wrapped column it is -(W-1), which set the sign bit for W % 16 in {2,4,6,8} and
+        // dropped the run's atomics (advisor, r02).  H, W <= 4096 (checked by the entry point), so idx[0] < 2^24.
+        // (bit 31 stays clear: key >= 0 <=> the lane has a sample)
+        const int kx = corners.idx[1] - corners.idx[0];
+        const int flags = ((kx != 0) ? (1 << 28) : 0) | ((kx < 0) ? (1 << 30) : 0) | ((corners.idx[2] != corners.idx[0]) ? (1 << 29) : 0);
+        const int key = (live && have_corners) ? (corners.idx[0] | flags) : (-1 - lane);   // lanes without a sample: unique, never equal
         const int key_prev = __builtin_amdgcn_update_dpp(0, key, 0x111, 0xf, 0xf, true);  // row_shr:1
         int head = ((lane & 7) == 0) || (key_prev != key);
         float v0 = corners.val[0], v1 = corners.val[1], v2 = corners.val[2], v3 = corners.val[3];

@@ -7,9 +7,16 @@
 // (the reference bounces every tensor through host numpy first).  No MFMA, no LDS (the 7x7 box sum and the 3x3
 // median read neighbours through L1: 49 + 27 cached byte loads on the ~3 % of pixels that form the mask's border).
 //
-// Arithmetic follows the scripts' numpy expressions op for op, because a half-way case decides a byte:
-//   255.0*rendered            f32 * python float -> f32 (numpy keeps the array's dtype)
+// Arithmetic follows the scripts' numpy expressions op for op with the dtypes the REFERENCE holds, because a half-way
+// case decides a byte (pinned to the reference's own main(): tests/golden/slt_main_*.npz, oracle/make_golden_slt_main.py):
+//   255.0*rendered / albedo   f32 * python float -> f32 (numpy keeps the array's dtype)
 //   (...)*mask_3_channels     f32 * f64 -> f64   (np.zeros((H,W,3)) is f64, S1:602)
+//   final_shading, normals    f64 in the reference (promotion from the f64 camera matrix): the device holds them as f32
+//                             and they are widened BEFORE the arithmetic, so 255.0*x*mask runs in f64 as in the scripts
+//   the mask                  mask_f32 = 0: f64, a numpy f64 array / 255.0 (S1:580, S8:569-578);
+//                             mask_f32 = 1: f32, a torch uint8 tensor / 255.0 (SLT:540) -- the 3-channel mask is still an
+//                             f64 array holding those f32 values, but the single-channel products of f32 maps (shadow
+//                             mask SLT:575, depth map SLT:577) then stay f32
 //   training_images*255.0     f64 (imread / 255.0 is f64, S1:513-516); here the image arrives as f32 and is widened
 //   cv2.imwrite(float image)  saturate_cast<uchar>(cvRound(v)): round half to even, clip to [0, 255]
 // Channel order: the scripts flip to BGR only because cv2 writes BGR; the bytes produced here are RGB, HWC -- what
@@ -38,7 +45,7 @@ struct ImagesArgs {
     const uint8_t *mask;      // (MB,H,W) u8 skin mask as stored on disk; mask/255.0 is an f64 division (S1:580)
     uint8_t *out_rendered;    // (B,H,W,3)
     uint8_t *out_shadow, *out_albedo, *out_depth, *out_shading, *out_normals;  // (B,H,W) / (B,H,W,3) or null
-    int32_t mask_batch, H, W;
+    int32_t mask_batch, H, W, mask_f32;
 };
 
 __global__ __launch_bounds__(256) void inference_images_kernel(ImagesArgs a)
@@ -48,7 +55,9 @@ __global__ __launch_bounds__(256) void inference_images_kernel(ImagesArgs a)
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P)
         return;
-    const double m = (double)a.mask[(size_t)(a.mask_batch == 1 ? 0 : b) * P + p] / 255.0;
+    const uint8_t mk = a.mask[(size_t)(a.mask_batch == 1 ? 0 : b) * P + p];
+    const float mf = (float)mk / 255.0f;                                   // SLT:540 (torch: u8 -> f32, IEEE division)
+    const double m = a.mask_f32 ? (double)mf : (double)mk / 255.0;         // value of mask_3_channels (an f64 array)
     const size_t hwc = ((size_t)b * P + p) * 3;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
@@ -58,18 +67,21 @@ __global__ __launch_bounds__(256) void inference_images_kernel(ImagesArgs a)
         a.out_rendered[hwc + ch] = quantise_u8(m > 0.0 ? paste : keep);
         if (a.out_albedo)   // 255.0*albedo*mask3                                   S8:605
             a.out_albedo[hwc + ch] = quantise_u8((double)(255.0f * a.albedo[((size_t)b * 3 + ch) * P + p]) * m);
-        if (a.out_normals)  // (255.0*(n + 1.0)/2.0)*mask3                          S8:594, 608
-            a.out_normals[hwc + ch] = quantise_u8((double)((255.0f * (a.normals[((size_t)b * 3 + ch) * P + p] + 1.0f)) / 2.0f) * m);
+        if (a.out_normals)  // (255.0*(n + 1.0)/2.0)*mask3, n f64 in the reference  S8:594, 608
+            a.out_normals[hwc + ch] = quantise_u8(((255.0 * ((double)a.normals[((size_t)b * 3 + ch) * P + p] + 1.0)) / 2.0) * m);
     }
     const size_t o = (size_t)b * P + p;
-    if (a.out_shadow)   // 255.0*shadow_mask_weights*mask                           S8:604
-        a.out_shadow[o] = quantise_u8((double)(255.0f * a.shadow_w[o]) * m);
-    if (a.out_shading)  // 255.0*final_shading*mask                                 S8:607
-        a.out_shading[o] = quantise_u8((double)(255.0f * a.shading[o]) * m);
+    if (a.out_shadow) {  // 255.0*shadow_mask_weights*mask (single-channel mask in ITS dtype)   S8:604 / SLT:575
+        const float s255 = 255.0f * a.shadow_w[o];
+        a.out_shadow[o] = quantise_u8(a.mask_f32 ? (double)(s255 * mf) : (double)s255 * m);
+    }
+    if (a.out_shading)  // 255.0*final_shading*mask, final_shading f64 in the reference          S8:607
+        a.out_shading[o] = quantise_u8((255.0 * (double)a.shading[o]) * m);
     if (a.out_depth) {  // depth = -depth; (depth - amin)/(amax - amin) in f32; 255.0*depth*mask   S8:588-590, 606
         const float lo = a.depth_range[0], hi = a.depth_range[1];
         const float d = ((-a.depth[o]) - lo) / (hi - lo);
-        a.out_depth[o] = quantise_u8((double)(255.0f * d) * m);
+        const float d255 = 255.0f * d;
+        a.out_depth[o] = quantise_u8(a.mask_f32 ? (double)(d255 * mf) : (double)d255 * m);
     }
 }
 
@@ -137,16 +149,17 @@ extern "C" int gcfr_inference_images_u8(const float *input_hwc, const float *ren
                                         const float *depth_range, const float *shadow_w, const float *final_shading,
                                         const float *normals, const uint8_t *mask, int32_t mask_batch, int32_t B, int32_t H,
                                         int32_t W, uint8_t *out_rendered, uint8_t *out_shadow, uint8_t *out_albedo,
-                                        uint8_t *out_depth, uint8_t *out_shading, uint8_t *out_normals, void *stream)
+                                        uint8_t *out_depth, uint8_t *out_shading, uint8_t *out_normals, int32_t mask_f32,
+                                        void *stream)
 {
     if (!input_hwc || !rendered || !mask || !out_rendered || B <= 0 || H <= 0 || W <= 0 || B > 65535 ||
-        (mask_batch != 1 && mask_batch != B))
+        (mask_batch != 1 && mask_batch != B) || (mask_f32 != 0 && mask_f32 != 1))
         return GCFR_ERR_INVALID_ARGUMENT;
     if ((out_shadow && !shadow_w) || (out_albedo && !albedo) || (out_shading && !final_shading) || (out_normals && !normals) ||
         (out_depth && (!depth || !depth_range)))
         return GCFR_ERR_INVALID_ARGUMENT;
     ImagesArgs a{input_hwc, rendered, albedo, depth, depth_range, shadow_w, final_shading, normals, mask,
-                 out_rendered, out_shadow, out_albedo, out_depth, out_shading, out_normals, mask_batch, H, W};
+                 out_rendered, out_shadow, out_albedo, out_depth, out_shading, out_normals, mask_batch, H, W, mask_f32};
     const size_t P = (size_t)H * W;
     hipLaunchKernelGGL(inference_images_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0,
                        (hipStream_t)stream, a);

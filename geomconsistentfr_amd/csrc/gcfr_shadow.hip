@@ -2145,14 +2145,19 @@ static inline int launch_status()
 extern "C" const char *gcfr_version(void)
 {
 #if defined(GCFR_COUNTERS) && defined(GCFR_EXPERIMENTAL_SCHEDULES)
-    return "gcfr-hip 0.2.0 gfx950 +counters +schedules";
+    return "gcfr-hip 0.3.0 gfx950 +counters +schedules";
 #elif defined(GCFR_COUNTERS)
-    return "gcfr-hip 0.2.0 gfx950 +counters";
+    return "gcfr-hip 0.3.0 gfx950 +counters";
 #elif defined(GCFR_EXPERIMENTAL_SCHEDULES)
-    return "gcfr-hip 0.2.0 gfx950 +schedules";
+    return "gcfr-hip 0.3.0 gfx950 +schedules";
 #else
-    return "gcfr-hip 0.2.0 gfx950";
+    return "gcfr-hip 0.3.0 gfx950";
 #endif
+}
+
+extern "C" int32_t gcfr_abi_version(void)
+{
+    return GCFR_ABI_VERSION;
 }
 
 extern "C" int gcfr_sample_table(double t0, double dt, int32_t n, double *out_host)

@@ -65,21 +65,27 @@ def relight_batch(model: RelightNetSingleImage, images, masks_u8, lights, ambien
 
 @torch.no_grad()
 def relight_single_image(model: RelightNetSingleImage, image, mask_u8, light, ambient: float = 0.5,
-                         focal: float = 1570.0, device="cuda") -> np.ndarray:
+                         focal: float = 1570.0, device="cuda", fix_border: bool = False,
+                         composite_mask_u8=None) -> np.ndarray:
     """S1:569-620 for one image: returns the composite (H,W,3) uint8 RGB (rendered face pasted into the input),
     composited and quantised on the device (gcfr_inference_images_u8); `fix_border=True` also applies
-    fix_border_artifacts_CVPR2022.m there."""
-    return relight_images(model, image, mask_u8, np.asarray(light, np.float32)[None], ambient, focal, device)[0]
+    fix_border_artifacts_CVPR2022.m there.  `composite_mask_u8`: see relight_images."""
+    return relight_images(model, image, mask_u8, np.asarray(light, np.float32)[None], ambient, focal, device,
+                          fix_border=fix_border, composite_mask_u8=composite_mask_u8)[0]
 
 
 @torch.no_grad()
 def relight_images(model: RelightNetSingleImage, images, mask_u8, lights, ambient: float = 0.5, focal: float = 1570.0,
-                   device="cuda", fix_border: bool = False) -> np.ndarray:
+                   device="cuda", fix_border: bool = False, composite_mask_u8=None) -> np.ndarray:
     """Batch form of S1:569-620 (+ the MATLAB border fix): (B,H,W,3) uint8 RGB composites.  Forward, compositing,
-    quantisation and the border fix all run on the device; one device-to-host copy of B*H*W*3 bytes at the end."""
+    quantisation and the border fix all run on the device; one device-to-host copy of B*H*W*3 bytes at the end.
+    The script feeds the MODEL `curr_mask` (S1:586-588) and composites with the fill-nose-and-mouth mask
+    (`curr_mask_fill_nose_3_channels`, S1:606-618); both are read from the same file in the shipped script (S1:564-567), so
+    `composite_mask_u8` defaults to `mask_u8` -- pass the second mask when they differ."""
     x = _as_batch(images).to(device)
     out = relight_batch(model, x, mask_u8, lights, ambient, focal, device)
-    mask = torch.as_tensor(np.asarray(mask_u8), dtype=torch.uint8, device=device)
+    mask = torch.as_tensor(np.asarray(mask_u8 if composite_mask_u8 is None else composite_mask_u8), dtype=torch.uint8,
+                           device=device)
     imgs = pp.inference_images_device(x, out[5], mask)["rendered_image"]
     if fix_border:
         imgs = pp.fix_border_artifacts_device(imgs, mask)
@@ -103,7 +109,7 @@ def lighting_transfer(model: RelightNetLightingTransfer, input_image, reference_
     out = model(xin, 200, K, mask, est_light.reshape(1, 3, 1, 1).float(), est_amb.reshape(1, 1, 1).float())
     m_u8 = torch.as_tensor(np.asarray(mask_u8), dtype=torch.uint8, device=device)
     dev_imgs = pp.inference_images_device(xin, out[5], m_u8, albedo=out[0], depth=out[1], shadow_mask_weights=out[2],
-                                          final_shading=out[8], surface_normals=out[9])
+                                          final_shading=out[8], surface_normals=out[9], mask_f32=True)      # SLT:540
     imgs = {k: v[0].cpu().numpy() for k, v in dev_imgs.items()}                # uint8, what SLT:574-579 writes
     imgs["estimated_light"] = est_light.reshape(3).cpu().numpy()
     imgs["estimated_ambient"] = est_amb.reshape(1).cpu().numpy()

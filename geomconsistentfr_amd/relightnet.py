@@ -95,6 +95,26 @@ class _Hourglass(nn.Module):
             x = _lrelu(self._cb("%s_c2_%d" % (br, j), x))
         return getattr(self, "conv_%s_c2_o" % br)(x)
 
+    _pinned_camera = None
+
+    def pin_camera(self, intrinsic_matrix):
+        """Fix the camera for every later forward from a HOST copy of the matrix (None = unpin).
+        The reference's call site uploads a fresh `intrinsic_matrix.cuda()` every step (T8:618, S1:588); a fresh device
+        tensor cannot be recognised without reading it back -- one device-to-host synchronisation per step.  A drop-in
+        that keeps the call site untouched pins the (constant, T8:571-577) matrix once and the per-step argument is then
+        ignored; a call site that can change passes the host tensor itself (no `.cuda()`), which is read without a sync."""
+        if intrinsic_matrix is None:
+            self._pinned_camera = None
+            return self
+        K = intrinsic_matrix.detach().to("cpu", torch.float64)
+        if K.shape[0] != 1 and not bool((K == K[:1]).all()):
+            raise ValueError("pin_camera needs one camera matrix for the whole batch")
+        self._pinned_camera = K[:1].clone()
+        return self
+
+    def _camera(self, intrinsic_matrix):
+        return self._pinned_camera if self._pinned_camera is not None else intrinsic_matrix
+
     def features(self, img_nhwc, epoch):
         """-> (albedo (B,3,H,W) in (0,1), depth (B,1,H,W) x100, SL_lin2 (B,1,1,4)).  T8:197-350."""
         img = img_nhwc.permute(0, 3, 1, 2)
@@ -132,7 +152,7 @@ class RelightNet(_Hourglass):
     def forward(self, img, epoch, intrinsic_matrix, masks):
         albedo, depth, SL = self.features(img, epoch)
         B = depth.shape[0]
-        r = render_from_depth(depth, albedo, SL[:, 0, 0, 1:4], SL[:, 0, 0, 0], intrinsic_matrix, self.normal_z_offset,
+        r = render_from_depth(depth, albedo, SL[:, 0, 0, 1:4], SL[:, 0, 0, 0], self._camera(intrinsic_matrix), self.normal_z_offset,
                               masks.reshape(B, masks.shape[1], masks.shape[2]), self.render_params)   # T8:353-522
         return (albedo, depth, r["shadow_mask_weights"], r["ambient_light"], r["full_shading"],
                 r["rendered_images"], r["unit_light_direction"], r["ambient_values"])   # T8:524
@@ -153,7 +173,7 @@ class RelightNetSingleImage(_Hourglass):
         albedo, depth, SL = self.features(img, epoch)
         B, _, H, W = depth.shape
         ambient = SL[:, 0, 0, 0] + self.ambient_offset                                  # S1:342
-        r = render_from_depth(depth, albedo, target_lighting.reshape(B, 3), ambient, intrinsic_matrix,
+        r = render_from_depth(depth, albedo, target_lighting.reshape(B, 3), ambient, self._camera(intrinsic_matrix),
                               self.normal_z_offset, mask.reshape(1, H, W), self.render_params)
         normals = r["surface_normals"]
         return (albedo, depth, r["shadow_mask_weights"], r["ambient_light"], r["full_shading"],
@@ -178,7 +198,7 @@ class RelightNetLightingTransfer(_Hourglass):
         est = torch.stack([est[:, 0], est[:, 1], torch.clamp_min(est[:, 2], self.estimate_z_min)], 1)
         est_unit = F.normalize(est, p=2, dim=1).reshape(B, 3, 1, 1)                     # SLT:329-335
         r = render_from_depth(depth, albedo, target_lighting.reshape(B, 3), target_ambient_values.reshape(B),
-                              intrinsic_matrix, self.normal_z_offset, mask.reshape(1, H, W), self.render_params)
+                              self._camera(intrinsic_matrix), self.normal_z_offset, mask.reshape(1, H, W), self.render_params)
         normals = r["surface_normals"]
         return (albedo, depth, r["shadow_mask_weights"], r["ambient_light"], r["full_shading"],
                 r["rendered_images"], r["unit_light_direction"], r["ambient_values"], r["final_shading"],

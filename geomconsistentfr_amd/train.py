@@ -154,7 +154,10 @@ class TrainConfig:
     miopen_find: bool = True    # torch.backends.cudnn.benchmark: MIOpen picks the fastest conv algorithm (+9 % step rate)
 
 
-def ddp_kwargs(cfg: "TrainConfig", device: torch.device, generator: bool) -> dict:
+LAST_GATED_EPOCH = 14      # T8:245, 258, 271, 283: the decoders' skip additions switch on after epochs 8 / 10 / 12 / 14
+
+
+def ddp_kwargs(cfg: "TrainConfig", device: torch.device, generator: bool, epoch: int = 0) -> dict:
     """DistributedDataParallel arguments of the two models.
     broadcast_buffers=False: BatchNorm running statistics stay per GPU (module docstring), and the discriminator
     runs two forwards (fake, real) before one backward -- DDP's per-forward buffer broadcast would overwrite BN
@@ -162,11 +165,13 @@ def ddp_kwargs(cfg: "TrainConfig", device: torch.device, generator: bool) -> dic
     find_unused_parameters=True for the generator: its skip convolutions are epoch-gated (relightnet._decode,
     T8:245, 258, 271, 283: added only when epoch > 8 / 10 / 12 / 14).  The reference trains from epoch 0 (T8:592),
     where those branches run in forward but never reach the loss; without the flag DDP's reducer waits for their
-    gradients for ever and the SECOND step raises "Expected to have finished reduction in the prior iteration"."""
+    gradients for ever and the SECOND step raises "Expected to have finished reduction in the prior iteration".
+    Once epoch > LAST_GATED_EPOCH every parameter takes part in every step and the flag only costs a traversal of the
+    autograd graph per iteration: Trainer re-wraps the generator without it when training crosses that epoch."""
     kw = dict(device_ids=[device.index] if device.type == "cuda" else None, bucket_cap_mb=cfg.bucket_cap_mb,
               gradient_as_bucket_view=True, broadcast_buffers=False)
     if generator:
-        kw["find_unused_parameters"] = True
+        kw["find_unused_parameters"] = epoch <= LAST_GATED_EPOCH
     return kw
 
 
@@ -181,9 +186,10 @@ class Trainer:
         self.model = (model or RelightNet(cfg.shortcut)).float().to(self.device)
         self.patchgan = (patchgan or PatchGAN()).float().to(self.device)
         self.net, self.disc = self.model, self.patchgan
+        self.distributed, self._net_find_unused = distributed, None
         if distributed:
             from torch.nn.parallel import DistributedDataParallel as DDP
-            self.net = DDP(self.model, **ddp_kwargs(cfg, self.device, generator=True))
+            self._wrap_generator(0)
             self.disc = DDP(self.patchgan, **ddp_kwargs(cfg, self.device, generator=False))
         self.opt = torch.optim.Adam(self.model.parameters(), lr=cfg.lr)                  # T8:589
         self.opt_d = torch.optim.Adam(self.patchgan.parameters(), lr=cfg.lr)             # T8:590
@@ -193,8 +199,22 @@ class Trainer:
         K[:, 0, 2], K[:, 1, 2] = cfg.W / 2.0, cfg.H / 2.0
         self.K = K.to(self.device)
 
+    def _wrap_generator(self, epoch: int):
+        """(Re-)wrap the generator for `epoch`: find_unused_parameters only while some skip branch is still gated off
+        (epoch <= LAST_GATED_EPOCH).  The old wrapper is dropped first -- its reducer removes its autograd hooks when it
+        is destroyed -- and the new one broadcasts rank 0's parameters, which are already equal on every rank."""
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        kw = ddp_kwargs(self.cfg, self.device, generator=True, epoch=epoch)
+        if self._net_find_unused == kw["find_unused_parameters"]:
+            return
+        self.net = None                                                       # release the previous reducer's hooks
+        self.net = DDP(self.model, **kw)
+        self._net_find_unused = kw["find_unused_parameters"]
+
     def step(self, batch: Dict[str, torch.Tensor], epoch: int, j: int, log: bool = True) -> Dict[str, float]:
         """log=False skips the per-iteration .item() syncs the reference pays for its 11 prints (T8:657-669)."""
+        if self.distributed:
+            self._wrap_generator(epoch)
         img = batch["images"].permute(0, 3, 1, 2)
         m3 = batch["masks_fill"].permute(0, 3, 1, 2).repeat(1, 3, 1, 1)
         out = self.net(batch["images"], epoch, self.K, batch["masks_fill"])              # T8:618

@@ -40,6 +40,16 @@ typedef enum gcfr_status {
 const char *gcfr_version(void);
 
 /*
+ * ABI revision of THIS header.  It changes whenever an entry point's argument list or a struct layout changes
+ * (every symbol keeps its name, so a stale library would otherwise be called with shifted arguments).  A binding
+ * compares gcfr_abi_version() of the library it loaded with the GCFR_ABI_VERSION it was written against and refuses
+ * to proceed on a mismatch (geomconsistentfr_amd/_lib.py does).
+ *   3: round 3 -- gcfr_inference_images_u8 gained `mask_f32`; gcfr_abi_version itself; the metrics entry points.
+ */
+#define GCFR_ABI_VERSION 3
+int32_t gcfr_abi_version(void);
+
+/*
  * Per-call options of the forward entry points (HOST struct, read during the call only; NULL = defaults).
  * Nothing here changes a result bit: the knobs select among kernels / schedules that are bit-identical
  * (tests/test_gpu_parity.py asserts it for every combination), the hooks only observe.
@@ -270,15 +280,20 @@ int gcfr_light_prep_bwd(const float *light_raw, int32_t n, int32_t clamp_z, floa
  *   depth_range   DEVICE {lo, hi} f32      = min / max of -depth over the whole batch (S8:589-590)
  *   shadow_w, final_shading (B,H,W) f32 or NULL -> out_shadow, out_shading (B,H,W) = 255 x mask
  *   normals       (B,3,H,W) f32 or NULL    -> out_normals (B,H,W,3) = 255 (n + 1)/2 mask
- *   mask          (MB,H,W) u8               the skin mask as read from disk; the kernel forms the scripts' f64
- *                                          mask/255.0 (S1:580) itself; MB = 1 or B
- * Any out_* except out_rendered may be NULL.
+ *   mask          (MB,H,W) u8               the skin mask as read from disk; the kernel forms the scripts' mask/255.0
+ *                                          itself; MB = 1 or B
+ *   mask_f32      0: the mask is f64 as in test_relight_single_image.py:580 / S8:569-578 (numpy f64 array / 255.0);
+ *                 1: f32 as in test_relight_single_image_lighting_transfer.py:540 (torch uint8 tensor / 255.0), which
+ *                    keeps the shadow-mask and depth images' products in f32 (SLT:575, 577)
+ * final_shading and normals are f64 in the reference; they are widened to f64 before the arithmetic.
+ * Pinned to the reference's own main() (tests/golden/slt_main_*.npz).  Any out_* except out_rendered may be NULL.
  */
 int gcfr_inference_images_u8(const float *input_hwc, const float *rendered, const float *albedo, const float *depth,
                              const float *depth_range, const float *shadow_w, const float *final_shading,
                              const float *normals, const uint8_t *mask, int32_t mask_batch, int32_t B, int32_t H,
                              int32_t W, uint8_t *out_rendered, uint8_t *out_shadow, uint8_t *out_albedo,
-                             uint8_t *out_depth, uint8_t *out_shading, uint8_t *out_normals, void *stream);
+                             uint8_t *out_depth, uint8_t *out_shading, uint8_t *out_normals, int32_t mask_f32,
+                             void *stream);
 
 /*
  * fix_border_artifacts_CVPR2022.m:1-18: pixels on the border of the face mask (0 < 7x7 box sum of the rounded

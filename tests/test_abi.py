@@ -43,9 +43,10 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert L.gcfr_light_prep(None, 1, 1, 0.0, 4013.0, None, None, None) == -1
     assert L.gcfr_shade_fwd(None, None, None, None, None, None, 1, 1, 8, 8, 0.5, None, None, None, None, None) == -1
     # the inference image side: null planes, a diagnostic output without its input, mask batch neither 1 nor B, in-place border fix
-    assert L.gcfr_inference_images_u8(None, None, None, None, None, None, None, None, None, 1, 1, 8, 8, None, None, None, None, None, None, None) == -1
-    assert L.gcfr_inference_images_u8(16, 16, None, None, None, None, None, None, 16, 1, 1, 8, 8, 16, 16, None, None, None, None, None) == -1
-    assert L.gcfr_inference_images_u8(16, 16, None, None, None, None, None, None, 16, 2, 3, 8, 8, 16, None, None, None, None, None, None) == -1
+    assert L.gcfr_inference_images_u8(None, None, None, None, None, None, None, None, None, 1, 1, 8, 8, None, None, None, None, None, None, 0, None) == -1
+    assert L.gcfr_inference_images_u8(16, 16, None, None, None, None, None, None, 16, 1, 1, 8, 8, 16, 16, None, None, None, None, 0, None) == -1
+    assert L.gcfr_inference_images_u8(16, 16, None, None, None, None, None, None, 16, 2, 3, 8, 8, 16, None, None, None, None, None, 0, None) == -1
+    assert L.gcfr_inference_images_u8(16, 16, None, None, None, None, None, None, 16, 1, 1, 8, 8, 16, None, None, None, None, None, 2, None) == -1
     assert L.gcfr_fix_border_u8(16, 16, 1, 1, 8, 8, 16, None) == -1
 
 
@@ -90,5 +91,20 @@ def test_product_does_not_import_the_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
-                assert not re.search(r"^\s*(from|import)\s+(oracle|c_oracle|materialised|ref_shim)\b", src, re.M), f
+                assert not re.search(r"^\s*(from|import)\s+(oracle|c_oracle|materialised|ref_shim|postprocess_statements|normals_restatement)\b", src, re.M), f
                 assert "/root/reference" not in src, f
+
+
+def test_stale_library_abi_is_refused(monkeypatch):
+    """A library of another ABI revision exports the same symbol names; the binding must refuse it instead of calling it
+    with shifted arguments (round-2 advisor finding)."""
+    import pytest
+    from geomconsistentfr_amd import _lib
+    L = _lib.load()
+    assert L.gcfr_abi_version() == _lib.ABI_VERSION
+    header = open(os.path.join(ROOT, "include", "gcfr.h")).read()
+    assert int(re.search(r"#define GCFR_ABI_VERSION (\d+)", header).group(1)) == _lib.ABI_VERSION
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.GcfrError, match="ABI revision"):
+        _lib.load()

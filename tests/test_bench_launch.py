@@ -1,0 +1,48 @@
+"""bench.py's own process layout: `python bench.py --gpus N` must spawn its N ranks itself.
+
+CPU container: `--dry-run` takes the launcher path all the way to rank start-up -- self-launch under
+torch.distributed.run on 127.0.0.1, rendezvous, one SUM all-reduce (gloo here, RCCL on a GPU node), one JSON line from
+rank 0 -- and the real command must fail loudly (not hang, not fall back) when there is no GPU.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+@pytest.mark.parametrize("workload", ["render", "train"])
+def test_gpus2_self_launch_reaches_rank_startup_and_prints_one_json_line(workload):
+    p = _run(["--gpus", "2", "--dry-run", "--workload", workload])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["self_launched"] is True
+    assert d["ranks_seen"] == [0.0, 1.0]
+    assert d["workload"] == workload
+
+
+def test_single_rank_needs_no_launcher():
+    p = _run(["--dry-run"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["self_launched"] is False
+
+
+def test_without_a_gpu_the_real_command_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"])
+    assert p.returncode != 0
+    assert "needs a GPU" in (p.stderr + p.stdout)

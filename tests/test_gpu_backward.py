@@ -273,3 +273,43 @@ def test_fused_backward_multi_light_equals_sum_of_single_lights():
         np.testing.assert_allclose(g_amb[:, l].cpu().numpy(), am.grad.cpu().numpy(), rtol=1e-5)
     assert float((g_alb - sum_alb).abs().max()) <= 1e-5 * float(sum_alb.abs().max())
     assert float((g_depth - sum_depth).abs().max()) <= 1e-5 * float(sum_depth.abs().max())
+
+
+@pytest.mark.parametrize("Ws", [40, 72, 100, 24, 56, 34])
+def test_fused_backward_wrapped_column_runs_at_widths_not_multiple_of_16(Ws):
+    """Round-2 advisor finding: the fused kernel merged runs of lanes with equal corner addresses under a key that packed
+    idx[1] - idx[0] as if it were 0 or 1; a sample on column 0 wraps to column W-1 (T8:488-491), the difference is
+    -(W-1), and for W % 16 in {2,4,6,8} the sign bit dropped the whole run's depth atomics.  All-ones mask, light far to
+    the LEFT of the image (every column-0 pixel has dx = 0 -> samples on the wrapped column), shadow-only loss so the
+    corner atomics dominate; the three-kernel path (no run merging, pinned against the oracle) is the reference."""
+    from geomconsistentfr_amd import render
+    from geomconsistentfr_amd.block import render_from_depth
+    from geomconsistentfr_amd.normals import depth_to_normals
+    rng = np.random.default_rng(Ws)
+    B, Hs = 2, 48
+    r, c = np.mgrid[0:Hs, 0:Ws]
+    depth = np.stack([(10 * np.exp(-(((c - 8) / 9.0) ** 2 + ((r - 24) / 12.0) ** 2)) + 2 * rng.random((Hs, Ws))).astype(np.float32)
+                      for _ in range(B)])[:, None]
+    mask = np.ones((B, Hs, Ws), np.uint8)
+    albedo = rng.random((B, 3, Hs, Ws), dtype=np.float32)
+    light = np.array([[-0.95, 0.02, 0.3], [-0.8, -0.1, 0.59]], np.float32)
+    amb = np.array([0.45, 0.6], np.float32)
+    K = camera(600.0, Hs, Ws).to(dev())
+    Gw = torch.from_numpy(rng.standard_normal((B, Hs, Ws)).astype(np.float32)).to(dev())
+    grads, col0 = [], None
+    for fused in (True, False):
+        leaves = [_leaf(a) for a in (depth, albedo, light, amb)]
+        if fused:
+            o = render_from_depth(leaves[0], leaves[1], leaves[2], leaves[3], K, 900.0, torch.from_numpy(mask).to(dev()))
+        else:
+            n = depth_to_normals(leaves[0], K, z_offset=900.0)
+            o = render(leaves[0], leaves[1], leaves[2], leaves[3], n, torch.from_numpy(mask).to(dev()))
+        (o["shadow_mask_weights"] * Gw).sum().backward()
+        grads.append([l.grad.cpu().numpy() for l in leaves])
+    gd_f, gd_3 = grads[0][0][:, 0], grads[1][0][:, 0]
+    scale = np.abs(gd_3).max()
+    assert scale > 0
+    # the wrapped column really receives gradient in this set-up (otherwise the test pins nothing)
+    assert np.abs(gd_3[:, :, Ws - 1]).max() > 0 and np.abs(gd_3[:, :, 0]).max() > 0
+    assert np.abs(gd_f - gd_3).max() <= 2e-6 * scale, (np.abs(gd_f - gd_3).max(), scale)
+    np.testing.assert_allclose(grads[0][2], grads[1][2], rtol=1e-5, atol=1e-6 * np.abs(grads[1][2]).max())

@@ -1,9 +1,22 @@
-"""GPU: the inference-side byte kernels (csrc/gcfr_postprocess.hip) against the host statements of the same script
-lines (geomconsistentfr_amd/postprocess.py: composite_into_input, diagnostic_images, to_uint8, fix_border_artifacts),
-byte for byte -- half-way cases included -- and against scipy for the MATLAB border fix."""
+"""GPU: the inference-side byte kernels (csrc/gcfr_postprocess.hip)
+  (1) against the bytes the reference's OWN main() produced (tests/golden/slt_main_*.npz, SLT:516-579 run unmodified by
+      oracle/make_golden_slt_main.py): the kernel on the reference's model outputs, and the whole
+      inference.lighting_transfer() with the shipped checkpoint;
+  (2) against the oracle's numpy statements of the same script lines (oracle/postprocess_statements.py, themselves
+      bit-equal to that main(): tests/test_oracle_postprocess.py), byte for byte -- half-way cases included -- at other
+      shapes and in both mask modes, and against scipy for the MATLAB border fix."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import postprocess_statements as st  # noqa: E402  (checker only)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 pytestmark = pytest.mark.gpu
 
@@ -26,27 +39,87 @@ def _inputs(B, H, W, seed):
     return x, ren, alb, depth, w, fin, nrm, mask_u8
 
 
+def rgb(a):
+    if a.ndim == 3 and a.shape[2] == 3:
+        return a[..., ::-1]
+    return a[..., 0] if a.ndim == 3 else a
+
+
+KEYS = ["rendered_image", "shadow_mask", "albedo", "depth", "shading", "surface_normals"]
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_kernel_on_the_reference_model_outputs_gives_the_reference_main_bytes(tag):
+    """The device kernel fed with what the reference's relighting pass returned (final_shading / normals rounded to the
+    f32 the device holds) against the bytes of the six images the reference's main() wrote: every byte within 1 LSB,
+    >= 99.99 % identical (the f32 rounding of the two f64 maps can move a value across a half-way point)."""
+    from geomconsistentfr_amd import postprocess as pp
+    z = np.load(os.path.join(GOLDEN, "slt_main_%s.npz" % tag))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    got = pp.inference_images_device(t((z["input_u8"] / 255.0).astype(np.float32)[None]), t(z["model_rendered_images"]),
+                                     t(z["mask_u8"]), albedo=t(z["model_albedo"]), depth=t(z["model_depth"]),
+                                     shadow_mask_weights=t(z["model_shadow_mask_weights"]),
+                                     final_shading=t(z["model_final_shading"].astype(np.float32)),
+                                     surface_normals=t(z["model_surface_normals"].astype(np.float32)), mask_f32=True)
+    torch.cuda.synchronize()
+    for k in KEYS:
+        g, e = got[k][0].cpu().numpy().astype(int), rgb(z[k + "_u8"]).astype(int)
+        assert np.abs(g - e).max() <= 1, k
+        assert (g == e).mean() >= 0.9999, (k, (g == e).mean())
+    for k in ("rendered_image", "shadow_mask", "albedo", "depth"):     # all-f32 inputs: nothing was rounded, so exact
+        np.testing.assert_array_equal(got[k][0].cpu().numpy(), rgb(z[k + "_u8"]), err_msg=k)
+
+
+def _slt_model():
+    from geomconsistentfr_amd.relightnet import RelightNetLightingTransfer
+    sd = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "slt_checkpoint_epoch106.npz")).items()}
+    m = RelightNetLightingTransfer()
+    m.load_state_dict(sd, strict=True)
+    return m.float().to(DEV).eval()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_lighting_transfer_end_to_end_against_the_reference_main(tag):
+    """inference.lighting_transfer() -- both passes of the network (MIOpen), the HIP render block, the HIP image
+    kernel -- with the reference's shipped checkpoint on the reference's inputs, against the six images its main()
+    wrote.  The network runs on other convolution kernels than torch-CPU's, so: estimated light within 1e-4, every
+    byte within 1 LSB except isolated pixels (a shadow decision can flip), >= 99.9 % of the bytes identical."""
+    from geomconsistentfr_amd.inference import lighting_transfer
+    z = np.load(os.path.join(GOLDEN, "slt_main_%s.npz" % tag))
+    res = lighting_transfer(_slt_model(), z["input_u8"] / 255.0, z["reference_u8"] / 255.0, z["mask_u8"], device=DEV)
+    np.testing.assert_allclose(res["estimated_light"], z["estimated_light"], atol=1e-4)
+    np.testing.assert_allclose(res["estimated_ambient"], z["estimated_ambient"], atol=1e-4)
+    for k in KEYS:
+        g, e = res[k].astype(int), rgb(z[k + "_u8"]).astype(int)
+        diff = np.abs(g - e)
+        assert (diff <= 1).mean() >= 0.9999, (k, (diff <= 1).mean(), diff.max())
+        assert (diff == 0).mean() >= 0.999, (k, (diff == 0).mean())
+
+
+@pytest.mark.parametrize("mask_f32", [False, True])
 @pytest.mark.parametrize("B,H,W", [(1, 256, 256), (3, 64, 96), (2, 37, 51)])
-def test_inference_images_match_the_host_statement_byte_for_byte(B, H, W):
+def test_inference_images_match_the_host_statement_byte_for_byte(B, H, W, mask_f32):
     from geomconsistentfr_amd import postprocess as pp
     x, ren, alb, depth, w, fin, nrm, mask_u8 = _inputs(B, H, W, B * 1000 + W)
-    m01 = mask_u8 / 255.0                                                     # S1:580: uint8 / python float -> f64
+    # the mask as the script holds it: S1:580 / S8:569 numpy f64 / 255.0; SLT:540 torch u8 / 255.0 -> f32
+    m01 = (mask_u8.astype(np.float32) / np.float32(255.0)) if mask_f32 else mask_u8 / 255.0
     t = lambda a: torch.from_numpy(a).to(DEV)
     got = pp.inference_images_device(t(x), t(ren), t(mask_u8), albedo=t(alb), depth=t(depth), shadow_mask_weights=t(w),
-                                     final_shading=t(fin), surface_normals=t(nrm))
+                                     final_shading=t(fin), surface_normals=t(nrm), mask_f32=mask_f32)
     torch.cuda.synchronize()
     for b in range(B):
-        exp = pp.diagnostic_images(x[b].astype(np.float64), alb[b], depth, b, w[b], ren[b], fin[b], nrm[b],
-                                   m01)
+        # final_shading / normals are f64 in the reference: the kernel widens the device's f32 before the arithmetic
+        exp = st.diagnostic_images(x[b].astype(np.float64), alb[b], depth, b, w[b], ren[b], fin[b].astype(np.float64),
+                                   nrm[b].astype(np.float64), m01)
         for k, v in exp.items():
-            np.testing.assert_array_equal(got[k][b].cpu().numpy(), pp.to_uint8(v), err_msg="%s face %d" % (k, b))
+            np.testing.assert_array_equal(got[k][b].cpu().numpy(), st.to_uint8(v), err_msg="%s face %d" % (k, b))
     # only the composite, per-face masks
     masks = np.stack([np.roll(mask_u8, 3 * b, axis=1) for b in range(B)])
     only = pp.inference_images_device(t(x), t(ren), t(masks))
     assert set(only) == {"rendered_image"}
     for b in range(B):
         np.testing.assert_array_equal(only["rendered_image"][b].cpu().numpy(),
-                                      pp.to_uint8(pp.composite_into_input(x[b].astype(np.float64), ren[b], masks[b] / 255.0)))
+                                      st.to_uint8(st.composite_into_input(x[b].astype(np.float64), ren[b], masks[b] / 255.0)))
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 256, 256), (2, 40, 36), (2, 33, 70)])
@@ -61,7 +134,7 @@ def test_border_fix_matches_matlab_semantics(B, H, W):
     got = pp.fix_border_artifacts_device(torch.from_numpy(img).to(DEV), torch.from_numpy(mask).to(DEV)).cpu().numpy()
     n_border = 0
     for b in range(B):
-        np.testing.assert_array_equal(got[b], pp.fix_border_artifacts(img[b], mask[b]))          # host statement
+        np.testing.assert_array_equal(got[b], st.fix_border_artifacts(img[b], mask[b]))          # host statement
         m = np.floor(mask[b] / 255.0 + 0.5)                                                        # MATLAB uint8 division
         conv = ndi.correlate(m, np.ones((7, 7)), mode="constant", cval=0.0)
         border = (conv < 30) & (conv > 0)
@@ -73,7 +146,7 @@ def test_border_fix_matches_matlab_semantics(B, H, W):
     assert n_border > 0
     # one mask shared by the batch
     shared = pp.fix_border_artifacts_device(torch.from_numpy(img).to(DEV), torch.from_numpy(mask[B - 1]).to(DEV)).cpu().numpy()
-    np.testing.assert_array_equal(shared[0], pp.fix_border_artifacts(img[0], mask[B - 1]))
+    np.testing.assert_array_equal(shared[0], st.fix_border_artifacts(img[0], mask[B - 1]))
 
 
 def test_device_functions_have_no_cpu_path():

@@ -50,6 +50,7 @@ def test_march_kernels_fit_their_forced_occupancy_without_scratch(tmp_path):
         hit = [v for m, v in k.items() if m.startswith(n)]
         assert hit and all(v["scratch"] == 0 for v in hit), (n, hit)
     # the staged backward runs at four waves per SIMD (128 VGPRs) with its ~40 pointer arguments parked in two VGPRs'
-    # lanes (v_writelane) and three dwords of scratch outside its hot stages: bounded, not zero
+    # lanes (v_writelane) and a few dwords of scratch outside its hot stages: bounded, not zero (round 3: the run key of
+    # the corner-atomic merge carries the wrapped-column flag, one dword more than round 2's 16 B)
     bwd = [v for m, v in k.items() if m.startswith("render_bwd_single_light_kernel")]
-    assert bwd and all(v["vgpr"] <= 128 and v["scratch"] <= 16 for v in bwd), bwd
+    assert bwd and all(v["vgpr"] <= 128 and v["scratch"] <= 24 for v in bwd), bwd

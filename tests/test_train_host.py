@@ -231,3 +231,63 @@ def test_gloo_world2_gradient_allreduce_matches_mean_of_shards():
     for rank, err, scale, n in res:
         assert n == 1_204_796
         assert err <= 1e-5 * max(scale, 1e-3), (rank, err, scale)
+
+
+def _ddp_rewrap_worker(rank, world, port, q):
+    """Trainer._wrap_generator's mechanism on CPU: one step at the last gated epoch under find_unused_parameters=True,
+    then the wrapper is dropped and the SAME module re-wrapped without the flag for two steps at the next epoch."""
+    try:
+        import torch.distributed as dist
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from geomconsistentfr_amd.train import LAST_GATED_EPOCH, TrainConfig, ddp_kwargs, shard_range, synthetic_batch
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.set_num_threads(2)
+        m = _FeatureLoss(epoch=LAST_GATED_EPOCH)
+        kw0 = ddp_kwargs(TrainConfig(), torch.device("cpu"), generator=True, epoch=LAST_GATED_EPOCH)
+        kw1 = ddp_kwargs(TrainConfig(), torch.device("cpu"), generator=True, epoch=LAST_GATED_EPOCH + 1)
+        flags = (kw0["find_unused_parameters"], kw1["find_unused_parameters"])
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+        lo, hi = shard_range(2, rank, world)
+        full = synthetic_batch(2, 0, 256, 256)["images"]
+        ddp = DDP(m, **kw0)
+        opt.zero_grad(set_to_none=True)
+        ddp(full[lo:hi]).backward()
+        opt.step()
+        ddp = None                                            # the old reducer goes, with its autograd hooks
+        m.epoch = LAST_GATED_EPOCH + 1                        # every skip branch now reaches the loss
+        ddp = DDP(m, **kw1)
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            ddp(full[lo:hi]).backward()
+            opt.step()
+        grads = [p.grad for p in m.parameters()]
+        n_none = sum(g is None for g in grads)
+        flat = torch.cat([g.flatten() for g in grads if g is not None])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        q.put((rank, float((gathered[0] - gathered[1]).abs().max()), float(flat.abs().max()), (flags, n_none)))
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, "error: %r" % (e,), 0.0, 0))
+        raise
+
+
+def test_gloo_world2_generator_is_rewrapped_without_find_unused_after_the_last_gated_epoch():
+    """find_unused_parameters is needed only while epoch <= 14 (T8:245-283); after that every
+    parameter gets a gradient, the re-wrapped DDP (flag off) keeps the ranks' gradients identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_rewrap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    assert all(not isinstance(r[1], str) for r in res), res
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, diff, scale, (flags, n_none) in res:
+        assert flags == (True, False)
+        assert diff == 0.0 and scale > 0 and n_none == 0
