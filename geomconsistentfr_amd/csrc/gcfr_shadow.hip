@@ -24,6 +24,7 @@
 
 #include <atomic>
 #include <cstddef>
+#include <type_traits>
 
 namespace gcfr {
 
@@ -345,6 +346,12 @@ __device__ inline int zb_log2_stride(int H, int W, int N, TablePtrT t_table, int
 
 // records per image: the tiles at the finest stride plus one sentinel (-inf, +inf) that uncovered footprints read
 __host__ __device__ inline int zb_max_tiles(int H, int W) { return ((H >> 3) + 1) * ((W >> 3) + 1) + 1; }
+// per-image stride of the records, a whole number of 1-KiB pieces: the march's LDS-staged variant copies an image's
+// records with global_load_lds_dwordx4, 64 lanes x 16 B per instruction
+__host__ __device__ inline int zb_stride(int H, int W) { return (zb_max_tiles(H, W) + 63) & ~63; }
+// mask bitmap of the LDS-staged march: one bit per cell (1 = mask cell non-zero), row-major, 32 cells per dword,
+// per-mask stride padded to 1 KiB; needs W % 32 == 0
+__host__ __device__ inline int bitmap_stride_bytes(int H, int W) { return (((H * W) >> 3) + 1023) & ~1023; }
 
 // Sum over each 16-lane row of the wave, result in every lane of the row's last lane ... read with readlane(row*16+15).
 __device__ inline float row_sum_f32(float v)
@@ -375,7 +382,7 @@ __device__ inline void build_zbounds_block(int block, int b, const float *__rest
     const int ntw = (W >> ls) + 1, nth = (H >> ls) + 1;
     const int tile = block * 4 + (int)(threadIdx.x >> 6);
     if (block == 0 && threadIdx.x == 0)
-        zb[(size_t)b * zb_max_tiles(H, W) + zb_max_tiles(H, W) - 1] =
+        zb[(size_t)b * zb_stride(H, W) + zb_max_tiles(H, W) - 1] =
             make_float4(0.0f, 0.0f, -__builtin_inff(), __builtin_inff());
     if (tile >= nth * ntw)
         return;
@@ -414,7 +421,7 @@ __device__ inline void build_zbounds_block(int block, int b, const float *__rest
         const float wlo = f32_unsortable(wave_min_i32(f32_sortable(lo)));
         const float whi = -f32_unsortable(wave_min_i32(f32_sortable(-hi)));
         if (lane == 0)
-            zb[(size_t)b * zb_max_tiles(H, W) + tile] = make_float4(pa, pb, wlo, whi);
+            zb[(size_t)b * zb_stride(H, W) + tile] = make_float4(pa, pb, wlo, whi);
         return;
     }
     // pass 1: slopes from the means of the tile's four s x s quadrants (finite proper cells only).  Row q of
@@ -463,7 +470,7 @@ __device__ inline void build_zbounds_block(int block, int b, const float *__rest
     const float wlo = f32_unsortable(wave_min_i32(f32_sortable(lo)));
     const float whi = -f32_unsortable(wave_min_i32(f32_sortable(-hi)));
     if (lane == 0)
-        zb[(size_t)b * zb_max_tiles(H, W) + tile] = make_float4(pa, pb, wlo, whi);
+        zb[(size_t)b * zb_stride(H, W) + tile] = make_float4(pa, pb, wlo, whi);
 }
 
 // Per-image statistics the march needs before it starts: the bounding box of the mask's non-zero cells and the
@@ -472,9 +479,7 @@ __device__ inline void build_zbounds_block(int block, int b, const float *__rest
 // nothing to report), so an image has only P/16384 partials (4 at 256x256) and every march wave reduces them
 // itself with one load and six DPP minima -- no atomics to initialise, no workgroup barrier in the march (round 1
 // kept 256 partials per image and reduced them through LDS in every march workgroup's prologue).
-// The tile queue of the persistent schedule lives 256 B after the sample-table flag: every tile start reads the flag
-// with a scalar load, and a line that is being hammered by device-scope atomics answers reads slowly.
-constexpr int kQueueSlot = 64;
+constexpr int kQueueSlot = 64;  // (workspace layout: the table flag keeps a 256-B line to itself)
 constexpr int kStatChunk = 16384;
 __host__ __device__ inline int n_stat_chunks(int H, int W) { return (H * W + kStatChunk - 1) / kStatChunk; }
 
@@ -582,33 +587,30 @@ __device__ inline void build_stats_block(int chunk, int b, const float *__restri
     }
 }
 
-// The board of schedule 6 (helping across the chip; see march_tile, SPLIT = 4): reset by the prepass, used by the march.
-constexpr int kHelpSlots = 1024, kHelpEmpty = 0, kHelpPosted = 1, kHelpTaken = 2, kHelpReclaimed = 3;
-#ifndef GCFR_HELP_BODIES
-#define GCFR_HELP_BODIES 4
-#endif
-#ifndef GCFR_HELP_MIN_GROUPS
-#define GCFR_HELP_MIN_GROUPS 6
-#endif
-[[maybe_unused]] constexpr int kHelpBodies = GCFR_HELP_BODIES, kHelpMinGroups = GCFR_HELP_MIN_GROUPS;
-struct HelpSlot {
-    int state, arrivals;
-    int bl, qy, tx;          // the tile
-    int k_mid, k_far;        // the posted samples [k_mid, k_far)
-    int poster_duty;         // what the second arriver goes on to complete: -1 the tile itself, s >= 0 the taker's side of slot s
-    unsigned warm[64];       // the poster's running minima (f32 bits) when it posted: valid bounds for the taker
-    unsigned part[2][64];    // partial results {poster's side, taker's side}: f32 bits of min S | any_masked << 31
-};
-struct HelpArea {
-    int n_posted, pad[15];
-    HelpSlot slot[kHelpSlots];
-};
-
 // Prepass, one launch.  Grid x = [depth-bounds tiles | statistics chunks | repack blocks], y = image:
 //   (d) the depth-bounds tiles (head of the grid: their short dependent-load chains start first),
 //   (c) per-chunk partial mask bounding boxes and depth ranges (build_stats_block),
+//   (f) the mask bitmap of the LDS-staged march (build_bitmap_block), when that variant will run,
 //   (a) the repack of depth into 2x2-neighbourhood texels; its first block also runs (b) the optional light
-//       preparation, (e) the sample-table check and zeroes the persistent march's tile queue.
+//       preparation and (e) the sample-table check.
+// The mask as a bitmap (LDS-staged march): thread i of an image packs cells [32 i, 32 i + 32) into dword i.
+__device__ inline void build_bitmap_block(int block, int b, const uint8_t *__restrict__ mask, int H, int W,
+                                          uint32_t *__restrict__ bitmap)
+{
+    const int i = block * 256 + (int)threadIdx.x;
+    if (i >= ((H * W) >> 5))
+        return;
+    const uint4 *m = (const uint4 *)(mask + (size_t)b * H * W) + 2 * (size_t)i;  // 32 bytes (W % 32 == 0: 16-byte aligned rows)
+    const uint4 lo = m[0], hi = m[1];
+    auto nib = [](uint32_t d) -> uint32_t {  // one bit per non-zero byte, byte k -> bit k
+        const uint32_t nz = (d | ((d & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;
+        return ((nz >> 7) & 1u) | ((nz >> 14) & 2u) | ((nz >> 21) & 4u) | ((nz >> 28) & 8u);
+    };
+    const uint32_t bits = nib(lo.x) | (nib(lo.y) << 4) | (nib(lo.z) << 8) | (nib(lo.w) << 12) | (nib(hi.x) << 16) |
+                          (nib(hi.y) << 20) | (nib(hi.z) << 24) | (nib(hi.w) << 28);
+    bitmap[(size_t)b * (bitmap_stride_bytes(H, W) >> 2) + i] = bits;
+}
+
 __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict__ depth,
                                                          float4 *__restrict__ quad, int H, int W,
                                                          PrepassLights pl,
@@ -618,7 +620,8 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
                                                          float4 *__restrict__ zb, int zb_blocks, int stat_blocks,
                                                          int want_z, int vec_ok, int N,
                                                          const double *__restrict__ t_table, int group,
-                                                         int *__restrict__ tflag, HelpArea *__restrict__ help)
+                                                         int *__restrict__ tflag, uint32_t *__restrict__ bitmap,
+                                                         int bitmap_blocks)
 {
     const int Wp = W + 1, Hp = H + 1;
     const int b = blockIdx.y;
@@ -631,7 +634,12 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
                           want_z != 0, vec_ok != 0);
         return;
     }
-    const int qb = (int)blockIdx.x - zb_blocks - stat_blocks;
+    if ((int)blockIdx.x < zb_blocks + stat_blocks + bitmap_blocks) {
+        if (b < mask_batch)
+            build_bitmap_block((int)blockIdx.x - zb_blocks - stat_blocks, b, mask, H, W, bitmap);
+        return;
+    }
+    const int qb = (int)blockIdx.x - zb_blocks - stat_blocks - bitmap_blocks;
     const int i = qb * blockDim.x + threadIdx.x;
     if (qb == 0 && b == 0 && threadIdx.x < 64) {
         // Is the sample table what the march's pruning / skipping reasons about -- increasing, inside [0, 1]
@@ -646,18 +654,8 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
             }
         }
         const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
-        if (threadIdx.x == 0) {
-            tflag[0] = all_ok ? 1 : 0;
-            tflag[kQueueSlot] = 0;  // the persistent march's tile queue (an atomic counter), reset for this call
-        }
-    }
-    if (help && qb == 1 && b == 0) {  // an empty board for this call's march (schedule 6)
         if (threadIdx.x == 0)
-            help->n_posted = 0;
-        for (int i = threadIdx.x; i < kHelpSlots; i += blockDim.x) {
-            help->slot[i].state = kHelpEmpty;
-            help->slot[i].arrivals = 0;
-        }
+            tflag[0] = all_ok ? 1 : 0;
     }
     if (pl.light_raw && qb == 0) {
         for (int l = threadIdx.x; l < pl.L; l += blockDim.x)
@@ -700,22 +698,18 @@ struct ShadowQuadArgs {
     const float *depth;     // (B,H,W)      own-pixel depth
     const float4 *quad;     // (B,H+1,W+1)  prepass output
     const int *bbox;        // (MB,n_stat,4) prepass output: partial mask bounding boxes {r_min, c_min, -r_max, -c_max}
-    const float4 *zb;       // (B,zb_max_tiles) prepass output: depth bounds grid {a, b, c_lo, c_hi}, or null (skip off)
+    const float4 *zb;       // (B,zb_stride) prepass output: depth bounds grid {a, b, c_lo, c_hi}, or null (skip off)
     const int *zrange;      // (B,n_stat,2) prepass output: partial depth ranges {z_min, -z_max} (sortable ints)
     const int *mones;       // (MB,n_stat)  prepass output: 1 iff every mask cell of the chunk is non-zero
-    int *tflag;             // [0] prepass output: 1 iff the sample table is increasing, inside [0,1] and uniform;
-                            // [kQueueSlot] the persistent schedule's tile queue (zeroed by the prepass)
+    int *tflag;             // [0] prepass output: 1 iff the sample table is increasing, inside [0,1] and uniform
     const uint8_t *mask;    // (MB,H,W)
+    const uint32_t *bitmap; // (MB, bitmap_stride_bytes / 4) prepass output (LDS-staged march): one bit per mask cell
     const float *light_pt;  // (B,L,3)
     const double *t_table;  // (N)
     unsigned long long *counters;  // GCFR_COUNTERS builds: work counts, see gcfr_options
-    HelpArea *help;         // the board of posted half-tiles (schedule 6), reset by the prepass
     int32_t mask_batch, B, L, H, W, N;
     int32_t tiles_x, tiles_y;  // tiles per image row / column
-    int32_t total_tiles;       // B * L * tiles_x * tiles_y (persistent schedule)
-    int32_t tile_order;        // persistent schedule: see gcfr_options
-    int32_t bl_offset;         // grid schedule: first (image, light) index of this launch (grid z is limited to 65535)
-    int32_t help_bodies, help_min_groups;  // schedule 6: post after this many executed groups / with this many left
+    int32_t bl_offset;         // first (image, light) index of this launch (grid z is limited to 65535)
     MarchEpilogueArgs epi;
 };
 
@@ -835,16 +829,41 @@ __device__ inline ImageStats reduce_image_stats(ArgPtr a, int b, int lane, bool 
 // SPLIT = 1: the 4 waves of the workgroup march the SAME tile, a contiguous quarter of the sample range each
 //            (four gathers in flight per body, natural occupancy), and combine their partial minima through LDS
 //            (earliest index wins ties, as torch.min): tiny, latency-bound launches (one or two images).
-// SPLIT = 2: cooperative march: the 4 waves take the tile's sample GROUPS round-robin (wave w: groups w, w+4, ...),
-//            so they advance along the rays together, publish their running minima in LDS and use each other's as
-//            the bound of the exact depth-bound skip and of the early termination (any minimum already found for a
-//            pixel bounds its final minimum: a group skipped against it could neither win nor tie).  The heaviest
-//            tile's critical path -- which IS the launch time of the one-wave-per-tile schedule (timeline: the
-//            longest tile runs 69 of the launch's 74 us) -- shrinks fourfold and the work items are four times
-//            finer, so one launch keeps the SIMDs full to the end.
+// (Round 2 also built and measured four more schedules on this tile function -- persistent waves with a tile queue or a
+//  strided assignment, four cooperating waves per tile, work stealing inside the workgroup, helping across the chip;
+//  all bit-identical, all slower: profiles/r02_schedule_experiments.md.  Their code was removed from the product source
+//  in round 3; it builds from commit 4db51f3 with -DGCFR_EXPERIMENTAL_SCHEDULES.)
 #ifndef GCFR_TILE_INLINE
 #define GCFR_TILE_INLINE __forceinline__
 #endif
+
+// LDS image of the LDS-staged march (dynamic shared memory, sized by the launch): [mask bitmap, bitmap_stride_bytes |
+// depth-bounds records, zb_stride * 16 B] of the workgroup's image.  26 KiB at 256 x 256: six workgroups per CU, which is
+// what the march's forced occupancy (six waves per SIMD, four waves per workgroup) needs.
+extern __shared__ uint4 gcfr_lds_stage[];
+
+// Copy the image's bitmap (unless its mask has no zero cell: then the march never reads it) and bounds records into LDS:
+// 1-KiB pieces, piece i by wave i mod 4, each ONE global_load_lds_dwordx4 -- global -> LDS without passing through
+// registers, issued at kernel entry and awaited by the workgroup barrier in front of the sample loop, so the copy runs
+// behind the tile prologue's ~750 instructions.
+__device__ inline void stage_lds(ArgPtr a, int b, bool with_bitmap)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int H = a->H, W = a->W;
+    const int bm_bytes = bitmap_stride_bytes(H, W), zb_bytes = a->zb ? zb_stride(H, W) * 16 : 0;
+    const char *gbm = (const char *)a->bitmap + (size_t)(a->mask_batch == 1 ? 0 : b) * bm_bytes;
+    const char *gzb = (const char *)a->zb + (size_t)b * zb_stride(H, W) * 16;
+    const int n_bm = with_bitmap ? (bm_bytes >> 10) : 0, n_zb = zb_bytes >> 10;
+    for (int ch = wave; ch < n_bm + n_zb; ch += 4) {
+        const bool is_bm = ch < n_bm;
+        const int piece = is_bm ? ch : ch - n_bm;
+        const char *src = (is_bm ? gbm : gzb) + ((size_t)piece << 10) + (lane << 4);
+        const int dst = (is_bm ? 0 : bm_bytes) + (piece << 10);  // wave-uniform LDS byte offset; lane i lands at + 16 i
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)((__attribute__((address_space(3))) char *)gcfr_lds_stage + dst),
+                                         16, 0, 0);
+    }
+}
 // lane id from the hardware (two VALU), opaque to the optimiser: a value derived from it has no live range before this point
 __device__ inline int fresh_lane_id()
 {
@@ -853,127 +872,13 @@ __device__ inline int fresh_lane_id()
     return l;
 }
 
-// SPLIT = 4, helping across the chip (shadow_fwd_quad_help_kernel; gcfr_options.schedule 6).  One launch of the grid
-// schedule ends when its heaviest tile does, long after half of the SIMDs have gone idle; stealing
-// inside the workgroup (SPLIT = 3) cannot help, because the idle SIMDs sit on other CUs.  Here a wave that has
-// executed kHelpBodies sample groups of its tile and still has kHelpMinGroups to go POSTS the far half of what is left
-// in a small board in global memory (its range, the tile's coordinates and its running minima as a warm start) and
-// carries on with the near half; a wave that has finished its own tile TAKES a posted half, re-runs that tile's
-// prologue and marches the half (and may post again).  Nobody ever waits: each posted half is a rendezvous of two
-// arrivals -- whoever completes the poster's side and whoever completes the taker's side each publish their partial
-// minima and fetch-add `arrivals`; the first to arrive simply leaves, the second merges both partials and inherits
-// the poster's duty (another rendezvous one level up, or, at the root, the tile's epilogue).  A half nobody took by
-// the time its poster is done is taken back with one compare-and-swap and marched by the poster itself.  Minima
-// merge in any order, so min_dist is the sequential march's bit for bit (inference variant only: no argmin).
-// MEASURED AND REJECTED (experimental builds only, profiles/r02_schedule_experiments.md section J): every hop of the
-// protocol is a memory-side round trip of 2-3 us across XCDs, a help needs six or more, and the launch it is meant to
-// shorten lasts 72 us -- the more halves are posted, the slower the launch (135 ... 230 us).
-#define GCFR_GLOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define GCFR_GSTORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-// Ordering on the board WITHOUT fences.  The chip is eight XCDs with an L2 each: an agent-scope release / acquire
-// fence (__threadfence, or acquire / release orders on the atomics) writes back and invalidates the issuing XCD's whole
-// L2 -- every wave there loses its cached texels (measured: the helping march 7x slower than the grid).  Every access
-// to the board is therefore a RELAXED agent-scope atomic -- such loads and stores bypass the non-coherent levels and
-// act at the memory side -- and "data before flag" is kept by waiting for the data stores' acknowledgements
-// (s_waitcnt vmcnt(0)) before the flag is touched; readers touch the flag first (a returning RMW) and read the data
-// after it has returned.
-__device__ __forceinline__ void help_order()
-{
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0);
-    asm volatile("" ::: "memory");
-}
-// (whole wave) take one of the newest posted halves that is still up for grabs, or -1.  No shared take counter: a
-// read-modify-write on ONE address completes every ~20 ns chip-wide, and 8192 finishing waves bumping one counter would
-// by themselves outlast the launch (measured: 34 ms).  Each lane reads the state of one of the newest 64 ... 256 slots
-// (plain L2 reads), the wave picks a pseudo-random posted one and lane 0 claims it with a compare-and-swap on that
-// slot alone; up to three candidates per window, then it gives up -- a half nobody takes goes back to its poster.
-__device__ inline int help_take(HelpArea *ha, int lane, unsigned salt)
-{
-    const int np = min(__builtin_amdgcn_readfirstlane(GCFR_GLOAD(&ha->n_posted)), kHelpSlots);
-    for (int w = 0; w < 4; ++w) {
-        const int hi = np - 64 * w;
-        if (hi <= 0)
-            break;
-        const int idx = hi - 1 - lane;  // lane 0: the newest of this window
-        const int st = idx >= 0 ? GCFR_GLOAD(&ha->slot[idx].state) : kHelpEmpty;
-        unsigned long long m = __builtin_amdgcn_ballot_w64(st == kHelpPosted);
-        for (int tries = 0; m != 0ull && tries < 3; ++tries) {
-            const int kth = (int)((salt + 7u * (unsigned)tries) % (unsigned)__builtin_popcountll(m));
-            unsigned long long mm = m;
-            for (int i = 0; i < kth; ++i)
-                mm &= mm - 1ull;
-            const int l = (int)__builtin_ctzll(mm);
-            const int cand = hi - 1 - l;
-            int got = 0;
-            if (lane == 0) {
-                int e = kHelpPosted;
-                got = __hip_atomic_compare_exchange_strong(&ha->slot[cand].state, &e, kHelpTaken, __ATOMIC_RELAXED,
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
-            }
-            if (__builtin_amdgcn_readfirstlane(got))
-                return cand;
-            m &= ~(1ull << l);
-        }
-    }
-    return -1;
-}
-
-// SPLIT = 3, work stealing inside the workgroup (shadow_fwd_quad_steal_kernel).  The workgroup's four tiles are four
-// queues of sample groups in LDS.  A wave first marches its OWN tile, claiming kStealChunk groups at a time (a fetch-add;
-// consecutive claims continue the prefetch pipeline, so an unshared tile marches exactly as in the grid schedule);
-// when its tile is exhausted it looks at the other three, and if one still has at least kMinSteal unclaimed groups it
-// repeats that tile's prologue (the per-pixel ray set-up, ~400 VALU) and joins in, claiming from the same front --
-// from the back it would march what the owner's early termination is about to declare dead.
-// Every worker of a tile publishes its running minimum in LDS (ds_min_u32 on the bits of a non-negative float) and
-// bounds its depth-bound skip and its termination test by the smallest value anyone has published -- any distance
-// already found for a pixel bounds its final minimum, so a group skipped against it could not have won: the minimum
-// is the one the sequential march finds.  Every group is claimed exactly once (a worker whose termination test fires
-// claims the whole unclaimed rest as dead with a fetch-max); a worker leaving a tile adds the groups it claimed to the
-// tile's `done` count, and the one that completes the count runs the tile's epilogue on the merged minimum.  Inference variant only (no argmin: a
-// minimum needs no order, the first index of the minimal distance does).
-#ifndef GCFR_STEAL_TILES
-#define GCFR_STEAL_TILES 16
-#endif
-constexpr int kStealTiles = GCFR_STEAL_TILES;  // tiles = waves per workgroup
-struct StealShared {
-    int next[kStealTiles];               // first unclaimed group of the tile (claims are fetch-adds; may run past total)
-    int done[kStealTiles], total[kStealTiles];  // groups accounted for / groups of the tile's pruned sample range
-    unsigned min_bits[kStealTiles][64];  // running minimum of S per pixel (f32 bits; S >= 0 or +inf, never NaN)
-    unsigned anym[kStealTiles][64];      // some sample of the pixel was masked
-};
-#ifndef GCFR_STEAL_CHUNK
-#define GCFR_STEAL_CHUNK 4
-#endif
-#ifndef GCFR_MIN_STEAL
-#define GCFR_MIN_STEAL 8
-#endif
-[[maybe_unused]] constexpr int kStealChunk = GCFR_STEAL_CHUNK, kMinSteal = GCFR_MIN_STEAL;  // groups per claim (even), groups left that justify a second prologue
-static_assert(kStealChunk % 2 == 0, "claims must keep the two-buffer pipeline's parity");
-__device__ __forceinline__ StealShared &steal_shared()
-{
-    __shared__ StealShared s;
-    return s;
-}
-
-template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, int SPLIT, bool ALL_ONES = false>
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, int SPLIT, bool ALL_ONES = false, bool LDS = false>
 __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy, const int tx,
-                                           const ImageStats &st, const int ti = 0, const bool owner = true,
-                                           const bool tile_ok = true)
+                                           const ImageStats &st)
 {
     constexpr int TILE_H = 64 / TILE_W;
-    constexpr bool STEAL = SPLIT == 3, HELP = SPLIT == 4;
-    static_assert(!((STEAL || HELP) && WANT_ARGMIN), "work stealing / helping merge minima, not first indices");
-    if (STEAL && owner && !tile_ok) {  // a wave without a tile of its own: empty queue, then it may steal
-        StealShared &ss0 = steal_shared();
-        if ((threadIdx.x & 63) == 0) {
-            ss0.next[ti] = 0;
-            ss0.total[ti] = 0;
-            ss0.done[ti] = 0;
-        }
-        __syncthreads();
-        return;
-    }
+    static_assert(SPLIT == 0 || SPLIT == 1, "SPLIT: 0 = one wave per tile, 1 = the workgroup's four waves split the sample range");
+    static_assert(!(LDS && SPLIT != 0), "the LDS-staged march is a throughput variant: one wave per tile");
     const int H = a->H, W = a->W, L = a->L;
     // Wave-uniform read-only inputs are read through the CONSTANT address space: in the persistent schedule the
     // previous tile's stores and the queue atomic precede these loads in program order, so through a plain global
@@ -988,7 +893,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // sample range of this wave
-    constexpr bool KSPLIT = SPLIT == 1, COOP = SPLIT == 2;
+    constexpr bool KSPLIT = SPLIT == 1;
     const int chunk = KSPLIT ? (a->N + 3) >> 2 : a->N;
     const int k_lo = KSPLIT ? wave * chunk : 0;
     const int N = KSPLIT ? min(a->N, k_lo + chunk) : a->N;  // exclusive upper bound ("N" below)
@@ -1134,7 +1039,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     const bool zb_trusted = __builtin_amdgcn_readfirstlane((int)zfits) != 0;
     const int zntw = (W >> zls) + 1;
     const __amdgpu_buffer_rsrc_t zr =
-        make_rsrc(a->zb + (size_t)b * zb_max_tiles(H, W), zb_max_tiles(H, W) * (int)sizeof(float4));
+        make_rsrc(a->zb + (size_t)b * zb_stride(H, W), zb_max_tiles(H, W) * (int)sizeof(float4));
     const float nrm = __builtin_sqrtf(BCx * BCx + BCy * BCy);
     const float c1 = BCz * ((dxf * BCx + dyf * BCy) / nrm);
     const float Qz = nrm * zb;
@@ -1151,7 +1056,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 #endif
     if (use_zb) {
         const int own = __mul24((qy * TILE_H) >> zls, zntw) + ((tx * TILE_W) >> zls);
-        const ConstF32Ptr rec = (ConstF32Ptr)(unsigned long long)a->zb + 4 * ((size_t)b * zb_max_tiles(H, W) + own);
+        const ConstF32Ptr rec = (ConstF32Ptr)(unsigned long long)a->zb + 4 * ((size_t)b * zb_stride(H, W) + own);
         const float band = rec[3] - rec[2];  // c_hi - c_lo (wave-uniform address: scalar loads)
         const bool hopeless = !(fabsf(c1) * t_abs >= GCFR_GIVEUP_FACTOR * nrm * band);  // (NaN / inf bands: hopeless)
         if (__builtin_amdgcn_ballot_w64(!hopeless) == 0ull) {
@@ -1203,6 +1108,22 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
             off = covered ? off : zb_sentinel;
         }
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, off, 0, 0));
+    };
+    // the same record from the workgroup's LDS copy (bitmap first, records behind it)
+    const int lds_zb_base = bitmap_stride_bytes(H, W);
+    auto lds_load_b32 = [&](int byte_off) -> uint32_t {
+        return *(const __attribute__((address_space(3))) uint32_t *)((__attribute__((address_space(3))) const char *)gcfr_lds_stage + byte_off);
+    };
+    auto lds_zb_fetch = [&](int ca, int ra, int cb, int rb) -> f32x4 {
+        const int cmin = min(ca, cb), cmax = max(ca, cb), rmin = min(ra, rb), rmax = max(ra, rb);
+        const int tj = cmin >> zls, ti = rmin >> zls;
+        int off = (__mul24(ti, zntw) + tj) << 4;
+        if (!zb_trusted) {  // (wave-uniform branch)
+            const bool covered = (cmin >= 0) && (rmin >= 0) && (cmax <= W - 1) && (rmax <= H - 1) &&
+                                 (cmax + 2 <= ((tj + 2) << zls) - 1) && (rmax + 2 <= ((ti + 2) << zls) - 1);
+            off = covered ? off : zb_sentinel;
+        }
+        return *(const __attribute__((address_space(3))) f32x4 *)((__attribute__((address_space(3))) const char *)gcfr_lds_stage + lds_zb_base + off);
     };
 
     // Two-stage software pipeline.  Stage A (sample k+1): position, rounded cell, issue the mask byte
@@ -1280,54 +1201,62 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     // consumed in place -- with a single buffer copied at the loop's back edge the compiler waits for the
     // gathers (s_waitcnt vmcnt(0)) at the END of the iteration that issued them, which exposes their whole
     // latency on every skipped group.
-    // COOP: this wave's next group is four groups on; the running minima of the workgroup's four waves live in LDS
-    constexpr int GSTRIDE = COOP ? 4 * DEPTH : DEPTH;
-    __shared__ float s_run_min[COOP ? 4 : 1][64];
-    volatile float *run_min = &s_run_min[0][0];
-    if (COOP) {
-        run_min[wave * 64 + lane] = __builtin_inff();
-        __syncthreads();
-    }
-    // the bound the skip / termination tests compare against: the lane's own running minimum, or (COOP) the
-    // smallest one any of the four waves has published for this pixel -- stale values are larger, hence safe
-    auto bound_min = [&]() -> float {
-        if (STEAL)
-            return fminf(bestS, __builtin_bit_cast(float, *(volatile unsigned *)&steal_shared().min_bits[ti][lane]));
-        if (!COOP)
-            return bestS;
-        const float m01 = fminf(run_min[lane], run_min[64 + lane]), m23 = fminf(run_min[128 + lane], run_min[192 + lane]);
-        return fminf(bestS, fminf(m01, m23));
-    };
-    int help_bodies = 0;  // (HELP) sample groups of this tile this wave has executed
-    auto group = [&](int k0, const Prefetched &cur, Prefetched &nxt, bool check_finished) -> bool {
-        const double ta64 = tc0, tb64 = tc3;  // first / last table value of THIS group (tq of the previous call)
-        tc0 = tq[0];
-        tc3 = tq[DEPTH - 1];
-        prefetch(nxt);                 // group k0 + GSTRIDE
-        load_tq(k0 + 2 * GSTRIDE);     // ... and the table values of the one after it
-        GCFR_COUNT(kCntGroupsVisited, 1);
-        bool none = true;
-#pragma unroll
-        for (int j = 0; j < DEPTH; ++j) {
-            none = none && (cur.m[j] == 0);
-            any_masked |= (cur.m[j] == 0);
+    // consume(): what happens to one group once its mask values `cm` (0 = masked) and its bounds record `cz` are known.
+    // ta64 / tb64: the group's first / last table value; tn64: the next group's first one.
+    // finish_check(): early termination, see Dcap.  false: no later sample of any lane of the wave can matter.
+    auto finish_check = [&](int k0, double tn64, bool check_finished) -> bool {
+        if (check_finished && use_zb && k0 + DEPTH < k_end) {
+            const float tn = (float)tn64;  // tt[k0 + DEPTH]: the next group's first value
+            const float gd = __builtin_fmaf(c1, tn, -Dcap);
+            const float bS = bestS;
+            const bool finished = ((gd > 0.0f) && (gd * gd * 0.998f > bS) && (bS < safeS)) ||
+                                  (lane_last < k0 + DEPTH);
+            if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) {
+                any_masked |= (lane_last < k0 + DEPTH);
+                GCFR_COUNT(kCntEarlyExit, 1);
+                return false;
+            }
         }
-        bool run_body = __builtin_amdgcn_ballot_w64(!none) != 0ull;
-        if (run_body && use_zb) {
+        return true;
+    };
+    // bound_cw(): the depth-bound test of one group for this lane -- true: no sample of the group can lower (or tie) the
+    // lane's running minimum.  cz: the group's bounds record, ta64 / tb64: its first / last table value.
+    auto bound_cw = [&](const f32x4 &cz, double ta64, double tb64) -> bool {
             GCFR_COUNT(kCntBoundTests, 1);
             const float ta = (float)ta64, tb = (float)tb64;  // tt[k0], tt[clampk(k0 + DEPTH - 1)]
             const float Ta = c1 * ta, Tb = c1 * tb;
             const float Tlo = fminf(Ta, Tb), Thi = fmaxf(Ta, Tb);
             // surface band at the sample position s(t) = (x, y) + t d:  z in A0 + t A1 + [c_lo, c_hi], so
             // G(t) = n (z - zb) - c1 t  lies in  [F_lo + t E, F_hi + t E]: linear in t, extremes at the group's ends
-            const float A0 = __builtin_fmaf(cur.z.x, x, cur.z.y * y), A1 = __builtin_fmaf(cur.z.x, dxf, cur.z.y * dyf);
+            const float A0 = __builtin_fmaf(cz.x, x, cz.y * y), A1 = __builtin_fmaf(cz.x, dxf, cz.y * dyf);
             const float E = __builtin_fmaf(nrm, A1, -c1);
-            const float Flo = __builtin_fmaf(nrm, A0 + cur.z.z, -Qz), Fhi = __builtin_fmaf(nrm, A0 + cur.z.w, -Qz);
+            const float Flo = __builtin_fmaf(nrm, A0 + cz.z, -Qz), Fhi = __builtin_fmaf(nrm, A0 + cz.w, -Qz);
             const float eA = ta * E, eB = tb * E;
             const float gap = fmaxf(Flo + fminf(eA, eB), -(Fhi + fmaxf(eA, eB)));  // > 0 iff the band stays clear of the ray
             const float gap0 = fmaxf(-Qz - Thi, Tlo + Qz);     // the same for the isolated value z = 0
             const float g = fminf(gap, gap0) - Kerr;
-            const bool cannot_win = (g > 0.0f) && (g * g * 0.998f > bound_min());
+            return (g > 0.0f) && (g * g * 0.998f > bestS);
+    };
+    // consume(): what happens to one group once its mask values `cm` (0 = masked) are known.  LAZY = false: `cz` is the
+    // group's bounds record, tested here if some lane has an unmasked sample; LAZY = true (LDS-staged variant): the
+    // caller has tested it already and passes the lane's verdict in `cw_in`.  ta64 / tb64: the group's first / last
+    // table value; tn64: the next group's first one.
+    auto consume = [&](int k0, const uint32_t (&cm)[DEPTH], const f32x4 &cz, double ta64, double tb64, double tn64,
+                       bool check_finished, auto lazy, bool cw_in) -> bool {
+        constexpr bool LAZY = decltype(lazy)::value;
+        if (!LAZY)
+            GCFR_COUNT(kCntGroupsVisited, 1);
+        bool none = true;
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            none = none && (cm[j] == 0);
+            any_masked |= (cm[j] == 0);
+        }
+        bool run_body = __builtin_amdgcn_ballot_w64(!none) != 0ull;
+        if (LAZY) {
+            run_body = __builtin_amdgcn_ballot_w64(!none && !cw_in) != 0ull;
+        } else if (run_body && use_zb) {
+            const bool cannot_win = bound_cw(cz, ta64, tb64);
             run_body = __builtin_amdgcn_ballot_w64(!none && !cannot_win) != 0ull;
         }
         // samples of the group evaluated together (texel gathers in flight): one at a time in the throughput
@@ -1336,8 +1265,6 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         constexpr int GCFR_BODY_CHUNK = KSPLIT ? DEPTH : 1;  // (KSPLIT here: SPLIT == 1 only)
         if (run_body) {
           GCFR_COUNT(kCntBodies, 1);
-          if (HELP)
-              ++help_bodies;
 #ifdef GCFR_PRIO_AFTER
           // Longest-job-first at the issue port: a wave that keeps executing bodies is one of the few heavy ones whose
           // length sets the launch time; VALU issue is arbitrated by priority, so raising it lets the heavy wave run
@@ -1348,7 +1275,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 #ifdef GCFR_COUNTERS
 #pragma unroll
           for (int j = 0; j < DEPTH; ++j)
-              cnt[kCntLaneSamples] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(cur.m[j] != 0));
+              cnt[kCntLaneSamples] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(cm[j] != 0));
 #endif
 #pragma unroll
           for (int h0 = 0; h0 < DEPTH; h0 += GCFR_BODY_CHUNK) {
@@ -1378,7 +1305,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 #pragma unroll
             for (int j = h0; j < h0 + GCFR_BODY_CHUNK && j < DEPTH; ++j) {
                 const int k = clampk(k0 + j);
-                const bool masked = (cur.m[j] == 0);
+                const bool masked = (cm[j] == 0);
                 const double gxd = __builtin_ceil(ux[j]), gyd = __builtin_ceil(uy[j]);
                 const double wx0 = gxd - ux[j], wx1 = ux[j] - fxd[j];
                 const double wy0 = gyd - uy[j], wy1 = uy[j] - fyd[j];
@@ -1401,235 +1328,109 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
                 bestS = take ? S : bestS;
             }
           }
-          if (COOP)
-              run_min[wave * 64 + lane] = bestS;  // publish (racy by design: any value ever written is a valid bound)
-          if (STEAL)
-              atomicMin(&steal_shared().min_bits[ti][lane], __builtin_bit_cast(unsigned, bestS));
         }
-        if (check_finished && use_zb && k0 + DEPTH < k_end) {  // early termination, see Dcap
-            const float tn = (float)(COOP ? tt[k0 + DEPTH] : tc0);  // tt[k0 + DEPTH]: the next group's first value
-            const float gd = __builtin_fmaf(c1, tn, -Dcap);
-            const float bS = bound_min();
-            const bool finished = ((gd > 0.0f) && (gd * gd * 0.998f > bS) && (bS < safeS)) ||
-                                  (lane_last < k0 + DEPTH);
-            if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) {
-                any_masked |= (lane_last < k0 + DEPTH);
-                GCFR_COUNT(kCntEarlyExit, 1);
-                return false;
-            }
-        }
-        return true;
+        return finish_check(k0, tn64, check_finished);
+    };
+    auto group = [&](int k0, const Prefetched &cur, Prefetched &nxt, bool check_finished) -> bool {
+        const double ta64 = tc0, tb64 = tc3;  // first / last table value of THIS group (tq of the previous call)
+        tc0 = tq[0];
+        tc3 = tq[DEPTH - 1];
+        prefetch(nxt);                 // group k0 + DEPTH
+        load_tq(k0 + 2 * DEPTH);       // ... and the table values of the one after it
+        return consume(k0, cur.m, cur.z, ta64, tb64, tc0, check_finished, std::false_type{}, false);
     };
 
-    Prefetched bufA, bufB;
-    bufA.z = bufB.z = f32x4{0.0f, 0.0f, -__builtin_inff(), __builtin_inff()};
-    if (STEAL) {
-        StealShared &ss = steal_shared();
-        const int g_total = k_end > k_begin ? (k_end - k_begin + DEPTH - 1) / DEPTH : 0;
-        if (owner) {
-            if (lane == 0) {
-                ss.next[ti] = 0;
-                ss.total[ti] = g_total;
-                ss.done[ti] = 0;
+    // LDS-staged variant (round 3).  The workgroup's image -- its mask as a BITMAP and its depth-bounds
+    // records -- was copied into LDS by the four waves at kernel entry (stage_lds, global_load_lds_dwordx4); what the
+    // global variant gathers one group ahead through the texture path (four 1-byte mask gathers, each occupying the
+    // addressers like a full-width load, and one 16-byte record per lane) is here four ds_read_b32 + one ds_read_b128 of
+    // the group ITSELF: LDS answers in ~100 cycles, so there is no second register buffer and no two-groups-ahead table
+    // bookkeeping, and the texture path carries only the bodies' texel gathers.  Same cells, same records, same
+    // arithmetic after them: bit-identical.
+    auto group_lds = [&](int k0, bool check_finished) -> bool {
+        const double ta64 = tq[0], tb64 = tq[DEPTH - 1];  // (tq holds THIS group's table values)
+        uint32_t cm[DEPTH];
+        int cj[DEPTH], rj[DEPTH], cell[DEPTH];
+        GCFR_COUNT(kCntGroupsVisited, 1);
+        // (1) the bounds test FIRST: it needs the first and the last sample's cells only.  The mask decides nothing for a
+        //     lane that cannot win AND already holds a minimum that is certainly below the masked value 1e6 (bestS <
+        //     safeS: its `any_masked` no longer matters, see the early termination) -- if that is every lane of the wave,
+        //     the group is over without a single mask lookup: the two middle positions, the four bitmap reads and the
+        //     mask bookkeeping are never computed.  Only the LDS variant can order it this way: the global variant has to
+        //     start its mask gathers a group ahead, before it knows anything.
+        bool cw = false;
+        if (use_zb) {
+            double px, py;
+            pos_tq(0, px, py);
+            cell[0] = mask_offset(px, py, cj[0], rj[0]);
+            pos_tq(DEPTH - 1, px, py);
+            cell[DEPTH - 1] = mask_offset(px, py, cj[DEPTH - 1], rj[DEPTH - 1]);
+            const f32x4 cz = lds_zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1]);
+            cw = bound_cw(cz, ta64, tb64);
+            if (__builtin_amdgcn_ballot_w64(!(cw && (bestS < safeS))) == 0ull) {
+                load_tq(k0 + DEPTH);
+                return finish_check(k0, tq[0], check_finished);
             }
-            ss.min_bits[ti][lane] = 0x7f800000u;
-            ss.anym[ti][lane] = 0u;
-            __syncthreads();  // (the only barrier: every wave of the workgroup passes here once, as owner)
         }
-        // claim the next kStealChunk groups of the tile, [c_lo, c_hi)
-        auto claim = [&](int &c_lo, int &c_hi) -> bool {
-            int c = 0;
-            if (lane == 0)
-                c = atomicAdd(&ss.next[ti], kStealChunk);
-            c = __builtin_amdgcn_readfirstlane(c);
-            if (c >= g_total)
-                return false;
-            c_lo = c;
-            c_hi = min(c + kStealChunk, g_total);
-            return true;
-        };
-        int mine = 0;
-        if (!owner)
-            GCFR_COUNT(kCntSteals, 1);
-        int k0 = k_begin, k_stop = k_begin;
-        bool primed = false;
-        for (;;) {
-            if (k0 >= k_stop) {  // (chunks are an even number of groups: only ever true at the top of a pair)
-                int c_lo, c_hi;
-                if (!claim(c_lo, c_hi))
-                    break;
-                mine += c_hi - c_lo;
-                if (!owner)
-                    GCFR_COUNT(kCntStolenGroups, c_hi - c_lo);
-                const int k_new = k_begin + c_lo * DEPTH;
-                if (!primed || k_new != k0) {  // not the continuation of the previous chunk: restart the pipeline
-                    k0 = k_new;
-                    load_tq(k0);
-                    tc0 = tq[0];
-                    tc3 = tq[DEPTH - 1];
-                    prefetch(bufA);
-                    load_tq(k0 + DEPTH);
-                    primed = true;
+        // (2) some lane may still win (or has no minimum yet): the group's mask bits, then the bodies
+        if (ALL_ONES) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j)
+                cm[j] = 1u;
+        } else {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                if (!(use_zb && (j == 0 || j == DEPTH - 1))) {
+                    double px, py;
+                    pos_tq(j, px, py);
+                    cell[j] = mask_offset(px, py, cj[j], rj[j]);  // row * W + col; W % 32 == 0: 32 cells of a row per dword
                 }
-                k_stop = min(k_begin + c_hi * DEPTH, k_end);
+                cm[j] = lds_load_b32((cell[j] >> 3) & ~3);
             }
-            bool fin = !group(k0, bufA, bufB, false);
-            if (!fin && k0 + DEPTH < k_stop)
-                fin = !group(k0 + DEPTH, bufB, bufA, true);
-            if (fin) {
-                // no later sample can be taken (whoever finds that out): everything still unclaimed is dead
-                int old = g_total;
-                if (lane == 0)
-                    old = atomicMax(&ss.next[ti], g_total);
-                old = __builtin_amdgcn_readfirstlane(old);
-                mine += max(0, g_total - old);
+        }
+        load_tq(k0 + DEPTH);           // the next group's table values (scalar loads, answered while this group runs)
+        if (!ALL_ONES) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j)
+                cm[j] = __builtin_amdgcn_ubfe(cm[j], (uint32_t)cj[j], 1u);  // bit (col mod 32): the offset operand uses 5 bits
+        }
+        return consume(k0, cm, f32x4{}, ta64, tb64, tq[0], check_finished, std::true_type{}, cw);
+    };
+
+    if (LDS) {
+        __syncthreads();  // the staged image is complete (every wave of the workgroup gets here exactly once)
+        if (k_begin < k_end)
+            load_tq(k_begin);
+        for (int k0 = k_begin; k0 < k_end; k0 += 2 * DEPTH) {
+            if (!group_lds(k0, false))
                 break;
-            }
-            k0 += 2 * DEPTH;
-        }
-        // leave the tile: merge, account, and the worker that completes the count finishes the tile
-        atomicMin(&ss.min_bits[ti][lane], __builtin_bit_cast(unsigned, bestS));
-        if (any_masked)
-            ss.anym[ti][lane] = 1u;
-        int prev = 0;
-        if (lane == 0)
-            prev = __hip_atomic_fetch_add(&ss.done[ti], mine, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        prev = __builtin_amdgcn_readfirstlane(prev);
-        const bool last = (owner || mine > 0) && (prev + mine == g_total);
-        if (!last)
-            return;
-        bestS = __builtin_bit_cast(float, *(volatile unsigned *)&ss.min_bits[ti][lane]);
-        any_masked = any_masked || (*(volatile unsigned *)&ss.anym[ti][lane] != 0u);
-    } else if (HELP) {
-        HelpArea *const ha = a->help;
-        int duty = ti;  // -1: this wave answers for the tile itself; s >= 0: for the taker's side of slot s
-        if (duty >= 0) {  // a taken half: its range, and the poster's running minima as a warm start
-            HelpSlot *hs = &ha->slot[duty];
-            k_begin = max(k_begin, __builtin_amdgcn_readfirstlane(GCFR_GLOAD(&hs->k_mid)));
-            k_end = min(k_end, __builtin_amdgcn_readfirstlane(GCFR_GLOAD(&hs->k_far)));
-            bestS = __builtin_bit_cast(float, GCFR_GLOAD(&hs->warm[lane]));
-        }
-        auto pack = [&]() { return __builtin_bit_cast(unsigned, bestS) | (any_masked ? 0x80000000u : 0u); };
-        // publish this side's partial result, arrive; true = the other side arrived first and its partial was merged
-        auto rendezvous = [&](HelpSlot *hs, int side) -> bool {
-            GCFR_GSTORE(&hs->part[side][lane], pack());
-            help_order();
-            int arr = 0;
-            if (lane == 0)
-                arr = __hip_atomic_fetch_add(&hs->arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            arr = __builtin_amdgcn_readfirstlane(arr);
-            if (arr == 0)
-                return false;
-            help_order();
-            const unsigned o = GCFR_GLOAD(&hs->part[side ^ 1][lane]);
-            bestS = fminf(bestS, __builtin_bit_cast(float, o & 0x7fffffffu));
-            any_masked = any_masked || (o >> 31) != 0u;
-            return true;
-        };
-        int child = -1, child_mid = 0, child_far = 0;
-        int k_lo = k_begin;
-        for (;;) {
-            bool fin = false;
-            if (k_lo < k_end) {
-                load_tq(k_lo);
-                tc0 = tq[0];
-                tc3 = tq[DEPTH - 1];
-                prefetch(bufA);
-                load_tq(k_lo + DEPTH);
-                for (int k0 = k_lo; k0 < k_end; k0 += 2 * DEPTH) {
-                    if (!group(k0, bufA, bufB, false)) {
-                        fin = true;
-                        break;
-                    }
-                    if (k0 + DEPTH >= k_end)
-                        break;
-                    if (!group(k0 + DEPTH, bufB, bufA, true)) {
-                        fin = true;
-                        break;
-                    }
-                    // a heavy tile with a long way to go: post the far half of what is left
-                    const int k_next = k0 + 2 * DEPTH;
-                    if (child < 0 && help_bodies >= a->help_bodies && k_end - k_next >= a->help_min_groups * DEPTH) {
-                        int pidx = kHelpSlots;
-                        if (lane == 0)
-                            pidx = __hip_atomic_fetch_add(&ha->n_posted, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        pidx = __builtin_amdgcn_readfirstlane(pidx);
-                        if (pidx < kHelpSlots) {
-                            const int k_mid = k_next + (((k_end - k_next) / DEPTH) >> 1) * DEPTH;
-                            HelpSlot *cs = &ha->slot[pidx];
-                            if (lane == 0) {
-                                GCFR_GSTORE(&cs->bl, bl);
-                                GCFR_GSTORE(&cs->qy, qy);
-                                GCFR_GSTORE(&cs->tx, tx);
-                                GCFR_GSTORE(&cs->k_mid, k_mid);
-                                GCFR_GSTORE(&cs->k_far, k_end);
-                                GCFR_GSTORE(&cs->poster_duty, duty);
-                            }
-                            GCFR_GSTORE(&cs->warm[lane], __builtin_bit_cast(unsigned, bestS));
-                            help_order();
-                            if (lane == 0)
-                                GCFR_GSTORE(&cs->state, (int)kHelpPosted);
-                            child = pidx;
-                            child_mid = k_mid;
-                            child_far = k_end;
-                            k_end = k_mid;
-                            help_bodies = 0;
-                        } else {
-                            help_bodies = -(1 << 20);  // the board is full: stop trying
-                        }
-                    }
-                }
-            }
-            k_lo = k_end;  // (this range is done)
-            if (child >= 0) {  // the half posted from this range
-                HelpSlot *cs = &ha->slot[child];
-                int st = kHelpPosted;
-                if (lane == 0)
-                    (void)__hip_atomic_compare_exchange_strong(&cs->state, &st, kHelpReclaimed, __ATOMIC_RELAXED,
-                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                st = __builtin_amdgcn_readfirstlane(st);  // (the value found: kHelpPosted = nobody came, taken back)
-                if (st == kHelpPosted) {
-                    child = -1;
-                    if (!fin) {  // march it here after all (finished early: no later sample can be taken, it is dead)
-                        k_lo = child_mid;
-                        k_end = child_far;
-                        continue;
-                    }
-                } else {
-                    child = -1;
-                    if (!rendezvous(cs, 0))
-                        return;  // the taker's side finishes later and carries this wave's duty on
-                }
-            }
-            if (duty < 0)
-                break;  // the tile's result is complete in this wave: epilogue
-            HelpSlot *ps = &ha->slot[duty];
-            const int up = __builtin_amdgcn_readfirstlane(GCFR_GLOAD(&ps->poster_duty));
-            if (!rendezvous(ps, 1))
-                return;  // the poster's side finishes later
-            duty = up;
+            if (k0 + DEPTH >= k_end)
+                break;
+            if (!group_lds(k0 + DEPTH, true))
+                break;
         }
     } else {
-    const int k_first = k_begin + (COOP ? wave * DEPTH : 0);
+    Prefetched bufA, bufB;
+    bufA.z = bufB.z = f32x4{0.0f, 0.0f, -__builtin_inff(), __builtin_inff()};
+    const int k_first = k_begin;
     if (k_first < k_end) {
         load_tq(k_first);
         tc0 = tq[0];
         tc3 = tq[DEPTH - 1];
         prefetch(bufA);
-        load_tq(k_first + GSTRIDE);
+        load_tq(k_first + DEPTH);
     }
-    for (int k0 = k_first; k0 < k_end; k0 += 2 * GSTRIDE) {
+    for (int k0 = k_first; k0 < k_end; k0 += 2 * DEPTH) {
         if (!group(k0, bufA, bufB, false))
             break;
-        if (k0 + GSTRIDE >= k_end)
+        if (k0 + DEPTH >= k_end)
             break;
-        if (!group(k0 + GSTRIDE, bufB, bufA, true))  // the termination test runs every other group (it costs ~18 VALU)
+        if (!group(k0 + DEPTH, bufB, bufA, true))  // the termination test runs every other group (it costs ~18 VALU)
             break;
     }
     }
 
-    bool coop_tie = false;  // COOP + argmin: some wave holds an earlier sample that may round to the same distance
-    if (KSPLIT || COOP) {  // combine the four waves' partial results for this tile
+    if (KSPLIT) {  // combine the four waves' partial results for this tile
         __shared__ float sS[4][64], sPS[4][64];
         __shared__ int sK[4][64], sPK[4][64];
         __shared__ uint8_t sM[4][64];
@@ -1641,40 +1442,8 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         __syncthreads();
         if (wave != 0)
             return;
-        if (COOP) {
-            // interleaved groups: the minimum of the four partial minima, the SMALLER index on equal S (first minimum,
-            // T8:514).  Distance ties (a slightly larger S at an earlier index rounding to the same distance): every
-            // wave's chain of running minima ends in (prevS, prevk) -> (bestS, besti), and the tie class restricted to
-            // one wave is a suffix of that wave's chain, so if neither link of any wave ties at an earlier index
-            // nothing does; otherwise the epilogue re-marches [0, besti) for the lane (first_tied_sample, exact).
-            float fS = bestS;
-            int fK = besti;
 #pragma unroll
-            for (int q = 1; q < 4; ++q) {
-                const float Sq = sS[q][lane];
-                const int Kq = sK[q][lane];
-                const bool take = (Sq < fS) || (WANT_ARGMIN && Sq == fS && Kq >= 0 && (fK < 0 || Kq < fK));
-                fS = take ? Sq : fS;
-                fK = take ? Kq : fK;
-                any_masked |= (sM[q][lane] != 0);
-            }
-            if (WANT_ARGMIN) {
-                const float den_c = __builtin_sqrtf(((BCx * BCx + BCy * BCy) + BCz * BCz) + kEps4);
-                const float d_c = __builtin_sqrtf(fS) / den_c;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float Sb = sS[q][lane], Sp = sPS[q][lane];
-                    const int Kb = sK[q][lane], Kp = sPK[q][lane];
-                    coop_tie |= (Kb >= 0) && (Kb < fK) && (__builtin_sqrtf(Sb) / den_c == d_c);
-                    coop_tie |= (Kp >= 0) && (Kp < fK) && (__builtin_sqrtf(Sp) / den_c == d_c);
-                }
-                prevk = -1;  // the sequential tie test below does not apply
-            }
-            bestS = fS;
-            besti = fK;
-        }
-#pragma unroll
-        for (int q = 1; q < 4 && KSPLIT; ++q) {
+        for (int q = 1; q < 4; ++q) {
             const float Sq = sS[q][lane];
             const bool take = Sq < bestS;  // strict: the earlier quarter keeps ties (first minimum, T8:514)
             // predecessor of a new best from quarter q: q's own predecessor if it already beat the running
@@ -1697,9 +1466,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     float d = __builtin_sqrtf(bestS) / den;
     // torch.min (T8:514) returns the FIRST index of the minimal distance: see first_tied_sample.
     if (WANT_ARGMIN) {
-        const bool tie = COOP ? coop_tie : ((prevk >= 0) && (__builtin_sqrtf(prevS) / den == d));
-        if (COOP)
-            prevk = besti;  // re-march [0, besti): the first sample whose distance equals d, else besti itself
+        const bool tie = (prevk >= 0) && (__builtin_sqrtf(prevS) / den == d);
         if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare; wave-uniform branch
             GCFR_COUNT(kCntTieRemarch, 1);
             RayConst rc;
@@ -1832,180 +1599,39 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 #ifndef GCFR_MARCH_ARGMIN_WAVES_PER_EU
 #define GCFR_MARCH_ARGMIN_WAVES_PER_EU 5
 #endif
-#ifndef GCFR_STEAL_WAVES_PER_EU
-#define GCFR_STEAL_WAVES_PER_EU 4
-#endif
 
 // Grid schedule: one workgroup = four horizontally adjacent tiles (one per wave), 3-D grid x = tile-quad column,
 // y = tile row, z = (image, light) -- no integer divisions, dispatch order image-major with row-major tiles.
-template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE>
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool LDS = false>
 __device__ __forceinline__ void march_grid(ArgPtr a)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tx = (int)blockIdx.x * 4 + wave;
-    if (tx >= a->tiles_x)
-        return;  // (the waves of a workgroup never synchronise)
     const int bl = a->bl_offset + (int)blockIdx.z;
     const bool want_z = (a->zb != nullptr);
     const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, want_z);
+    if (LDS)
+        stage_lds(a, bl / a->L, st.mask_all_ones == 0);  // every wave of the workgroup copies its share, tile or no tile
+    if (tx >= a->tiles_x) {
+        if (LDS)
+            __syncthreads();  // (the barrier the marching waves pass in front of their sample loop)
+        return;  // (without LDS staging the waves of a workgroup never synchronise)
+    }
     if (st.mask_all_ones != 0)  // wave-uniform (a fact about the mask: valid for any sample table)
-        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, true>(a, bl, (int)blockIdx.y, tx, st);
+        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, true, LDS>(a, bl, (int)blockIdx.y, tx, st);
     else
-        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, false>(a, bl, (int)blockIdx.y, tx, st);
+        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, false, LDS>(a, bl, (int)blockIdx.y, tx, st);
 }
 
-// ---- experimental schedules (-DGCFR_EXPERIMENTAL_SCHEDULES; profiles/r02_schedule_experiments.md) -----------------
-// Round 2 measured four alternatives to the plain grid, all bit-identical to it and all slower on this workload; they
-// are kept behind a build flag so that the evidence stays reproducible while the product library instantiates only the
-// grid and the k-split kernels.
-#ifdef GCFR_EXPERIMENTAL_SCHEDULES
-// Queue order of the persistent / strided schedules: tile index t -> (image-light pair, tile row, tile column).
-//   tile_order 0: image-major, row-major -- consecutive indices are horizontal neighbours;
-//   tile_order 1: the same with each image's tile rows centre-first;
-//   tile_order 2: centre rows first across ALL images: the heavy face-centre tiles of every image start first and
-//                 the nearly free border rows (their rays are pruned by the mask's bounding box) fill the tail;
-//   tile_order 3: image-major, row-major, but image i's tiles are rotated by i * 0.38 of an image.  The dispatcher
-//                 places consecutive workgroups on consecutive CUs, so with order 0 a CU's resident workgroups are
-//                 the SAME tile position of six different images -- six heavy face-centre waves on one SIMD, six
-//                 nearly free border waves on another.  The rotation gives every SIMD a mix of positions.
-__device__ __forceinline__ void decode_tile(ArgPtr a, int t, int &bl, int &qy, int &tx)
-{
-    const int tiles_x = a->tiles_x, tiles_y = a->tiles_y;
-    int k;
-    if (a->tile_order == 4 && tiles_y >= 4) {
-        // heavy / light mix: the middle half of every image's tile rows ("heavy": the face) and the outer half
-        // ("light") are two lists, both image-major; the queue takes two heavy rows, then one light row, so the heavy
-        // rows are spread evenly over the first three quarters of the launch and the last quarter is light rows only
-        const int BL = a->B * a->L;
-        const int q1 = tiles_y >> 2, nhr = tiles_y - 2 * q1, nlr = 2 * q1;  // heavy rows [q1, q1 + nhr)
-        const int nH = BL * nhr;
-        const int s_ = t / tiles_x;
-        tx = t - s_ * tiles_x;
-        const int mixed = 3 * (nH >> 1);  // row slots in the mixed part (nH even: nhr is even for even tiles_y ... else the tail absorbs it)
-        int hi = -1, li = -1;
-        if (s_ < mixed) {
-            const int blk = s_ / 3, pos = s_ - 3 * blk;
-            if (pos < 2)
-                hi = 2 * blk + pos;
-            else
-                li = blk;
-        } else {
-            li = (nH >> 1) + (s_ - mixed);
-        }
-        if ((nH & 1) && li >= 0 && s_ == mixed + (BL * nlr - (nH >> 1))) {  // odd heavy count: the last slot is the last heavy row
-            hi = nH - 1;
-            li = -1;
-        }
-        if (hi >= 0) {
-            bl = hi / nhr;
-            qy = q1 + (hi - bl * nhr);
-        } else {
-            bl = li / nlr;
-            const int r_ = li - bl * nlr;
-            qy = r_ < q1 ? r_ : r_ + nhr;
-        }
-        return;
-    }
-    if (a->tile_order == 2) {  // t = (k * BL + bl) * tiles_x + tx
-        const int BL = a->B * a->L;
-        const int row = t / tiles_x;
-        tx = t - row * tiles_x;
-        k = row / BL;
-        bl = row - k * BL;
-    } else {                   // t = (bl * tiles_y + k) * tiles_x + tx
-        const int per_image = tiles_x * tiles_y;
-        bl = t / per_image;
-        const int rem = t - bl * per_image;
-        k = rem / tiles_x;
-        tx = rem - k * tiles_x;
-    }
-    if (a->tile_order == 3) {  // rotate each image's tiles by a different amount (whole 4-tile groups)
-        const int per_image = tiles_x * tiles_y;
-        const int rot = ((int)((unsigned)per_image * 25033u >> 16) & ~3) | 4;  // ~0.382 of the image, a multiple of 4
-        int p = k * tiles_x + tx + (int)(((long long)bl * rot) % per_image);
-        p = p >= per_image ? p - per_image : p;
-        k = p / tiles_x;
-        tx = p - k * tiles_x;
-    }
-    qy = k;
-    if (a->tile_order == 1 || a->tile_order == 2) {  // centre rows first: mid-1, mid, mid-2, mid+1, ...
-        const int mid = (tiles_y + 1) >> 1, j = k >> 1;
-        qy = (k & 1) ? mid + j : mid - 1 - j;
-    }
-}
+// (SCHED is the schedule the kernel was built for; the product has the grid only -- the parameter keeps the kernel
+//  names of rounds 1-2 in profiles and tools: shadow_fwd_quad_kernel<16, true, 4, true, 0>.)
+enum { kSchedGrid = 0 };
 
-// Persistent schedules: the launch is exactly as many waves as the chip holds at the forced occupancy and every
-// wave marches several tiles, so one launch keeps every SIMD busy to the end -- round 1's grid of 8192 one-tile
-// waves for 6144 slots ran 1.33 rounds with a one-third-full tail and needed three more launches in flight on other
-// streams to fill it.  Two ways to hand out the tiles:
-//   DYNAMIC = false  strided: wave g marches tiles g, g + G, g + 2G, ... (G = waves in the launch).  In a
-//                    heavy-first queue order every SIMD gets one tile from each band of the cost distribution, which
-//                    balances the SIMDs statically, with no atomics;
-//   DYNAMIC = true   tile queue: the first tile is the wave's own index, every further one comes from an atomic
-//                    counter (started at G by the prepass... see shadow_fwd_impl).  Same-address device-scope
-//                    atomics complete at ~9 ns each on MI355X (measured: 8192 + 6144 of them cost the march
-//                    0.12 ms when every wave fetched its FIRST tile that way), so the counter is only touched for
-//                    the second and later tiles and polled with a plain load first (no atomic to learn "empty").
-template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool DYNAMIC>
-__device__ __forceinline__ void march_persistent(ArgPtr a)
-{
-    const int lane = threadIdx.x & 63;
-    const int gwave = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int n_waves = (int)gridDim.x * 4;
-    int t = gwave;
-    for (;;) {
-        a = launder(a);  // nothing loaded from the arguments stays live across tiles
-        if (t >= a->total_tiles)
-            break;
-        int bl, qy, tx;
-        decode_tile(a, t, bl, qy, tx);
-        const ImageStats st = reduce_image_stats(a, bl / a->L, lane, a->zb != nullptr);
-        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0>(a, bl, qy, tx, st);
-        if (DYNAMIC) {
-            int *queue = a->tflag + kQueueSlot;  // counts tiles handed out beyond the first n_waves
-            int nxt = a->total_tiles;
-            if (lane == 0) {
-                if (__hip_atomic_load(queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + n_waves < a->total_tiles)
-                    nxt = atomicAdd(queue, 1) + n_waves;
-            }
-            t = __builtin_amdgcn_readfirstlane(nxt);
-        } else {
-            t += n_waves;
-        }
-    }
-}
-
-// 1-D grid in queue order: one workgroup = four consecutive tiles of the queue, handed to the CUs by the hardware
-// dispatcher as slots free up (dynamic balancing for free, heavy tiles first with tile_order 2).
-template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE>
-__device__ __forceinline__ void march_grid_ordered(ArgPtr a)
-{
-    const int t = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (t >= a->total_tiles)
-        return;
-    int bl, qy, tx;
-    decode_tile(a, t, bl, qy, tx);
-    const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, a->zb != nullptr);
-    march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0>(a, bl, qy, tx, st);
-}
-
-#endif  // GCFR_EXPERIMENTAL_SCHEDULES
-
-enum { kSchedGrid = 0, kSchedQueue = 1, kSchedStrided = 2, kSchedGridOrdered = 3, kSchedHelp = 6 };
-
-template <int SCHED, int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE>
+template <int SCHED, int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool LDS = false>
 __device__ __forceinline__ void march_dispatch()
 {
-#ifdef GCFR_EXPERIMENTAL_SCHEDULES
-    if (SCHED == kSchedQueue)
-        march_persistent<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, true>(kernel_args());
-    else if (SCHED == kSchedStrided)
-        march_persistent<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, false>(kernel_args());
-    else if (SCHED == kSchedGridOrdered)
-        march_grid_ordered<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE>(kernel_args());
-    else
-#endif
-        march_grid<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE>(kernel_args());
+    static_assert(SCHED == kSchedGrid, "the product library has the grid schedule only");
+    march_grid<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, LDS>(kernel_args());
 }
 
 template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE, int SCHED>
@@ -2020,6 +1646,19 @@ __attribute__((amdgpu_waves_per_eu(GCFR_MARCH_ARGMIN_WAVES_PER_EU, GCFR_MARCH_AR
 {
     march_dispatch<SCHED, TILE_W, EVEN_HALF, true, DEPTH, FUSE_SHADE>();
 }
+// LDS-staged variants (see group_lds in march_tile): the same kernels with the image's mask bitmap and bounds records in LDS
+template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE, int SCHED>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(GCFR_MARCH_WAVES_PER_EU, GCFR_MARCH_WAVES_PER_EU))) void shadow_fwd_quad_lds_kernel(ShadowQuadArgs)
+{
+    march_dispatch<SCHED, TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, true>();
+}
+template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE, int SCHED>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(GCFR_MARCH_ARGMIN_WAVES_PER_EU, GCFR_MARCH_ARGMIN_WAVES_PER_EU))) void shadow_fwd_quad_argmin_lds_kernel(ShadowQuadArgs)
+{
+    march_dispatch<SCHED, TILE_W, EVEN_HALF, true, DEPTH, FUSE_SHADE, true>();
+}
 // k-split (tiny launches, one or two images): latency-bound, four gathers in flight per body, occupancy as it falls;
 // grid x = tile column, y = tile row, z = (image, light)
 template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE>
@@ -2030,105 +1669,6 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_ksplit_kernel(ShadowQuadA
     const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, a->zb != nullptr);
     march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 1>(a, bl, (int)blockIdx.y, (int)blockIdx.x, st);
 }
-
-#ifdef GCFR_EXPERIMENTAL_SCHEDULES
-// Helping across the chip (SPLIT = 4, gcfr_options.schedule 6; see march_tile): the grid schedule's workgroups -- wave
-// w of workgroup (x, y, z) owns tile (4 x + w, y) of pair z -- whose waves, once their own tile is done, keep taking
-// posted half-tiles from the board until it is empty.
-#ifndef GCFR_HELP_WAVES_PER_EU
-#define GCFR_HELP_WAVES_PER_EU 6
-#endif
-template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
-__global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(GCFR_HELP_WAVES_PER_EU, GCFR_HELP_WAVES_PER_EU))) void shadow_fwd_quad_help_kernel(ShadowQuadArgs)
-{
-    const ArgPtr a = kernel_args();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    int bl = a->bl_offset + (int)blockIdx.z, qy = (int)blockIdx.y, tx = (int)blockIdx.x * 4 + wave, duty = -1;
-    bool have = tx < a->tiles_x;
-    for (;;) {
-        if (!have) {
-            HelpArea *ha = a->help;
-            const unsigned salt = ((unsigned)blockIdx.x * 4u + (unsigned)wave + 64u * (unsigned)blockIdx.y) * 2654435761u +
-                                  (unsigned)__builtin_amdgcn_s_memtime();
-            const int s = help_take(ha, lane, __builtin_amdgcn_readfirstlane((int)(salt >> 8)));
-            if (s < 0)
-                break;
-            bl = __builtin_amdgcn_readfirstlane(GCFR_GLOAD(&ha->slot[s].bl));
-            qy = __builtin_amdgcn_readfirstlane(GCFR_GLOAD(&ha->slot[s].qy));
-            tx = __builtin_amdgcn_readfirstlane(GCFR_GLOAD(&ha->slot[s].tx));
-            duty = s;
-        }
-        have = false;
-        const ImageStats st = reduce_image_stats(a, bl / a->L, lane, a->zb != nullptr);
-        if (st.mask_all_ones != 0)
-            march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, 4, true>(a, bl, qy, tx, st, duty);
-        else
-            march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, 4, false>(a, bl, qy, tx, st, duty);
-    }
-}
-
-// work stealing inside the workgroup (SPLIT = 3, see StealShared): one workgroup = kStealTiles waves = kStealTiles
-// tiles; 1-D grid of G * BL workgroups, G = ceil(tiles per image / kStealTiles), BL = (image, light) pairs.
-// Workgroup id = j * BL + r; its wave w owns tile u = w * G + j (row-major tile list, each tile row rotated by five
-// columns per row) of pair (r + w) mod BL: the workgroup's tiles are spread evenly over the height and the width of the
-// image AND over the batch, so every workgroup carries the same mix of heavy (face, grazing light) and light (border,
-// overhead light) tiles -- its duration is the mix's mean, not its heaviest member.  After its own tile a wave keeps
-// joining the tile with the most unclaimed groups until none has kMinSteal left.
-template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
-__global__ __launch_bounds__(64 * kStealTiles)
-__attribute__((amdgpu_waves_per_eu(GCFR_STEAL_WAVES_PER_EU, GCFR_STEAL_WAVES_PER_EU))) void shadow_fwd_quad_steal_kernel(ShadowQuadArgs)
-{
-    const ArgPtr a = kernel_args();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    const int tiles_x = a->tiles_x, n_tiles = tiles_x * a->tiles_y, BL = a->B * a->L;
-    const int G = (n_tiles + kStealTiles - 1) / kStealTiles;
-    const int j = (int)blockIdx.x / BL, r = (int)blockIdx.x - j * BL;
-    StealShared &ss = steal_shared();
-    int ti = wave;
-    for (bool own = true;; own = false) {
-        if (!own) {  // the tile with the most unclaimed groups, if that justifies a second prologue
-            const int left = lane < kStealTiles ? *(volatile int *)&ss.total[lane] - *(volatile int *)&ss.next[lane] : 0;
-            const int most = -wave_min_i32(-left);
-            if (most < kMinSteal)
-                break;
-            ti = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(left == most)));
-        }
-        const int bl = (r + ti) % BL;
-        const int u = ti * G + j;
-        const int ty = u / tiles_x;
-        const int tx = (u - ty * tiles_x + 5 * ty) % tiles_x;
-        const ImageStats st = reduce_image_stats(a, bl / a->L, lane, a->zb != nullptr);
-        if (st.mask_all_ones != 0)  // (wave-uniform; the workgroup's one barrier is reached from either variant)
-            march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, 3, true>(a, bl, ty, tx, st, ti, own, u < n_tiles);
-        else
-            march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, 3, false>(a, bl, ty, tx, st, ti, own, u < n_tiles);
-    }
-}
-
-// cooperative march (SPLIT = 2): one workgroup per tile, throughput variant -- one sample at a time, forced occupancy;
-// grid x = tile column, y = tile row, z = (image, light)
-template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
-__global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(GCFR_MARCH_WAVES_PER_EU, GCFR_MARCH_WAVES_PER_EU))) void shadow_fwd_quad_coop_kernel(ShadowQuadArgs)
-{
-    const ArgPtr a = kernel_args();
-    const int bl = a->bl_offset + (int)blockIdx.z;
-    const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, a->zb != nullptr);
-    march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, 2>(a, bl, (int)blockIdx.y, (int)blockIdx.x, st);
-}
-template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
-__global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(GCFR_MARCH_ARGMIN_WAVES_PER_EU, GCFR_MARCH_ARGMIN_WAVES_PER_EU))) void shadow_fwd_quad_coop_argmin_kernel(ShadowQuadArgs)
-{
-    const ArgPtr a = kernel_args();
-    const int bl = a->bl_offset + (int)blockIdx.z;
-    const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, a->zb != nullptr);
-    march_tile<TILE_W, EVEN_HALF, true, DEPTH, FUSE_SHADE, 2>(a, bl, (int)blockIdx.y, (int)blockIdx.x, st);
-}
-#endif  // GCFR_EXPERIMENTAL_SCHEDULES
 
 }  // namespace gcfr
 
@@ -2144,12 +1684,8 @@ static inline int launch_status()
 
 extern "C" const char *gcfr_version(void)
 {
-#if defined(GCFR_COUNTERS) && defined(GCFR_EXPERIMENTAL_SCHEDULES)
-    return "gcfr-hip 0.3.0 gfx950 +counters +schedules";
-#elif defined(GCFR_COUNTERS)
+#if defined(GCFR_COUNTERS)
     return "gcfr-hip 0.3.0 gfx950 +counters";
-#elif defined(GCFR_EXPERIMENTAL_SCHEDULES)
-    return "gcfr-hip 0.3.0 gfx950 +schedules";
 #else
     return "gcfr-hip 0.3.0 gfx950";
 #endif
@@ -2190,9 +1726,7 @@ struct Knobs {
     int group = 4;       // samples per group (skip granularity / gathers in flight): 1, 2 or 4
     int ksplit = -1;     // sample-range split over the 4 waves of a workgroup: 0 off, 1 on, -1 auto
     int zbound = 1;      // depth-bound group skip (exact): 1 on, 0 off
-    int schedule = -1;   // 0 grid, 1 persistent tile queue, -1 auto
-    int tile_order = -1; // persistent schedule: 0, 1, 2, -1 auto
-    int reserved = 0;    // schedule 6 tuning: bodies | min_groups << 8 (0 = defaults)
+    int lds_stage = -1;  // mask bitmap + bounds records of the workgroup's image in LDS: 0 off, 1 on (where the shape allows), -1 auto
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     unsigned long long *counters = nullptr;
 };
@@ -2206,19 +1740,14 @@ static int resolve_options(const gcfr_options *opt, Knobs &k)
     const int tw = opt->tile_w, g = opt->group;
     if ((tw != 0 && tw != 8 && tw != 16 && tw != 32 && tw != 64) || (g != 0 && g != 1 && g != 2 && g != 4) ||
         opt->ksplit < -1 || opt->ksplit > 1 || opt->depth_bound_skip < -1 || opt->depth_bound_skip > 1 ||
-        opt->schedule < -1 || opt->schedule > 6 || opt->tile_order < -1 || opt->tile_order > 4)
-        return GCFR_ERR_INVALID_ARGUMENT;
-#ifndef GCFR_EXPERIMENTAL_SCHEDULES
-    if (opt->schedule > 0)
-        return GCFR_ERR_INVALID_ARGUMENT;  // the alternatives to the grid exist in experimental builds only
-#endif
+        opt->schedule < -1 || opt->schedule > 0 || opt->tile_order < -1 || opt->tile_order > 0 || opt->lds_stage < -1 ||
+        opt->lds_stage > 1)
+        return GCFR_ERR_INVALID_ARGUMENT;  // (schedule / tile_order: the grid is the only schedule; the fields keep the struct layout)
     k.tile_w = tw;
     k.group = g ? g : 4;
     k.ksplit = opt->ksplit;
     k.zbound = opt->depth_bound_skip < 0 ? 1 : opt->depth_bound_skip;
-    k.schedule = opt->schedule;
-    k.tile_order = opt->tile_order;
-    k.reserved = opt->reserved;
+    k.lds_stage = opt->lds_stage;
     k.ev_start = (hipEvent_t)opt->event_start;
     k.ev_stop = (hipEvent_t)opt->event_stop;
     k.counters = (unsigned long long *)opt->counters;
@@ -2231,47 +1760,29 @@ extern "C" void gcfr_options_default(gcfr_options *opt)
         return;
     *opt = gcfr_options{};
     opt->struct_size = (uint32_t)sizeof(gcfr_options);
-    opt->ksplit = opt->depth_bound_skip = opt->schedule = opt->tile_order = -1;
+    opt->ksplit = opt->depth_bound_skip = opt->schedule = opt->tile_order = opt->lds_stage = -1;
 }
 
-// workspace layout: [quad texels | partial boxes | depth-bounds records | partial depth ranges | tflag, queue | all-ones flags | help board]
+// workspace layout: [quad texels | partial boxes | depth-bounds records | partial depth ranges | tflag | all-ones flags | mask bitmaps]
 extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
 {
     if (B <= 0 || H <= 0 || W <= 0)
         return 0;
     const size_t n_stat = (size_t)n_stat_chunks(H, W);
     return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4) + (size_t)B * n_stat * 4 * sizeof(int) +
-           (size_t)B * (size_t)zb_max_tiles(H, W) * sizeof(float4) + (size_t)B * n_stat * 2 * sizeof(int) +
-           (kQueueSlot + 1) * sizeof(int) + 12 + (size_t)B * n_stat * sizeof(int)
-#ifdef GCFR_EXPERIMENTAL_SCHEDULES
-           + 16 + sizeof(HelpArea)  // the board of schedule 6
-#endif
-        ;
+           (size_t)B * (size_t)zb_stride(H, W) * sizeof(float4) + (size_t)B * n_stat * 2 * sizeof(int) +
+           (kQueueSlot + 1) * sizeof(int) + 12 + (size_t)B * n_stat * sizeof(int) + 16 +
+           (((W & 31) == 0) ? (size_t)B * (size_t)bitmap_stride_bytes(H, W) : 0);  // mask bitmaps (LDS-staged march)
 }
 
-// Number of compute units of the current device (immutable hardware fact; queried once per device and process).
-static int device_cu_count()
-{
-    static std::atomic<int> cache[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
-        return 256;
-    int n = cache[dev].load(std::memory_order_relaxed);
-    if (n == 0) {
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        cache[dev].store(n, std::memory_order_relaxed);
-    }
-    return n;
-}
-
-enum Schedule { kGrid = kSchedGrid, kQueue = kSchedQueue, kStrided = kSchedStrided, kGridOrdered = kSchedGridOrdered, kCoop = 4, kSteal = 5, kHelp = kSchedHelp, kKSplit };
+enum Schedule { kGrid = kSchedGrid, kKSplit, kGridLds };
 
 template <int TILE_W, int DEPTH, bool FUSE>
 static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argmin, Schedule sch, dim3 grid,
-                         hipStream_t st)
+                         hipStream_t st, unsigned lds_bytes)
 {
 #define GCFR_LAUNCH(KERNEL, ...) hipLaunchKernelGGL((KERNEL<TILE_W, __VA_ARGS__>), grid, dim3(256), 0, st, a)
+#define GCFR_LAUNCH_LDS(KERNEL, ...) hipLaunchKernelGGL((KERNEL<TILE_W, __VA_ARGS__>), grid, dim3(256), lds_bytes, st, a)
 #define GCFR_LAUNCH_SCHED(SCHED)                                                    \
     do {                                                                            \
         if (even_half) {                                                            \
@@ -2298,91 +1809,59 @@ static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argm
             else
                 GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, false, false, DEPTH, FUSE);
         }
-#ifdef GCFR_EXPERIMENTAL_SCHEDULES
-    } else if (sch == kHelp) {
-        if constexpr (TILE_W == 16 && DEPTH == 4) {  // (the one shape the helping kernel is built for)
-            if (even_half)
-                GCFR_LAUNCH(shadow_fwd_quad_help_kernel, true, DEPTH, FUSE);
-            else
-                GCFR_LAUNCH(shadow_fwd_quad_help_kernel, false, DEPTH, FUSE);
+    } else if (sch == kGridLds) {
+        if constexpr (TILE_W == 16 && DEPTH == 4) {  // (the default shape: the one the LDS-staged kernels are built for)
+            if (even_half) {
+                if (want_argmin)
+                    GCFR_LAUNCH_LDS(shadow_fwd_quad_argmin_lds_kernel, true, DEPTH, FUSE, kSchedGrid);
+                else
+                    GCFR_LAUNCH_LDS(shadow_fwd_quad_lds_kernel, true, DEPTH, FUSE, kSchedGrid);
+            } else {
+                if (want_argmin)
+                    GCFR_LAUNCH_LDS(shadow_fwd_quad_argmin_lds_kernel, false, DEPTH, FUSE, kSchedGrid);
+                else
+                    GCFR_LAUNCH_LDS(shadow_fwd_quad_lds_kernel, false, DEPTH, FUSE, kSchedGrid);
+            }
         }
-    } else if (sch == kSteal) {
-        if constexpr (TILE_W == 16 && DEPTH == 4) {  // (the one shape the stealing kernel is built for)
-            if (even_half)
-                hipLaunchKernelGGL((shadow_fwd_quad_steal_kernel<TILE_W, true, DEPTH, FUSE>), grid, dim3(64 * kStealTiles), 0, st, a);
-            else
-                hipLaunchKernelGGL((shadow_fwd_quad_steal_kernel<TILE_W, false, DEPTH, FUSE>), grid, dim3(64 * kStealTiles), 0, st, a);
-        }
-    } else if (sch == kCoop) {
-        if (even_half) {
-            if (want_argmin)
-                GCFR_LAUNCH(shadow_fwd_quad_coop_argmin_kernel, true, DEPTH, FUSE);
-            else
-                GCFR_LAUNCH(shadow_fwd_quad_coop_kernel, true, DEPTH, FUSE);
-        } else {
-            if (want_argmin)
-                GCFR_LAUNCH(shadow_fwd_quad_coop_argmin_kernel, false, DEPTH, FUSE);
-            else
-                GCFR_LAUNCH(shadow_fwd_quad_coop_kernel, false, DEPTH, FUSE);
-        }
-    } else if (sch == kQueue) {
-        GCFR_LAUNCH_SCHED(kSchedQueue);
-    } else if (sch == kStrided) {
-        GCFR_LAUNCH_SCHED(kSchedStrided);
-    } else if (sch == kGridOrdered) {
-        GCFR_LAUNCH_SCHED(kSchedGridOrdered);
-#endif
     } else {
         GCFR_LAUNCH_SCHED(kSchedGrid);
     }
 #undef GCFR_LAUNCH_SCHED
+#undef GCFR_LAUNCH_LDS
 #undef GCFR_LAUNCH
 }
 
 template <int TILE_W, int DEPTH>
 static void launch_quad3(const ShadowQuadArgs &a, bool even_half, bool want_argmin, Schedule sch, dim3 grid,
-                         hipStream_t st)
+                         hipStream_t st, unsigned lds_bytes)
 {
     if (a.epi.rendered)
-        launch_quad4<TILE_W, DEPTH, true>(a, even_half, want_argmin, sch, grid, st);
+        launch_quad4<TILE_W, DEPTH, true>(a, even_half, want_argmin, sch, grid, st, lds_bytes);
     else
-        launch_quad4<TILE_W, DEPTH, false>(a, even_half, want_argmin, sch, grid, st);
+        launch_quad4<TILE_W, DEPTH, false>(a, even_half, want_argmin, sch, grid, st, lds_bytes);
 }
 
 template <int TILE_W>
 static void launch_quad(ShadowQuadArgs a, bool even_half, bool want_argmin, int total_bl, Schedule sch,
-                        const Knobs &kn, hipStream_t st)
+                        const Knobs &kn, hipStream_t st, unsigned lds_bytes)
 {
     if (kn.ev_start)
         (void)hipEventRecord(kn.ev_start, st);
     auto one = [&](dim3 grid) {
+#ifndef GCFR_FAST_BUILD   // (development builds instantiate the default shape only: tools/build_variant.sh ... -DGCFR_FAST_BUILD)
         if (kn.group == 1)
-            launch_quad3<TILE_W, 1>(a, even_half, want_argmin, sch, grid, st);
+            launch_quad3<TILE_W, 1>(a, even_half, want_argmin, sch, grid, st, lds_bytes);
         else if (kn.group == 2)
-            launch_quad3<TILE_W, 2>(a, even_half, want_argmin, sch, grid, st);
+            launch_quad3<TILE_W, 2>(a, even_half, want_argmin, sch, grid, st, lds_bytes);
         else
-            launch_quad3<TILE_W, 4>(a, even_half, want_argmin, sch, grid, st);
+#endif
+            launch_quad3<TILE_W, 4>(a, even_half, want_argmin, sch, grid, st, lds_bytes);
     };
-    if (sch == kQueue || sch == kStrided) {
-        // exactly the waves the chip holds at the kernels' forced occupancy (one 4-wave workgroup = one wave per SIMD
-        // of a CU), fewer if there are fewer tiles
-        const int occ = want_argmin ? GCFR_MARCH_ARGMIN_WAVES_PER_EU : GCFR_MARCH_WAVES_PER_EU;
-        const long long resident = (long long)device_cu_count() * occ;
-        const long long need = ((long long)a.total_tiles + 3) / 4;
-        one(dim3((unsigned)(need < resident ? need : resident)));
-    } else if (sch == kGridOrdered) {
-        one(dim3((unsigned)(((long long)a.total_tiles + 3) / 4)));
-    } else {
-        const unsigned gx = (sch == kKSplit || sch == kCoop) ? (unsigned)a.tiles_x : (unsigned)((a.tiles_x + 3) / 4);
-        for (int z0 = 0; z0 < total_bl; z0 += 65535) {  // grid z is limited to 65535 (image, light) pairs per launch
-            a.bl_offset = z0;
-            const unsigned gz = (unsigned)((total_bl - z0) < 65535 ? (total_bl - z0) : 65535);
-            if (sch == kSteal) {  // 1-D grid over all (image, light) pairs at once
-                one(dim3((unsigned)(((a.tiles_x * a.tiles_y + kStealTiles - 1) / kStealTiles) * total_bl)));
-                break;
-            }
-            one(dim3(gx, (unsigned)a.tiles_y, gz));
-        }
+    const unsigned gx = (sch == kKSplit) ? (unsigned)a.tiles_x : (unsigned)((a.tiles_x + 3) / 4);  // (kGrid, kGridLds: four tiles per workgroup)
+    for (int z0 = 0; z0 < total_bl; z0 += 65535) {  // grid z is limited to 65535 (image, light) pairs per launch
+        a.bl_offset = z0;
+        const unsigned gz = (unsigned)((total_bl - z0) < 65535 ? (total_bl - z0) : 65535);
+        one(dim3(gx, (unsigned)a.tiles_y, gz));
     }
     if (kn.ev_stop)
         (void)hipEventRecord(kn.ev_stop, st);
@@ -2421,6 +1900,10 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
     // ray-steps/s) and wins above, and it degrades more gracefully when the bounds stop helping -- rough depth
     // (+15 % at noise 400, level with the kernel without bounds), all-ones masks (+4 %).  Without bounds 32x2 streams best.
     const int tile_auto = (kn.zbound && N >= 2) ? 16 : 32;
+#ifdef GCFR_FAST_BUILD   // (development builds instantiate 16 x 4 tiles and groups of four only)
+    kn.tile_w = 16;
+    kn.group = 4;
+#endif
     const int TILE_W = workspace ? (kn.tile_w ? kn.tile_w : tile_auto) : 16, TILE_H = 64 / TILE_W, WAVES = 4;
     const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
     const int quads_x = (tiles_x + WAVES - 1) / WAVES;
@@ -2441,22 +1924,32 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         const size_t n_stat = (size_t)n_stat_chunks(H, W);
         int *bbox = (int *)((char *)workspace + (size_t)B * texels * sizeof(float4));
         float4 *zb = (float4 *)((char *)bbox + (size_t)B * n_stat * 4 * sizeof(int));
-        int *zrange = (int *)(zb + (size_t)B * zb_max_tiles(H, W));  // (B, n_stat, 2)
-        int *tflag = zrange + (size_t)B * n_stat * 2;                 // [0] table flag, [kQueueSlot] tile queue
+        int *zrange = (int *)(zb + (size_t)B * zb_stride(H, W));  // (B, n_stat, 2)
+        int *tflag = zrange + (size_t)B * n_stat * 2;                 // [0] table flag
         int *mones = tflag + kQueueSlot + 4;                          // (B, n_stat) all-ones flags of the mask chunks
-#ifdef GCFR_EXPERIMENTAL_SCHEDULES
-        HelpArea *help = (HelpArea *)(((uintptr_t)(mones + (size_t)B * n_stat) + 15u) & ~(uintptr_t)15u);  // schedule 6
-#else
-        HelpArea *help = nullptr;
-#endif
+        uint32_t *bitmap = (uint32_t *)(((uintptr_t)(mones + (size_t)B * n_stat) + 15u) & ~(uintptr_t)15u);  // (MB, stride) 16-B aligned
         const bool use_zb = kn.zbound && N >= 2;
+        // Schedule.  Tiny launches (<= 2048 tiles, B <= 2 at 256^2): split every tile's sample range over the 4
+        // waves of its workgroup (finer, more uniform pieces; a quarter-range wave starts the depth-bound skip
+        // without a running minimum, so it loses from B = 4 up).  Otherwise the grid: one wave per tile -- with the
+        // image's mask bitmap and bounds records staged in LDS where they fit beside five other workgroups of the CU
+        // (26 KiB at 256 x 256; not at 512 x 512) and the rows are whole bitmap dwords.
+        const bool ksplit = (kn.ksplit < 0) ? (tiles_total <= 2048 && N >= 16) : (kn.ksplit == 1);
+        const unsigned lds_bytes = (unsigned)bitmap_stride_bytes(H, W) + (use_zb ? (unsigned)zb_stride(H, W) * 16u : 0u);
+        const bool lds_fits = ((W & 31) == 0) && (((uintptr_t)mask_u8 & 15u) == 0) && lds_bytes <= 26u * 1024u &&
+                              TILE_W == 16 && kn.group == 4;
+#ifndef GCFR_LDS_STAGE_AUTO
+#define GCFR_LDS_STAGE_AUTO 0
+#endif
+        const bool lds_stage = !ksplit && lds_fits && (kn.lds_stage < 0 ? (GCFR_LDS_STAGE_AUTO != 0) : (kn.lds_stage == 1));
+        const Schedule sch = ksplit ? kKSplit : (lds_stage ? kGridLds : kGrid);
         const int quad_blocks = (texels + 255) / 256;
         const int zb_blocks = use_zb ? (zb_max_tiles(H, W) + 3) / 4 : 0;  // sized for the finest stride
+        const int bitmap_blocks = lds_stage ? ((H * W) / 32 + 255) / 256 : 0;
         const int vec_ok = ((W & 15) == 0) && (((uintptr_t)depth & 15u) == 0) && (((uintptr_t)mask_u8 & 15u) == 0);
-        hipLaunchKernelGGL(build_quad_kernel, dim3(zb_blocks + (int)n_stat + quad_blocks, B), dim3(256), 0, st, depth,
-                           (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox, zrange, mones, zb, zb_blocks,
-                           (int)n_stat, use_zb ? 1 : 0, vec_ok, N, t_table, kn.group, tflag,
-                           kn.schedule == kSchedHelp ? help : nullptr);
+        hipLaunchKernelGGL(build_quad_kernel, dim3(zb_blocks + (int)n_stat + bitmap_blocks + quad_blocks, B), dim3(256), 0, st,
+                           depth, (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox, zrange, mones, zb, zb_blocks,
+                           (int)n_stat, use_zb ? 1 : 0, vec_ok, N, t_table, kn.group, tflag, bitmap, bitmap_blocks);
         ShadowQuadArgs a = {};
         a.zb = use_zb ? zb : nullptr;
         a.zrange = zrange;
@@ -2466,12 +1959,10 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         a.quad = (const float4 *)workspace;
         a.bbox = bbox;
         a.mask = mask_u8;
+        a.bitmap = bitmap;
         a.light_pt = light_pt;
         a.t_table = t_table;
         a.counters = kn.counters;
-        a.help = help;
-        a.help_bodies = (kn.reserved & 0xff) ? (kn.reserved & 0xff) : kHelpBodies;
-        a.help_min_groups = ((kn.reserved >> 8) & 0xff) ? ((kn.reserved >> 8) & 0xff) : kHelpMinGroups;
         a.mask_batch = mask_batch;
         a.B = B;
         a.L = L;
@@ -2480,16 +1971,7 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         a.N = N;
         a.tiles_x = tiles_x;
         a.tiles_y = tiles_y;
-        a.total_tiles = (int)tiles_total;
         a.bl_offset = 0;
-        // Schedule.  Tiny launches (<= 2048 tiles, B <= 2 at 256^2): split every tile's sample range over the 4
-        // waves of its workgroup (finer, more uniform pieces; a quarter-range wave starts the depth-bound skip
-        // without a running minimum, so it loses from B = 4 up).  Otherwise the persistent tile queue.
-        const bool ksplit = (kn.ksplit < 0) ? (tiles_total <= 2048 && N >= 16) : (kn.ksplit == 1);
-        Schedule sch = ksplit ? kKSplit : (Schedule)(kn.schedule < 0 ? kSchedGrid : kn.schedule);
-        if ((sch == kSteal || sch == kHelp) && (argmin != nullptr || TILE_W != 16 || kn.group != 4))
-            sch = kGrid;  // (work stealing / helping: inference variant, 16x4 tiles, groups of four)
-        a.tile_order = kn.tile_order < 0 ? 0 : kn.tile_order;
         a.epi.min_dist = min_dist;
         a.epi.argmin = argmin;
         a.epi.bonus = bonus;
@@ -2513,17 +1995,19 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         const bool even_half = (((W / 2) & 1) == 0) && (((H / 2) & 1) == 0);
         const bool want = argmin != nullptr;
         switch (TILE_W) {
+#ifndef GCFR_FAST_BUILD
         case 8:
-            launch_quad<8>(a, even_half, want, B * L, sch, kn, st);
+            launch_quad<8>(a, even_half, want, B * L, sch, kn, st, lds_bytes);
             break;
         case 32:
-            launch_quad<32>(a, even_half, want, B * L, sch, kn, st);
+            launch_quad<32>(a, even_half, want, B * L, sch, kn, st, lds_bytes);
             break;
         case 64:
-            launch_quad<64>(a, even_half, want, B * L, sch, kn, st);
+            launch_quad<64>(a, even_half, want, B * L, sch, kn, st, lds_bytes);
             break;
+#endif
         default:
-            launch_quad<16>(a, even_half, want, B * L, sch, kn, st);
+            launch_quad<16>(a, even_half, want, B * L, sch, kn, st, lds_bytes);
             break;
         }
         return launch_status();

@@ -62,15 +62,15 @@ typedef struct gcfr_options {
     int32_t ksplit;            /* split each tile's sample range over the 4 waves of a workgroup: 0, 1, -1 = auto by launch size */
     int32_t depth_bound_skip;  /* exact depth-bound group skip: 0, 1, -1 = auto (on) */
     int32_t schedule;          /* how tiles reach waves: 0 (= -1, auto) the 3-D grid, one workgroup per four adjacent tiles,
-                                  image-major.  1 ... 6 select the alternatives round 2 measured and rejected (persistent
-                                  waves with an atomic tile queue / strided assignment, a 1-D grid in `tile_order`, four
-                                  cooperating waves per tile, work stealing between the 16 waves of a workgroup, helping across the
-                                  chip through a board in global memory;
-                                  profiles/r02_schedule_experiments.md): they exist only in a
-                                  library built with -DGCFR_EXPERIMENTAL_SCHEDULES (gcfr_version() then contains
-                                  "+schedules"), otherwise GCFR_ERR_INVALID_ARGUMENT */
-    int32_t tile_order;        /* queue order of the experimental schedules 1-3 (0 ... 4), ignored by the grid; -1 = auto */
-    int32_t reserved;          /* 0.  (Experimental builds: thresholds of schedule 6, bodies | min_groups << 8.) */
+                                  image-major -- the only schedule.  Round 2 measured six alternatives (values 1 ... 6:
+                                  persistent waves, ordered grids, cooperating waves, work stealing, helping across the
+                                  chip; profiles/r02_schedule_experiments.md), all bit-identical and all slower; their code
+                                  left the library in round 3 and any other value is GCFR_ERR_INVALID_ARGUMENT */
+    int32_t tile_order;        /* 0 or -1 (it ordered the queues of the removed schedules; kept for the struct layout) */
+    int32_t lds_stage;         /* the march's workgroups copy their image's mask (as a bitmap) and depth-bounds records into
+                                  LDS and read them there instead of gathering them through the texture path: 0 off, 1 on
+                                  (wherever the shape allows: W % 32 == 0, 26 KiB per workgroup, default tile and group),
+                                  -1 = auto */
     void *event_start;         /* hipEvent_t recorded on `stream` immediately before the march kernel, or NULL */
     void *event_stop;          /* hipEvent_t recorded immediately after it, or NULL */
     uint64_t *counters;        /* DEVICE array of GCFR_N_COUNTERS + 4 * (number of tiles) u64: the march kernel adds its work

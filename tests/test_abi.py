@@ -39,7 +39,10 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     L = _lib.load()
     assert L.gcfr_shadow_fwd(None, None, 1, None, 1, 1, 256, 256, 160, None, 0.0, None, None, None, None, 0, None, None) == -1
     # workspace: quad texels + 4 statistics chunks per 256x256 image (box 16 B + depth range 8 B) + depth-bounds records
-    assert L.gcfr_shadow_workspace_bytes(8, 256, 256) == 8 * 257 * 257 * 16 + 8 * 4 * 16 + 8 * (33 * 33 + 1) * 16 + 8 * 4 * 8 + 65 * 4 + 12 + 8 * 4 * 4
+    # (round 3: the records' per-image stride is a whole number of 1-KiB pieces -- 1090 -> 1152 records -- and one mask bitmap of
+    #  H*W/8 bytes per image follows, both for the LDS-staged march)
+    assert L.gcfr_shadow_workspace_bytes(8, 256, 256) == (8 * 257 * 257 * 16 + 8 * 4 * 16 + 8 * 1152 * 16 + 8 * 4 * 8 + 65 * 4 + 12
+                                                          + 8 * 4 * 4 + 16 + 8 * 8192)
     assert L.gcfr_light_prep(None, 1, 1, 0.0, 4013.0, None, None, None) == -1
     assert L.gcfr_shade_fwd(None, None, None, None, None, None, 1, 1, 8, 8, 0.5, None, None, None, None, None) == -1
     # the inference image side: null planes, a diagnostic output without its input, mask batch neither 1 nor B, in-place border fix
@@ -59,7 +62,7 @@ def test_options_struct_defaults_and_layout():
     o = _lib.Options()
     L.gcfr_options_default(ctypes.byref(o))
     assert o.struct_size == ctypes.sizeof(_lib.Options) == 56
-    assert (o.tile_w, o.group, o.ksplit, o.depth_bound_skip, o.schedule, o.tile_order) == (0, 0, -1, -1, -1, -1)
+    assert (o.tile_w, o.group, o.ksplit, o.depth_bound_skip, o.schedule, o.tile_order, o.lds_stage) == (0, 0, -1, -1, -1, -1, -1)
     assert not o.event_start and not o.event_stop and not o.counters
     # argument validation happens on the host before any launch, so it can be exercised without a GPU: dummy non-null
     # pointers, a valid shape, then a bad options struct
@@ -72,8 +75,8 @@ def test_options_struct_defaults_and_layout():
     assert L.gcfr_shadow_fwd(*args, ctypes.byref(bad)) == -1
     bad = _lib.options(schedule=7)
     assert L.gcfr_shadow_fwd(*args, ctypes.byref(bad)) == -1
-    if not _lib.has_experimental_schedules():          # the product build has the grid schedule only
-        assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(schedule=2))) == -1
+    assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(schedule=2))) == -1      # the grid is the only schedule
+    assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(tile_order=2))) == -1
 
 
 def test_product_has_no_cpu_fallback():

@@ -46,8 +46,7 @@ CASES = list(all_cases())
 
 
 def _experimental():
-    from geomconsistentfr_amd import _lib
-    return _lib.has_experimental_schedules()
+    return False      # the schedules round 2 rejected left the library in round 3 (they build from commit 4db51f3)
 
 
 @pytest.mark.parametrize("name,case", CASES, ids=[c[0] for c in CASES])

@@ -27,11 +27,9 @@ def dev():
 
 
 def _sched(cases):
-    """Keep the (.., schedule, ..) cases the loaded library can run: the alternatives to the grid schedule exist only in
-    experimental builds (tools/build_variant.sh experimental -DGCFR_EXPERIMENTAL_SCHEDULES; run the suite with
-    GCFR_HIP_LIB pointing at it to cover them)."""
-    from geomconsistentfr_amd import _lib
-    return cases if _lib.has_experimental_schedules() else [c for c in cases if max(c[1] if isinstance(c, tuple) else c, 0) == 0]
+    """Keep the (.., schedule, ..) cases the library can run: the grid is the only schedule since round 3 (the
+    alternatives round 2 measured and rejected were removed; they build from commit 4db51f3)."""
+    return [c for c in cases if max(c[1] if isinstance(c, tuple) else c, 0) == 0]
 
 
 def to_dev(a):
@@ -481,85 +479,51 @@ def test_non_increasing_sample_tables_fall_back_to_the_full_march(t0, dt, N):
         assert np.array_equal(am.cpu().numpy()[lit], am_o[lit]), ws
 
 
-def test_work_stealing_schedule_gives_the_grid_bits():
-    """gcfr_options.schedule = 5 (the sixteen waves of a workgroup steal sample groups from each other's tiles, minima
-    merged through LDS): min_dist, and everything the fused epilogue derives from it, equal the grid schedule's bits --
-    ragged sizes (waves without a tile of their own), face / all-ones / empty / sparse masks, grazing and overhead
-    lights, rough depth, several lights per image."""
-    from geomconsistentfr_amd import RenderParams, _lib
-    from geomconsistentfr_amd.block import light_prep, render_fwd, shadow_min_distance
-    if not _lib.has_experimental_schedules():
-        pytest.skip("schedule 5 exists in -DGCFR_EXPERIMENTAL_SCHEDULES builds only (measured and rejected, see "
-                    "profiles/r02_schedule_experiments.md); run with GCFR_HIP_LIB=<experimental build> to cover it")
-    rng = np.random.default_rng(5)
-    for (B, Hs, Ws, N, L) in [(2, 256, 256, 160, 1), (3, 66, 130, 48, 2), (2, 130, 70, 37, 3), (1, 512, 512, 320, 2), (5, 96, 128, 80, 1)]:
-        r, c = np.mgrid[0:Hs, 0:Ws]
-        dome = 90.0 * np.sqrt(np.clip(1.0 - ((c - 0.5 * Ws) / (0.48 * Ws)) ** 2 - ((r - 0.5 * Hs) / (0.5 * Hs)) ** 2, 0.0, None))
-        depth = np.stack([(dome * (0.5 + 0.5 * (b % 3)) + (30.0 if b % 2 else 1.0) * rng.random((Hs, Ws))).astype(np.float32) for b in range(B)])
-        ell = ((((c - 0.5 * Ws) / (0.42 * Ws)) ** 2 + ((r - 0.5 * Hs) / (0.45 * Hs)) ** 2) < 1)
-        kinds = [ell, np.ones_like(ell), rng.random((Hs, Ws)) > 0.4, np.zeros_like(ell), ell & (rng.random((Hs, Ws)) > 0.05)]
-        mask = np.stack([kinds[(b + Hs) % len(kinds)] for b in range(B)]).astype(np.uint8)
-        lights = rng.standard_normal((B, L, 3)).astype(np.float32)
-        lights[:, 0, 2] = np.abs(lights[:, 0, 2]) * 0.05                     # grazing: long marches, the heavy tiles
-        lights[-1, -1] = (0.001, -0.002, 1.0)                                # overhead: end point = the light's own xy
-        prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
-        _, pt = light_prep(to_dev(lights), prm)
-        for zb in (1, 0):
-            ref, _ = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, want_argmin=False,
-                                         options=_lib.options(schedule=0, depth_bound_skip=zb))
-            for rep in range(3):                                             # (claims race differently every launch)
-                md, _ = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, want_argmin=False,
-                                            options=_lib.options(schedule=5, depth_bound_skip=zb))
-                bad = (md != ref).nonzero()
-                assert torch.equal(md, ref), (B, Hs, Ws, zb, rep, bad[:5].tolist())
-        # fused epilogue
-        alb = to_dev(rng.random((B, 3, Hs, Ws)).astype(np.float32))
-        nrm = rng.standard_normal((B, 3, Hs, Ws)).astype(np.float32)
-        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
-        amb = to_dev((0.3 + 0.4 * rng.random((B, L))).astype(np.float32))
-        outs = [render_fwd(to_dev(depth), to_dev(mask), to_dev(lights), amb, to_dev(nrm), alb, prm, want_argmin=False, options=_lib.options(schedule=sc))
-                for sc in (0, 5)]
-        for k in outs[0]:
-            if torch.is_tensor(outs[0][k]):
-                assert torch.equal(outs[0][k], outs[1][k]), (k, B, Hs, Ws)
-
-
-def test_helping_schedule_gives_the_grid_bits():
-    """gcfr_options.schedule = 6 (experimental builds; measured and rejected): heavy tiles post the far half of their remaining samples on a board in
-    global memory, waves that have finished take them; partial minima meet in two-party rendezvous, the last arriver
-    finishes the tile.  min_dist and everything the fused epilogue derives from it equal the grid schedule's bits, on
-    every launch (who helps whom differs from run to run)."""
-    from geomconsistentfr_amd import RenderParams, _lib
-    from geomconsistentfr_amd.block import light_prep, render_fwd, shadow_min_distance
-    if not _lib.has_experimental_schedules():
-        pytest.skip("schedule 6 exists in -DGCFR_EXPERIMENTAL_SCHEDULES builds only (profiles/r02_schedule_experiments.md, J)")
-    rng = np.random.default_rng(6)
-    for (B, Hs, Ws, N, L) in [(8, 256, 256, 160, 1), (3, 66, 130, 48, 2), (2, 130, 70, 37, 3), (1, 512, 512, 320, 2), (5, 96, 128, 80, 1)]:
-        r, c = np.mgrid[0:Hs, 0:Ws]
-        dome = 90.0 * np.sqrt(np.clip(1.0 - ((c - 0.5 * Ws) / (0.48 * Ws)) ** 2 - ((r - 0.5 * Hs) / (0.5 * Hs)) ** 2, 0.0, None))
-        depth = np.stack([(dome * (0.5 + 0.5 * (b % 3)) + (30.0 if b % 2 else 1.0) * rng.random((Hs, Ws))).astype(np.float32) for b in range(B)])
-        ell = ((((c - 0.5 * Ws) / (0.42 * Ws)) ** 2 + ((r - 0.5 * Hs) / (0.45 * Hs)) ** 2) < 1)
-        kinds = [ell, np.ones_like(ell), rng.random((Hs, Ws)) > 0.4, np.zeros_like(ell), ell & (rng.random((Hs, Ws)) > 0.05)]
-        mask = np.stack([kinds[(b + Hs) % len(kinds)] for b in range(B)]).astype(np.uint8)
-        lights = rng.standard_normal((B, L, 3)).astype(np.float32)
-        lights[:, 0, 2] = np.abs(lights[:, 0, 2]) * 0.05                     # grazing: long marches, the heavy tiles
-        lights[-1, -1] = (0.001, -0.002, 1.0)
-        prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
-        _, pt = light_prep(to_dev(lights), prm)
-        for zb in (1, 0):
-            ref, _ = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, want_argmin=False,
-                                         options=_lib.options(schedule=0, depth_bound_skip=zb))
-            for rep in range(4):
-                md, _ = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, want_argmin=False,
-                                            options=_lib.options(schedule=6, depth_bound_skip=zb))
-                bad = (md != ref).nonzero()
-                assert torch.equal(md, ref), (B, Hs, Ws, zb, rep, bad[:5].tolist())
-        alb = to_dev(rng.random((B, 3, Hs, Ws)).astype(np.float32))
-        nrm = rng.standard_normal((B, 3, Hs, Ws)).astype(np.float32)
-        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
-        amb = to_dev((0.3 + 0.4 * rng.random((B, L))).astype(np.float32))
-        outs = [render_fwd(to_dev(depth), to_dev(mask), to_dev(lights), amb, to_dev(nrm), alb, prm, want_argmin=False,
-                           options=_lib.options(schedule=sc)) for sc in (0, 6, 6)]
-        for k in outs[0]:
-            if torch.is_tensor(outs[0][k]):
-                assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k]), (k, B, Hs, Ws)
+@pytest.mark.parametrize("Hs,Ws,N,dt", [(64, 96, 40, 0.02), (128, 128, 80, 0.01), (256, 256, 160, 0.005), (96, 64, 33, 0.024)])
+def test_lds_staged_march_is_bit_identical(Hs, Ws, N, dt):
+    """gcfr_options.lds_stage = 1 (round 3): the workgroup's mask -- as a bitmap -- and its depth-bounds records are read
+    from LDS instead of being gathered through the texture path.  Same cells, same records, same arithmetic: min_dist
+    and argmin must equal the global-path kernel's and the C oracle's bits -- smooth / rough / offset / negative surfaces,
+    ellipse, all-ones and random masks, one mask shared by the batch, with and without the depth-bound skip, the
+    inference and the training (argmin) kernels, stand-alone and with the fused shading epilogue."""
+    import c_oracle
+    from geomconsistentfr_amd import RenderParams, _lib, light_prep, shadow_min_distance
+    from geomconsistentfr_amd.block import render_fwd
+    rng = np.random.default_rng(Hs * 7 + Ws)
+    r, c = np.mgrid[0:Hs, 0:Ws]
+    bump = 0.35 * Hs * np.exp(-(((c - 0.5 * Ws) / (0.25 * Ws)) ** 2 + ((r - 0.5 * Hs) / (0.3 * Hs)) ** 2))
+    depth = np.stack([bump, bump + 3 * rng.random((Hs, Ws)), 30 * rng.random((Hs, Ws)), bump - 0.15 * Hs, -bump,
+                      bump + 1000.0]).astype(np.float32)
+    B = depth.shape[0]
+    ell = ((((c - 0.5 * Ws) / (0.4 * Ws)) ** 2 + ((r - 0.5 * Hs) / (0.45 * Hs)) ** 2) < 1)
+    mask = np.stack([ell, ell, np.ones_like(ell), rng.random((Hs, Ws)) > 0.2, ell, rng.random((Hs, Ws)) > 0.7]).astype(np.uint8)
+    lights = np.array([[[0.75, 0.0, 0.66], [0.1, -0.2, 0.97]]] * B, np.float32)
+    lights[1::2, 0] = [-0.5, 0.47, 0.72]
+    lights[2, 1] = [0.99, 0.05, 0.05]                                  # grazing
+    prm = RenderParams(n_samples=N, t0=0.025, dt=dt)
+    _, pt = light_prep(to_dev(lights), prm)
+    tt = c_oracle.sample_table(0.025, dt, N)
+    pt_o = c_oracle.light_prep(lights.reshape(-1, 3), clamp_z_min=0.0)[1].reshape(B, 2, 3)
+    md_o, am_o = c_oracle.shadow_min_distance(depth, mask, pt_o, tt)
+    lit = md_o < 1e5
+    for zb in (1, 0):
+        for want in (True, False):
+            md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, want_argmin=want, use_workspace=True,
+                                         options=_lib.options(lds_stage=1, ksplit=0, depth_bound_skip=zb))
+            assert np.array_equal(md.cpu().numpy(), md_o), (zb, want)
+            if want:
+                assert np.array_equal(am.cpu().numpy()[lit], am_o[lit]), zb
+    # one mask for the whole batch (mask_batch = 1): per-image bitmaps collapse to one
+    md_s, _ = c_oracle.shadow_min_distance(depth, np.repeat(mask[3:4], B, 0), pt_o, tt)
+    md, _ = shadow_min_distance(to_dev(depth), to_dev(mask[3:4]), pt, prm, want_argmin=False, use_workspace=True,
+                                options=_lib.options(lds_stage=1, ksplit=0))
+    assert np.array_equal(md.cpu().numpy(), md_s)
+    # fused epilogue: every output of the two variants is the same bits
+    amb = to_dev((0.3 + 0.4 * rng.random((B, 2))).astype(np.float32))
+    nrm = to_dev(rng.standard_normal((B, 3, Hs, Ws)).astype(np.float32))
+    alb = to_dev(rng.random((B, 3, Hs, Ws)).astype(np.float32))
+    outs = [render_fwd(to_dev(depth), to_dev(mask), to_dev(lights), amb, nrm, alb, prm, want_argmin=True,
+                       options=_lib.options(lds_stage=ls, ksplit=0)) for ls in (0, 1)]
+    for k in outs[0]:
+        if outs[0][k] is not None:
+            assert torch.equal(outs[0][k], outs[1][k]), k

@@ -34,9 +34,9 @@ def _kernel_metadata(tmp_path):
 @pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-readelf")), reason="needs the ROCm LLVM tools")
 def test_march_kernels_fit_their_forced_occupancy_without_scratch(tmp_path):
     k = _kernel_metadata(tmp_path)
-    inference = {n: v for n, v in k.items() if n.startswith("shadow_fwd_quad_kernel<")}
-    training = {n: v for n, v in k.items() if n.startswith("shadow_fwd_quad_argmin_kernel<")}
-    assert len(inference) >= 16 and len(training) >= 16, sorted(k)
+    inference = {n: v for n, v in k.items() if n.startswith(("shadow_fwd_quad_kernel<", "shadow_fwd_quad_lds_kernel<"))}
+    training = {n: v for n, v in k.items() if n.startswith(("shadow_fwd_quad_argmin_kernel<", "shadow_fwd_quad_argmin_lds_kernel<"))}
+    assert len(inference) >= 16 + 4 and len(training) >= 16 + 4, sorted(k)      # + the LDS-staged variants of the default shape
     for n, v in inference.items():
         assert v["vgpr"] <= 80, (n, v)                      # 512 / 6 waves, granule 8
     for n, v in training.items():

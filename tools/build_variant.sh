@@ -1,5 +1,6 @@
 #!/bin/bash
-# build an experimental variant of the library: tools/build_variant.sh <name> [-DMACRO=..]...  -> geomconsistentfr_amd/lib/<name>.so
+# build a variant of the library: tools/build_variant.sh <name> [-DMACRO=..]...  -> geomconsistentfr_amd/lib/<name>.so
+# (-DGCFR_FAST_BUILD instantiates the default tile shape / group only: ~4x faster to compile, for A/B work)
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 C=$REPO/geomconsistentfr_amd/csrc
