@@ -70,6 +70,9 @@ _SIGNATURES = {
     "gcfr_light_prep_bwd": (_i, [_p, _i, _i, _f, _f, _p, _p, _p, _p]),
     "gcfr_inference_images_u8": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p]),
     "gcfr_fix_border_u8": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "gcfr_assemble_batch_u8": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "gcfr_masked_metrics_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i]),
+    "gcfr_masked_metrics_u8": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, ctypes.c_size_t, _p]),
 }
 
 

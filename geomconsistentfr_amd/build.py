@@ -11,7 +11,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgcfr_hip.so")
-SOURCES = ["gcfr_shadow.hip", "gcfr_shade.hip", "gcfr_backward.hip", "gcfr_normals.hip", "gcfr_postprocess.hip"]
+SOURCES = ["gcfr_shadow.hip", "gcfr_shade.hip", "gcfr_backward.hip", "gcfr_normals.hip", "gcfr_postprocess.hip",
+           "gcfr_dataset.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fno-fast-math", "-munsafe-fp-atomics", "-Wall"]
 

@@ -308,12 +308,10 @@ struct ShadeBwdArgs {
     const float *g_normals_out;  // (B,3,H,W) upstream grad on the returned unit normals, may be null
 };
 
-#ifndef GCFR_BWD_WAVES_PER_EU
-#define GCFR_BWD_WAVES_PER_EU 2
-#endif
-template <bool FUSED>
-__global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(FUSED ? GCFR_BWD_WAVES_PER_EU : 4))) void shade_bwd_kernel(ShadeBwdArgs a)
+// Stand-alone shading backward (gcfr_shade_bwd: the three-kernel path), f64 chain rule, any number of lights per image;
+// writes grad_normals / grad_min_dist for the stencil and march backward kernels that follow it.  (Its fused form of
+// rounds 1-2 -- the march backward inlined in this loop, 200 VGPRs -- was replaced by render_bwd_multi_light_kernel.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void shade_bwd_kernel(ShadeBwdArgs a)
 {
     const int H = a.H, W = a.W, L = a.L;
     const size_t P = (size_t)H * W;
@@ -326,18 +324,9 @@ __attribute__((amdgpu_waves_per_eu(FUSED ? GCFR_BWD_WAVES_PER_EU : 4))) void sha
     const float *zimg = a.depth + (size_t)b * P;
     float *gz = a.grad_depth + (size_t)b * P;
     const float zb = zimg[pp];
-    double nx, ny, nz;
-    if (FUSED) {  // the f32 unit normal the forward epilogue fed to shade_pixel()
-        float n[3];
-        unit_normal(a.nrm, zimg, r, c, n);
-        nx = n[0];
-        ny = n[1];
-        nz = n[2];
-    } else {
-        nx = a.normals[((size_t)b * 3 + 0) * P + pp];
-        ny = a.normals[((size_t)b * 3 + 1) * P + pp];
-        nz = a.normals[((size_t)b * 3 + 2) * P + pp];
-    }
+    const double nx = a.normals[((size_t)b * 3 + 0) * P + pp];
+    const double ny = a.normals[((size_t)b * 3 + 1) * P + pp];
+    const double nz = a.normals[((size_t)b * 3 + 2) * P + pp];
     double nn = sqrt(nx * nx + ny * ny + nz * nz);
     nn = nn > 1e-12 ? nn : 1e-12;
     const double inv_nn = fast_rcp64(nn);
@@ -384,17 +373,6 @@ __attribute__((amdgpu_waves_per_eu(FUSED ? GCFR_BWD_WAVES_PER_EU : 4))) void sha
             const float gmd = (float)(dw * (4.0 * e * (1.0 - e)) * (inv_ope2 * inv_ope));
             if (a.grad_min_dist)
                 a.grad_min_dist[o] = gmd;
-            if (FUSED) {  // ray-march backward through the argmin sample, right here
-                const int k = a.argmin[o];
-                if (k >= 0 && k < a.N && gmd != 0.0f) {
-                    double gC[3];
-                    shadow_bwd_pixel(zimg, gz, a.t_table, H, W, r, c, a.light_pt[3 * bl + 0], a.light_pt[3 * bl + 1],
-                                     a.light_pt[3 * bl + 2], k, gmd, gC);
-                    red[0] += gC[0];
-                    red[1] += gC[1];
-                    red[2] += gC[2];
-                }
-            }
             // full = amb + I*max(dot,0)  (T8:366)
             const double ddot = (dot > 0.0) ? dfull * (double)a.intensity : 0.0;
             const double dn0 = ddot * u0, dn1 = ddot * u1, dn2 = ddot * u2;  // d n_hat
@@ -416,19 +394,9 @@ __attribute__((amdgpu_waves_per_eu(FUSED ? GCFR_BWD_WAVES_PER_EU : 4))) void sha
         block_reduce_atomic4(red, a.grad_light_pt + 3 * (size_t)bl, a.grad_ambient + bl);
     }
     if (live) {
-        if (FUSED) {  // stencil backward: grad w.r.t. the unit normal (rounded to f32 as the unfused path stores it)
-            double h0 = (double)(float)gn0, h1 = (double)(float)gn1, h2 = (double)(float)gn2;
-            if (a.g_normals_out) {
-                h0 += a.g_normals_out[((size_t)b * 3 + 0) * P + p];
-                h1 += a.g_normals_out[((size_t)b * 3 + 1) * P + p];
-                h2 += a.g_normals_out[((size_t)b * 3 + 2) * P + p];
-            }
-            normals_bwd_pixel(a.nrm, zimg, gz, r, c, h0, h1, h2);
-        } else {
-            a.grad_normals[((size_t)b * 3 + 0) * P + p] = (float)gn0;
-            a.grad_normals[((size_t)b * 3 + 1) * P + p] = (float)gn1;
-            a.grad_normals[((size_t)b * 3 + 2) * P + p] = (float)gn2;
-        }
+        a.grad_normals[((size_t)b * 3 + 0) * P + p] = (float)gn0;
+        a.grad_normals[((size_t)b * 3 + 1) * P + p] = (float)gn1;
+        a.grad_normals[((size_t)b * 3 + 2) * P + p] = (float)gn2;
         a.grad_albedo[((size_t)b * 3 + 0) * P + p] = (float)ga0;
         a.grad_albedo[((size_t)b * 3 + 1) * P + p] = (float)ga1;
         a.grad_albedo[((size_t)b * 3 + 2) * P + p] = (float)ga2;
@@ -439,7 +407,7 @@ __attribute__((amdgpu_waves_per_eu(FUSED ? GCFR_BWD_WAVES_PER_EU : 4))) void sha
 // ----------------------------------------------------------------------------------------------
 // fused backward, one light per image (the training shape: T8 has one predicted light per face)
 //
-// Same per-pixel device functions and the same numbers as shade_bwd_kernel<true>, but staged so that each phase
+// Same per-pixel device functions as the stand-alone kernels, but staged so that each phase
 // keeps only its own operands alive: (1) shading backward -- writes grad_albedo at once and leaves three f32 normal
 // gradients, the own-depth term, the four reduction partials and the f32 gradient on the minimum distance;
 // (2) ray-march backward through the argmin sample; (3) block reduction; (4) normals-stencil backward.  The
@@ -676,7 +644,12 @@ __attribute__((amdgpu_waves_per_eu(GCFR_BWD1_WAVES_PER_EU, GCFR_BWD1_WAVES_PER_E
             atomicAdd(gz + corners.idx[3], v3);
         }
     }
+
     if (live) {
+        // (Round 3 measured gathering the tile's 84 halo pixels as well -- one atomic per halo pixel instead of up to five
+        //  per edge pixel, 0.9 -> 0.33 atomic elements per pixel: 145 -> 138 us on a dense upstream gradient, but 93 -> 96 us
+        //  inside the training step, whose masked gradient leaves half the tiles without stencil work, and 20 B more
+        //  scratch; HBM traffic unchanged at 293-300 MB.  Not kept: profiles/r03_backward_ab.txt.)
         if (!have_sg) {
             // nothing to scatter
         } else if (on_image_border)  // clamped targets: all eight by atomics, as the stand-alone kernel does
@@ -764,6 +737,137 @@ __global__ void light_prep_bwd_kernel(const float *__restrict__ light_raw, int n
     grad_light_raw[3 * i + 2] = (float)(r2 * zpass);
 }
 
+// ----------------------------------------------------------------------------------------------
+// fused backward, several lights per image (BASELINE configs[4]: 18 lights per face), restaged in round 3
+//
+// Round 1's fused kernel (shade_bwd_kernel<true>) runs its shading backward in f64 inside the loop over lights and keeps
+// every loop-invariant -- unit normal, albedo, six f64 accumulators -- alive across the inlined march backward: 200
+// VGPRs, two waves per SIMD.  This kernel is the single-light kernel's staging applied per light: stage (1) in f32
+// exactly as render_bwd_single_light_kernel evaluates it (so L = 1 and L > 1 give the same numbers), its operands
+// RE-READ per light (normal, albedo: three cached loads each, instead of 14 registers across the march backward), and
+// only seven f32 / one f64 accumulators carried through stage (2).  One lane per pixel, 256-pixel blocks; the corner
+// atomics go out at once and the stencil backward scatters (8 atomics per pixel, once per pixel whatever L).
+// 144 VGPRs, three waves per SIMD, no scratch (round 1's kernel: 200 VGPRs, two waves; forcing it to four spilled 268 B).
+// ----------------------------------------------------------------------------------------------
+#ifndef GCFR_BWDL_WAVES_PER_EU
+#define GCFR_BWDL_WAVES_PER_EU 3
+#endif
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(GCFR_BWDL_WAVES_PER_EU, GCFR_BWDL_WAVES_PER_EU))) void render_bwd_multi_light_kernel(ShadeBwdArgs a)
+{
+    const int H = a.H, W = a.W, L = a.L;
+    const size_t P = (size_t)H * W;
+    const int b = blockIdx.y;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = p < P;
+    const size_t pp = live ? p : 0;
+    const int r = (int)(pp / W), c = (int)(pp - (size_t)r * W);
+    const float *zimg = a.depth + (size_t)b * P;
+    float *gz = a.grad_depth + (size_t)b * P;
+    float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f;     // gradient on the unit normal, summed over the lights
+    float ga0 = 0.0f, ga1 = 0.0f, ga2 = 0.0f;  // gradient on the albedo
+    double gzb = 0.0;                          // own-depth terms of all stages
+    float npre[3] = {0.0f, 0.0f, 1.0f};        // without the forward's normals: the stencil is evaluated ONCE, in front of the loop
+    if (live && !a.normals)
+        unit_normal(a.nrm, zimg, r, c, npre);
+#pragma clang loop unroll(disable)
+    for (int l = 0; l < L; ++l) {
+        const int bl = b * L + l;
+        const float Cxf = a.light_pt[3 * bl + 0], Cyf = a.light_pt[3 * bl + 1], Czf = a.light_pt[3 * bl + 2];
+        double red[4] = {0.0, 0.0, 0.0, 0.0};  // dC.xyz, d ambient of this light
+        float gmd = 0.0f;
+        if (live) {  // ---- (1) shading backward, f32 as the forward (see render_bwd_single_light_kernel) ----
+#pragma clang fp contract(fast)
+            const size_t o = (size_t)bl * P + pp;
+            const float gr0 = a.g_rendered ? a.g_rendered[((size_t)bl * 3 + 0) * P + pp] : 0.0f;
+            const float gr1 = a.g_rendered ? a.g_rendered[((size_t)bl * 3 + 1) * P + pp] : 0.0f;
+            const float gr2 = a.g_rendered ? a.g_rendered[((size_t)bl * 3 + 2) * P + pp] : 0.0f;
+            const float gfin = a.g_final ? a.g_final[o] : 0.0f, gw = a.g_w ? a.g_w[o] : 0.0f, gfull = a.g_full ? a.g_full[o] : 0.0f;
+            if (gr0 != 0.0f || gr1 != 0.0f || gr2 != 0.0f || gfin != 0.0f || gw != 0.0f || gfull != 0.0f) {
+                const float x = (float)c - W / 2.0f, y = H / 2.0f - (float)r;
+                const float zb = zimg[pp];
+                float n[3];
+                if (a.normals) {
+                    n[0] = a.normals[((size_t)b * 3 + 0) * P + pp];
+                    n[1] = a.normals[((size_t)b * 3 + 1) * P + pp];
+                    n[2] = a.normals[((size_t)b * 3 + 2) * P + pp];
+                } else {
+                    n[0] = npre[0];
+                    n[1] = npre[1];
+                    n[2] = npre[2];
+                }
+                float nn = __builtin_sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                nn = nn > 1e-12f ? nn : 1e-12f;
+                const float inv_nn = 1.0f / nn;
+                const float n0 = n[0] * inv_nn, n1 = n[1] * inv_nn, n2 = n[2] * inv_nn;
+                const float amb = a.ambient[bl];
+                const float lx = Cxf - x, ly = Cyf - y, lz = Czf - zb;
+                float ln = __builtin_sqrtf(lx * lx + ly * ly + lz * lz);
+                ln = ln > 1e-12f ? ln : 1e-12f;
+                const float inv_ln = 1.0f / ln;
+                const float u0 = lx * inv_ln, u1 = ly * inv_ln, u2 = lz * inv_ln;
+                const float dot = n0 * u0 + n1 * u1 + n2 * u2;
+                const float full = amb + a.intensity * (dot > 0.0f ? dot : 0.0f);
+                const float e = expf(-a.min_dist[o]);  // T8:517
+                const float ope = 1.0f + e;
+                const float inv_ope = 1.0f / ope, inv_ope2 = inv_ope * inv_ope;
+                const float w = 1.0f - 4.0f * e * inv_ope2;
+                const float fin = w * full + (1.0f - w) * amb;
+                const float al0 = a.albedo[((size_t)b * 3 + 0) * P + pp];
+                const float al1 = a.albedo[((size_t)b * 3 + 1) * P + pp];
+                const float al2 = a.albedo[((size_t)b * 3 + 2) * P + pp];
+                ga0 += gr0 * fin;  // rendered = albedo * final  (T8:520-522)
+                ga1 += gr1 * fin;
+                ga2 += gr2 * fin;
+                const float dfin = (gr0 * al0 + gr1 * al1 + gr2 * al2) + gfin;
+                const float dw = dfin * (full - amb) + gw;  // final = w*full + (1-w)*amb (T8:518)
+                const float dfull = dfin * w + gfull;
+                red[3] = (double)(dfin * (1.0f - w) + dfull);
+                gmd = dw * (4.0f * e * (1.0f - e)) * (inv_ope2 * inv_ope);  // dw/dd = 4e(1-e)/(1+e)^3 (T8:517)
+                const float ddot = (dot > 0.0f) ? dfull * a.intensity : 0.0f;  // full = amb + I*max(dot,0) (T8:366)
+                const float dn0 = ddot * u0, dn1 = ddot * u1, dn2 = ddot * u2;
+                const float du0 = ddot * n0, du1 = ddot * n1, du2 = ddot * n2;
+                const float nd = n0 * dn0 + n1 * dn1 + n2 * dn2;  // n_hat = n/|n|
+                h0 += (dn0 - n0 * nd) * inv_nn;
+                h1 += (dn1 - n1 * nd) * inv_nn;
+                h2 += (dn2 - n2 * nd) * inv_nn;
+                const float ud = u0 * du0 + u1 * du1 + u2 * du2;  // l_hat = l/|l|, l = C - P
+                const float dl2 = (du2 - u2 * ud) * inv_ln;
+                red[0] = (double)((du0 - u0 * ud) * inv_ln);
+                red[1] = (double)((du1 - u1 * ud) * inv_ln);
+                red[2] = (double)dl2;
+                gzb -= (double)dl2;
+            }
+        }
+        if (live) {  // ---- (2) ray-march backward through the argmin sample ----
+            const int k = a.argmin[(size_t)bl * P + pp];
+            if (k >= 0 && k < a.N && gmd != 0.0f) {
+                double gC[3];
+                shadow_bwd_pixel(zimg, gz, a.t_table, H, W, r, c, Cxf, Cyf, Czf, k, gmd, gC, &gzb, nullptr);
+                red[0] += gC[0];
+                red[1] += gC[1];
+                red[2] += gC[2];
+            }
+        }
+        block_reduce_atomic4(red, a.grad_light_pt + 3 * (size_t)bl, a.grad_ambient + bl);  // ---- (3) ----
+    }
+    if (live) {  // ---- (4) stencil backward, once per pixel ----
+        double g0 = (double)h0, g1 = (double)h1, g2 = (double)h2;
+        if (a.g_normals_out) {
+            g0 += a.g_normals_out[((size_t)b * 3 + 0) * P + p];
+            g1 += a.g_normals_out[((size_t)b * 3 + 1) * P + p];
+            g2 += a.g_normals_out[((size_t)b * 3 + 2) * P + p];
+        }
+        if (g0 != 0.0 || g1 != 0.0 || g2 != 0.0)
+            normals_bwd_pixel(a.nrm, zimg, gz, r, c, g0, g1, g2);
+        a.grad_albedo[((size_t)b * 3 + 0) * P + p] = ga0;
+        a.grad_albedo[((size_t)b * 3 + 1) * P + p] = ga1;
+        a.grad_albedo[((size_t)b * 3 + 2) * P + p] = ga2;
+        if (gzb != 0.0)
+            atomicAdd(gz + p, (float)gzb);
+    }
+}
+
 }  // namespace gcfr
 
 using namespace gcfr;
@@ -822,7 +926,7 @@ extern "C" int gcfr_shade_bwd(const float *normals, const float *depth, const fl
     a.W = W;
     a.intensity = intensity;
     const size_t P = (size_t)H * W;
-    hipLaunchKernelGGL(shade_bwd_kernel<false>, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0,
+    hipLaunchKernelGGL(shade_bwd_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0,
                        (hipStream_t)stream, a);
     return launch_status();
 }
@@ -862,7 +966,7 @@ extern "C" int gcfr_render_bwd(const float *depth, const float *albedo, const fl
     a.W = W;
     a.intensity = intensity;
     a.argmin = argmin;
-    a.normals = (L == 1) ? normals_fwd : nullptr;  // (the multi-light kernel recomputes)
+    a.normals = normals_fwd;  // the unit normals the forward wrote, or NULL: recomputed from the depth stencil
     a.t_table = t_table;
     a.N = N;
     a.nrm.depth = depth;
@@ -885,7 +989,7 @@ extern "C" int gcfr_render_bwd(const float *depth, const float *albedo, const fl
                            (hipStream_t)stream, a);
     }
     else
-        hipLaunchKernelGGL(shade_bwd_kernel<true>, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0,
+        hipLaunchKernelGGL(render_bwd_multi_light_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0,
                            (hipStream_t)stream, a);
     return launch_status();
 }

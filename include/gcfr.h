@@ -158,6 +158,11 @@ int gcfr_shade_fwd(const float *normals, const float *depth, const float *albedo
  * camera matrix, normalised 3x3 Sobel with replicate padding, cross, normalise) -- parity UNPINNED.
  *   depth (B,H,W) f32;  fx, fy, cx, cy from intrinsic_matrix (T8:571-577);  z_offset added in f32
  *   negate_y: 1 = apply T8:354;  normals (B,3,H,W) f32 out, unit length
+ * Numerical contract (also of the normals the fused epilogue of gcfr_render_from_depth_fwd computes and of `normals_out`):
+ * NOT bit-reproducible against another evaluation order -- the reference's chain is f64 with an unspecified conv2d
+ * summation order, and the kernels use reciprocals / v_rsq + Newton steps instead of IEEE divisions -- but within 4 f32
+ * ulp of the f64 restatement (oracle/normals_restatement.py) after rounding to f32; a non-finite depth cell makes
+ * exactly the normals non-finite whose clamped 3 x 3 neighbourhood contains it (tests/test_gpu_normals.py).
  */
 int gcfr_normals_fwd(const float *depth, int32_t B, int32_t H, int32_t W, double fx, double fy, double cx,
                      double cy, float z_offset, int32_t negate_y, float *normals, void *stream);
@@ -303,6 +308,38 @@ int gcfr_inference_images_u8(const float *input_hwc, const float *rendered, cons
  */
 int gcfr_fix_border_u8(const uint8_t *img_hwc, const uint8_t *face_mask_u8, int32_t mask_batch, int32_t B, int32_t H,
                        int32_t W, uint8_t *out_hwc, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Data formats either side of the block: batch assembly from the bytes load_data() reads, and the
+ * MATLAB evaluation scripts' two metrics as device reductions.
+ * ------------------------------------------------------------------------------------------- */
+
+/*
+ * One training batch from the uint8 arrays as stored on disk -- what
+ * train_raytracing_relighting_CelebAHQ_DSSIM_8x.py:545-556 (load_data) and :607-615 (batch slicing) do in float64 on
+ * the host for the whole dataset, here per batch on the device:
+ *   images_u8     (B,H,W,3) u8  imread(jpg)                      -> images     (B,H,W,3) f32 = f32(u8 / 255.0)      T8:550, 618
+ *   depth_mask_u8 (B,H,W)   u8  imread(depth mask)               -> masks      (B,H,W)   f32 = u8 / 255.0           T8:546, 610
+ *   face_mask_u8  (B,H,W)   u8  imread(face mask)                -> masks_fill (B,H,W)   f32 = (max(face, depth) > 128) ? 1 : 0   T8:552-556, 612
+ *   albedo_u8     (B,H,W)   u8  imread(grey albedo)              -> albedo     (B,H,W)   f32 = u8 / 255.0           T8:551, 615
+ * masks / masks_fill (with face_mask_u8) / albedo (with albedo_u8) may be NULL.
+ */
+int gcfr_assemble_batch_u8(const uint8_t *images_u8, const uint8_t *depth_mask_u8, const uint8_t *face_mask_u8,
+                           const uint8_t *albedo_u8, int32_t B, int32_t H, int32_t W, float *images, float *masks,
+                           float *masks_fill, float *albedo, void *stream);
+
+/*
+ * Masked MSE (MSE_MP.m:24) and masked DSSIM (DSSIM_MP_RGB.m:24-26) of B image pairs, f64:
+ *   recon_u8, gt_u8 (B,H,W,3) u8 RGB;  mask_u8 (MB,H,W) u8 (MB = 1 or B), all scaled by 1/255.0 as the scripts do;
+ *   mse_out, dssim_out (B) f64, either may be NULL;
+ *   workspace: gcfr_masked_metrics_workspace_bytes(B,H,W) bytes of device scratch, 8-byte aligned.
+ * DSSIM follows MATLAB ssim()'s documented defaults on an M x N x 3 volume (Gaussian sigma 1.5, radius 5, replicate padding
+ * on all three axes, K = (0.01, 0.03), dynamic range 1).  PARITY UNPINNED: MATLAB is not available to the builder.
+ */
+size_t gcfr_masked_metrics_workspace_bytes(int32_t B, int32_t H, int32_t W);
+int gcfr_masked_metrics_u8(const uint8_t *recon_u8, const uint8_t *gt_u8, const uint8_t *mask_u8, int32_t mask_batch,
+                           int32_t B, int32_t H, int32_t W, double *mse_out, double *dssim_out, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

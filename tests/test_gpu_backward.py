@@ -313,3 +313,62 @@ def test_fused_backward_wrapped_column_runs_at_widths_not_multiple_of_16(Ws):
     assert np.abs(gd_3[:, :, Ws - 1]).max() > 0 and np.abs(gd_3[:, :, 0]).max() > 0
     assert np.abs(gd_f - gd_3).max() <= 2e-6 * scale, (np.abs(gd_f - gd_3).max(), scale)
     np.testing.assert_allclose(grads[0][2], grads[1][2], rtol=1e-5, atol=1e-6 * np.abs(grads[1][2]).max())
+
+
+def test_config5_backward_18_lights_512_equals_eighteen_single_light_backwards():
+    """BASELINE configs[4] shape, backward: one 512 x 512 face, 18 lights, 320 samples through ONE launch of the restaged
+    multi-light kernel (gcfr_render_bwd, L = 18; round 3: per-light f32 staging, 145 VGPRs / 3 waves per SIMD instead of
+    200 / 2) against the sum of eighteen autograd runs of the single-light path, which the golden gradients of the
+    reference pin (test_fused_backward_matches_reference_autograd).  A materialised-oracle autograd at this size would
+    need ~26 GB of host memory per (face, light) -- the oracle pins the single-light kernel at sizes it can hold
+    (test_backward_matches_materialised_oracle_small), this test carries that to the multi-light kernel at full size."""
+    import bench
+    from geomconsistentfr_amd import RenderParams, _lib
+    from geomconsistentfr_amd import block as R
+    L_ = _lib.load()
+    d = dev()
+    S, L, N = 512, 18, 320
+    depth_np, mask_np, albedo_np, _n, light_np, amb_np = bench.synth_faces_sized(1, 5, S, L)
+    rng = np.random.default_rng(55)
+    depth = torch.from_numpy(depth_np).to(d)
+    mask = torch.from_numpy(mask_np).to(d)
+    albedo = torch.from_numpy(albedo_np).to(d)
+    light = torch.from_numpy(light_np).to(d)
+    amb = torch.from_numpy(amb_np).to(d)
+    prm = RenderParams(n_samples=N, dt=0.8 / N)
+    cam = (3140.0, 3140.0, S / 2.0, S / 2.0, 1610.0)
+    K = camera(3140.0, S, S).to(d)
+    G = torch.from_numpy(rng.standard_normal((1, L, 3, S, S)).astype(np.float32)).to(d) * mask[:, None, None].float()
+    Gw = torch.from_numpy(rng.standard_normal((1, L, S, S)).astype(np.float32)).to(d)
+    o = R.render_fwd(depth, mask, light, amb, None, albedo, prm, want_argmin=True, camera=cam)
+    g_alb, g_depth = torch.empty_like(albedo), torch.zeros_like(depth)
+    g_pt = torch.zeros((1, L, 3), dtype=torch.float64, device=d)
+    g_amb = torch.zeros((1, L), dtype=torch.float64, device=d)
+    tt = R.sample_table(prm, d)
+    for normals_fwd in (o["surface_normals"], None):          # the forward's normals read back / recomputed from the stencil
+        g_depth.zero_(), g_pt.zero_(), g_amb.zero_()
+        _lib.check(L_.gcfr_render_bwd(depth.data_ptr(), albedo.data_ptr(), o["light_pt"].data_ptr(), amb.data_ptr(),
+                                      o["minimum_distance"].data_ptr(), o["argmin"].data_ptr(),
+                                      None if normals_fwd is None else normals_fwd.data_ptr(), 1, L, S, S, N, tt.data_ptr(),
+                                      *cam[:4], cam[4], 1, 0.5, Gw.data_ptr(), None, None, G.data_ptr(), None, g_alb.data_ptr(),
+                                      g_depth.data_ptr(), g_pt.data_ptr(), g_amb.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream), "gcfr_render_bwd")
+        torch.cuda.synchronize()
+        if normals_fwd is not None:
+            first = (g_alb.clone(), g_depth.clone(), g_pt.clone(), g_amb.clone())
+    for a_, b_ in zip(first, (g_alb, g_depth, g_pt, g_amb)):   # both normal sources: the same numbers up to atomic order
+        assert float((a_ - b_).abs().max()) <= 2e-6 * float(a_.abs().max())
+    sum_alb, sum_depth = torch.zeros_like(albedo), torch.zeros_like(depth)
+    for l in range(L):
+        dl = depth[:, None].clone().requires_grad_()
+        al = albedo.clone().requires_grad_()
+        li = light[:, l].clone().requires_grad_()
+        am = amb[:, l].clone().requires_grad_()
+        r = R.render_from_depth(dl, al, li, am, K, cam[4], mask, prm)
+        ((r["rendered_images"] * G[:, l]).sum() + (r["shadow_mask_weights"] * Gw[:, l]).sum()).backward()
+        sum_alb += al.grad
+        sum_depth += dl.grad[:, 0]
+        np.testing.assert_allclose(g_amb[:, l].cpu().numpy(), am.grad.cpu().numpy(), rtol=2e-5)
+    assert float(sum_depth.abs().max()) > 0
+    assert float((g_alb - sum_alb).abs().max()) <= 1e-5 * float(sum_alb.abs().max())
+    assert float((g_depth - sum_depth).abs().max()) <= 1e-5 * float(sum_depth.abs().max())

@@ -83,3 +83,35 @@ def test_fused_normals_forward_is_bit_identical_to_the_three_stage_path():
         r = R.render_from_depth(depth[:, None], albedo, light[:, 0], amb[:, 0], K, 1610.0, mask, prm)
     assert torch.equal(r["rendered_images"], a["rendered_images"][:, 0])
     assert torch.equal(r["surface_normals"], n)
+
+
+def test_forward_normals_tolerance_contract_and_non_finite_cells():
+    """include/gcfr.h: forward normals are NOT bit-pinned (kornia's summation order is unspecified and the kernel uses
+    reciprocals / rsq + Newton steps instead of IEEE divisions, round-2 advisor note): the contract is `within 4 f32 ulp of
+    the f64 restatement after rounding to f32`, and a non-finite depth cell poisons exactly the normals whose 3 x 3
+    neighbourhood (clamped at the border) contains it -- the same pixels as in the restatement."""
+    from geomconsistentfr_amd.normals import depth_to_normals
+    from normals_restatement import depth_to_normals as oracle_normals
+    H, W, f, off = 96, 128, 1570.0, 1610.0
+    r, c = np.mgrid[0:H, 0:W]
+    depth = (60 * np.exp(-(((c - 64) / 40.0) ** 2 + ((r - 48) / 30.0) ** 2)) + 2 * np.sin(c / 5.0) * np.cos(r / 7.0)).astype(np.float32)
+    depth = np.stack([depth, depth[::-1].copy()])[:, None]
+    K = camera(f, H, W)
+    n_ref = oracle_normals(torch.from_numpy(depth) + off, K)
+    n_ref = torch.cat([n_ref[:, 0:1], -n_ref[:, 1:2], n_ref[:, 2:3]], 1).numpy()
+    n = depth_to_normals(torch.from_numpy(depth).to(DEV), K.to(DEV), z_offset=off).cpu().numpy()
+    ulp = np.spacing(np.maximum(np.abs(n_ref), 2.0 ** -10).astype(np.float32))
+    assert (np.abs(n.astype(np.float64) - n_ref) <= 4 * ulp).all()
+    # non-finite cells: interior NaN, interior +inf, a NaN in the corner (replicate padding folds three offsets onto it)
+    bad = depth.copy()
+    bad[0, 0, 40, 50] = np.nan
+    bad[0, 0, 70, 20] = np.inf
+    bad[1, 0, 0, 0] = np.nan
+    nb_ref = oracle_normals(torch.from_numpy(bad) + off, K).numpy()
+    nb = depth_to_normals(torch.from_numpy(bad).to(DEV), K.to(DEV), z_offset=off).cpu().numpy()
+    poisoned_ref = ~np.isfinite(nb_ref).all(axis=1)
+    poisoned = ~np.isfinite(nb).all(axis=1)
+    assert poisoned_ref.sum() == 9 + 9 + 4
+    np.testing.assert_array_equal(poisoned, poisoned_ref)
+    ok = ~poisoned
+    assert (np.abs(nb.astype(np.float64) - np.concatenate([nb_ref[:, 0:1], -nb_ref[:, 1:2], nb_ref[:, 2:3]], 1))[np.broadcast_to(ok[:, None], nb.shape)] <= 1e-6).all()

@@ -527,3 +527,39 @@ def test_lds_staged_march_is_bit_identical(Hs, Ws, N, dt):
     for k in outs[0]:
         if outs[0][k] is not None:
             assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("lds", [0, 1])
+def test_non_finite_inputs_never_make_the_skipping_kernels_differ_from_the_plain_one(lds):
+    """Round-2 advisor note: with a checked sample table the depth-bounds record offset is used unchecked (`zb_trusted`);
+    a raw buffer load answers an out-of-range offset with zeros -- the record "surface is exactly z = 0", a wrong skip --
+    so exactness rests on every rounded cell lying inside the image.  It does whatever the inputs: samples sit on the
+    segment pixel -> clamped end point, and a non-finite end point (NaN / inf light, `finite_ray` false) collapses the
+    segment onto the pixel itself.  Adversarial inputs -- NaN / +-inf depth cells, NaN and inf light components, a
+    light exactly above the image centre -- through the workspace kernels (bounds on and off, global and LDS-staged)
+    against the plain direct-gather kernel, which has no bounds machinery: identical bits, NaNs in the same places."""
+    from geomconsistentfr_amd import RenderParams, _lib, shadow_min_distance
+    rng = np.random.default_rng(77)
+    Hs, Ws, N = 128, 128, 80
+    r, c = np.mgrid[0:Hs, 0:Ws]
+    base = (40 * np.exp(-(((c - 64) / 30.0) ** 2 + ((r - 64) / 35.0) ** 2)) + rng.random((Hs, Ws))).astype(np.float32)
+    depth = np.stack([base] * 6)
+    depth[1, 30:34, 40:44] = np.nan
+    depth[2, 90, 17] = np.inf
+    depth[2, 20, 100] = -np.inf
+    depth[3, ::16, ::16] = np.nan
+    depth[4, 64, 64] = 1e30
+    mask = (rng.random((6, Hs, Ws)) > 0.15).astype(np.uint8)
+    pt = np.array([[[3000.0, 500.0, 2600.0]], [[-2500.0, 1500.0, 2700.0]], [[100.0, -3500.0, 1900.0]],
+                   [[np.nan, 100.0, 3000.0]], [[2000.0, np.inf, 3000.0]], [[0.0, 0.0, 4013.0]]], np.float32)
+    prm = RenderParams(n_samples=N, t0=0.025, dt=0.01)
+    ref_md, ref_am = shadow_min_distance(to_dev(depth), to_dev(mask), to_dev(pt), prm, use_workspace=False)
+    for zb in (1, 0):
+        md, am = shadow_min_distance(to_dev(depth), to_dev(mask), to_dev(pt), prm, use_workspace=True,
+                                     options=_lib.options(ksplit=0, depth_bound_skip=zb, lds_stage=lds))
+        a, b = md.cpu().numpy(), ref_md.cpu().numpy()
+        np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+        ok = ~np.isnan(b)
+        assert np.array_equal(a[ok], b[ok]), (zb, lds)
+        assert np.array_equal(am.cpu().numpy()[ok], ref_am.cpu().numpy()[ok]), (zb, lds)
+    assert np.isnan(ref_md.cpu().numpy()[3]).all() and np.isfinite(ref_md.cpu().numpy()[0]).all()
