@@ -364,9 +364,14 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
+FORCED_REGIONS = 0       # --regions N: exactly N timed regions (profiling runs want 1); 0 = the rule below
+
+
 def regions_needed(steps, est_ms_per_step):
     """A fenced region shorter than ~200 ms is dominated by its fixed fence / drain cost and is ONE sample (round 2's
     record rested on a 1.03 ms region): repeat it >= 25 times, bounded to ~2 s in total."""
+    if FORCED_REGIONS > 0:
+        return FORCED_REGIONS
     region_ms = steps * est_ms_per_step
     if region_ms >= 200.0:
         return 1
@@ -856,6 +861,9 @@ def main():
                          "train_depth = depth / light / albedo of a freshly initialised RelightNet (use with --from-depth --argmin)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-worst-case", action="store_true", help="skip the secondary workloads of the headline line")
+    ap.add_argument("--regions", type=int, default=0,
+                    help="number of fenced timed regions of `steps` steps (0 = auto: repeated when a region is shorter than 200 ms; "
+                         "profiling scripts pass 1)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than GPUs (ranks share GPUs, collectives over gloo): rehearses the launch path")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous + one collective + JSON only (runs without a GPU)")
@@ -891,6 +899,8 @@ def main():
         a.steps = 3000 if a.workload == "render" else 20
     if a.warmup is None:
         a.warmup = 50 if a.workload == "render" else 6
+    global FORCED_REGIONS
+    FORCED_REGIONS = max(0, a.regions)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a))                     # this process becomes the launcher of N ranks
     rk = Ranks(a)

@@ -29,17 +29,16 @@ class Options(ctypes.Structure):
     """include/gcfr.h `gcfr_options`: per-call knobs and hooks of the forward entry points (never change a result
     bit).  Build one with `options(...)`; pass it as `options=` to the block functions / RenderFwdPlan."""
     _fields_ = [("struct_size", ctypes.c_uint32), ("tile_w", _i), ("group", _i), ("ksplit", _i),
-                ("depth_bound_skip", _i), ("schedule", _i), ("tile_order", _i), ("lds_stage", _i), ("twopass_bodies", _i), ("twopass_min_groups", _i),
+                ("depth_bound_skip", _i), ("schedule", _i), ("tile_order", _i), ("lds_stage", _i),
                 ("event_start", _p), ("event_stop", _p), ("counters", _p)]
 
 
 def options(tile_w=0, group=0, ksplit=-1, depth_bound_skip=-1, schedule=-1, tile_order=-1, event_start=None,
-            event_stop=None, counters=None, lds_stage=-1, twopass_bodies=0, twopass_min_groups=0) -> Options:
+            event_stop=None, counters=None, lds_stage=-1) -> Options:
     o = Options()
     load().gcfr_options_default(ctypes.byref(o))
     o.tile_w, o.group, o.ksplit, o.depth_bound_skip = tile_w, group, ksplit, depth_bound_skip
     o.schedule, o.tile_order, o.lds_stage = schedule, tile_order, lds_stage
-    o.twopass_bodies, o.twopass_min_groups = twopass_bodies, twopass_min_groups
     o.event_start, o.event_stop, o.counters = event_start, event_stop, counters
     return o
 

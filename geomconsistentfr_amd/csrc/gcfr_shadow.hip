@@ -593,18 +593,6 @@ __device__ inline void build_stats_block(int chunk, int b, const float *__restri
 //   (f) the mask bitmap of the LDS-staged march (build_bitmap_block), when that variant will run,
 //   (a) the repack of depth into 2x2-neighbourhood texels; its first block also runs (b) the optional light
 //       preparation and (e) the sample-table check.
-// Two-pass schedule (gcfr_options.schedule = 1, round 3): what the first pass leaves behind for a tile it suspends.
-// state[lane] = the lane's running minimum of S (f32 bits; S >= 0 or +inf, so bit 31 is free) | any_masked << 31.
-struct SuspSlot {
-    int bl, qy, tx, k_resume;
-    unsigned state[64];
-};
-struct SuspArea {
-    int n, pad[3];         // tiles suspended by this call's first pass (zeroed by the prepass; may exceed the capacity)
-    SuspSlot slot[1];      // [susp_cap]
-};
-constexpr int kSuspCap = 2048;
-
 // The mask as a bitmap (LDS-staged march): thread i of an image packs cells [32 i, 32 i + 32) into dword i.
 __device__ inline void build_bitmap_block(int block, int b, const uint8_t *__restrict__ mask, int H, int W,
                                           uint32_t *__restrict__ bitmap)
@@ -633,7 +621,7 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
                                                          int want_z, int vec_ok, int N,
                                                          const double *__restrict__ t_table, int group,
                                                          int *__restrict__ tflag, uint32_t *__restrict__ bitmap,
-                                                         int bitmap_blocks, SuspArea *__restrict__ susp)
+                                                         int bitmap_blocks)
 {
     const int Wp = W + 1, Hp = H + 1;
     const int b = blockIdx.y;
@@ -666,11 +654,8 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
             }
         }
         const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0)
             tflag[0] = all_ok ? 1 : 0;
-            if (susp)
-                susp->n = 0;  // (two-pass schedule: nothing suspended yet)
-        }
     }
     if (pl.light_raw && qb == 0) {
         for (int l = threadIdx.x; l < pl.L; l += blockDim.x)
@@ -725,8 +710,6 @@ struct ShadowQuadArgs {
     int32_t mask_batch, B, L, H, W, N;
     int32_t tiles_x, tiles_y;  // tiles per image row / column
     int32_t bl_offset;         // first (image, light) index of this launch (grid z is limited to 65535)
-    SuspArea *susp;            // two-pass schedule: tiles suspended by the first pass, resumed by the second
-    int32_t susp_cap, budget_bodies, budget_min_groups;
     MarchEpilogueArgs epi;
 };
 
@@ -849,7 +832,9 @@ __device__ inline ImageStats reduce_image_stats(ArgPtr a, int b, int lane, bool 
 // (Round 2 also built and measured four more schedules on this tile function -- persistent waves with a tile queue or a
 //  strided assignment, four cooperating waves per tile, work stealing inside the workgroup, helping across the chip;
 //  all bit-identical, all slower: profiles/r02_schedule_experiments.md.  Their code was removed from the product source
-//  in round 3; it builds from commit 4db51f3 with -DGCFR_EXPERIMENTAL_SCHEDULES.)
+//  in round 3; it builds from commit 4db51f3 with -DGCFR_EXPERIMENTAL_SCHEDULES.  Round 3 added the one round 2 had left
+//  untried -- a budgeted first pass plus a second launch that resumes the unfinished tiles four ways from warm minima --
+//  measured it (bit-identical, 79-87 us against 68: profiles/r03_twopass_ab.md) and took it out again: commit 7e0eaa4.)
 #ifndef GCFR_TILE_INLINE
 #define GCFR_TILE_INLINE __forceinline__
 #endif
@@ -889,24 +874,13 @@ __device__ inline int fresh_lane_id()
     return l;
 }
 
-template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, int SPLIT, bool ALL_ONES = false, bool LDS = false,
-          int MODE = 0>
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, int SPLIT, bool ALL_ONES = false, bool LDS = false>
 __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy, const int tx,
-                                           const ImageStats &st, const int resume_slot = -1)
+                                           const ImageStats &st)
 {
     constexpr int TILE_H = 64 / TILE_W;
     static_assert(SPLIT == 0 || SPLIT == 1, "SPLIT: 0 = one wave per tile, 1 = the workgroup's four waves split the sample range");
     static_assert(!(LDS && SPLIT != 0), "the LDS-staged march is a throughput variant: one wave per tile");
-    // MODE 1 / 2: the two passes of gcfr_options.schedule = 1 (one batch at a time: a launch ends when its heaviest tile
-    // ends).  Pass 1 is the grid march with a BUDGET: a wave that has executed `budget_bodies` sample groups and still has
-    // `budget_min_groups` to go writes its lanes' running minima and `any_masked` flags and the index it stopped at into a
-    // slot of the suspend area and leaves WITHOUT the epilogue.  Pass 2 gives every suspended tile a workgroup: its four
-    // waves repeat the prologue, start from the saved minima -- a warm bound for the depth-bound skip of all four, which
-    // is what the cold k-split of whole tiles lacked in round 2 -- split the REST of the sample range four ways with four
-    // gathers in flight per body (the k-split kernel's latency-oriented body), merge through LDS and run the epilogue.
-    // A minimum needs no order, so min_dist is the one-pass march's bit for bit; inference kernels only (no argmin).
-    static_assert(MODE == 0 || (MODE == 1 && SPLIT == 0 && !WANT_ARGMIN && !LDS) || (MODE == 2 && SPLIT == 1 && !WANT_ARGMIN),
-                  "MODE 1 = budgeted first pass (grid march), MODE 2 = resuming second pass (k-split march)");
     const int H = a->H, W = a->W, L = a->L;
     // Wave-uniform read-only inputs are read through the CONSTANT address space: in the persistent schedule the
     // previous tile's stores and the queue atomic precede these loads in program order, so through a plain global
@@ -922,10 +896,8 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // sample range of this wave
     constexpr bool KSPLIT = SPLIT == 1;
-    const SuspSlot *const rslot = (MODE == 2) ? &a->susp->slot[resume_slot] : nullptr;
-    const int k_base = (MODE == 2) ? __builtin_amdgcn_readfirstlane(rslot->k_resume) : 0;  // pass 2: the rest of the range
-    const int chunk = KSPLIT ? (a->N - k_base + 3) >> 2 : a->N;
-    const int k_lo = KSPLIT ? k_base + wave * chunk : 0;
+    const int chunk = KSPLIT ? (a->N + 3) >> 2 : a->N;
+    const int k_lo = KSPLIT ? wave * chunk : 0;
     const int N = KSPLIT ? min(a->N, k_lo + chunk) : a->N;  // exclusive upper bound ("N" below)
 #ifdef GCFR_COUNTERS
     unsigned cnt[kCntUsed] = {};
@@ -975,12 +947,6 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     float prevS = __builtin_inff();  // the running minimum replaced last (distance-tie resolution, see epilogue)
     int prevk = -1;
     bool any_masked = false;
-    [[maybe_unused]] int n_bodies = 0;  // (MODE 1) sample groups executed so far
-    if (MODE == 2) {  // the first pass' result for this pixel: a valid bound for every wave of the workgroup
-        const unsigned sv = rslot->state[threadIdx.x & 63];
-        bestS = __builtin_bit_cast(float, sv & 0x7fffffffu);
-        any_masked = (sv >> 31) != 0u;
-    }
 
     // Candidate sample range.  A sample can only be unmasked if its rounded cell lies inside the bounding
     // box of the mask's non-zero cells, i.e. if s(t) = start + t*delta lies inside that box inflated by
@@ -1038,7 +1004,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         const int w_lo = __builtin_amdgcn_readfirstlane(wave_min_i32(lane_lo));
         const int w_hi = -__builtin_amdgcn_readfirstlane(wave_min_i32(-lane_hi));
         const int nb = max(k_begin, w_lo), ne = min(k_end, w_hi + 1);
-        any_masked = any_masked || (nb > k_begin) || (ne < k_end);  // some sample of this wave's range was pruned
+        any_masked = (nb > k_begin) || (ne < k_end);  // some sample of this wave's range was pruned
         k_begin = nb;
         k_end = ne;
     }
@@ -1295,8 +1261,6 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         constexpr int GCFR_BODY_CHUNK = KSPLIT ? DEPTH : 1;  // (KSPLIT here: SPLIT == 1 only)
         if (run_body) {
           GCFR_COUNT(kCntBodies, 1);
-          if (MODE == 1)
-              ++n_bodies;
 #ifdef GCFR_COUNTERS
 #pragma unroll
           for (int j = 0; j < DEPTH; ++j)
@@ -1452,26 +1416,6 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
             break;
         if (!group(k0 + DEPTH, bufB, bufA, true))  // the termination test runs every other group (it costs ~18 VALU)
             break;
-        if (MODE == 1 && n_bodies >= a->budget_bodies && k0 + (2 + a->budget_min_groups) * DEPTH <= k_end) {
-            // over budget with a long way to go: suspend (pass 2 finishes the tile four ways, see MODE above)
-            SuspArea *const sa = a->susp;
-            int idx = a->susp_cap;
-            if (lane == 0)
-                idx = atomicAdd(&sa->n, 1);
-            idx = __builtin_amdgcn_readfirstlane(idx);
-            if (idx < a->susp_cap) {
-                SuspSlot *const ss = &sa->slot[idx];
-                if (lane == 0) {
-                    ss->bl = bl;
-                    ss->qy = qy;
-                    ss->tx = tx;
-                    ss->k_resume = k0 + 2 * DEPTH;
-                }
-                ss->state[lane] = __builtin_bit_cast(unsigned, bestS) | (any_masked ? 0x80000000u : 0u);
-                return;  // no epilogue here
-            }
-            n_bodies = -(1 << 28);  // the area is full: this tile marches on and never asks again
-        }
     }
     }
 
@@ -1644,7 +1588,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 
 // Grid schedule: one workgroup = four horizontally adjacent tiles (one per wave), 3-D grid x = tile-quad column,
 // y = tile row, z = (image, light) -- no integer divisions, dispatch order image-major with row-major tiles.
-template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool LDS = false, int MODE = 0>
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool LDS = false>
 __device__ __forceinline__ void march_grid(ArgPtr a)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1660,9 +1604,9 @@ __device__ __forceinline__ void march_grid(ArgPtr a)
         return;  // (without LDS staging the waves of a workgroup never synchronise)
     }
     if (st.mask_all_ones != 0)  // wave-uniform (a fact about the mask: valid for any sample table)
-        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, true, LDS, MODE>(a, bl, (int)blockIdx.y, tx, st);
+        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, true, LDS>(a, bl, (int)blockIdx.y, tx, st);
     else
-        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, false, LDS, MODE>(a, bl, (int)blockIdx.y, tx, st);
+        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, false, LDS>(a, bl, (int)blockIdx.y, tx, st);
 }
 
 // (SCHED is the schedule the kernel was built for; the product has the grid only -- the parameter keeps the kernel
@@ -1700,28 +1644,6 @@ __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(GCFR_MARCH_ARGMIN_WAVES_PER_EU, GCFR_MARCH_ARGMIN_WAVES_PER_EU))) void shadow_fwd_quad_argmin_lds_kernel(ShadowQuadArgs)
 {
     march_dispatch<SCHED, TILE_W, EVEN_HALF, true, DEPTH, FUSE_SHADE, true>();
-}
-// The two passes of gcfr_options.schedule = 1 (see MODE in march_tile): the budgeted grid march, then one workgroup per
-// suspended tile (1-D grid of susp_cap workgroups; those beyond the count leave at once).
-template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
-__global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(GCFR_MARCH_WAVES_PER_EU, GCFR_MARCH_WAVES_PER_EU))) void shadow_fwd_quad_budget_kernel(ShadowQuadArgs)
-{
-    march_grid<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, false, 1>(kernel_args());
-}
-template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE>
-__global__ __launch_bounds__(256) void shadow_fwd_quad_resume_kernel(ShadowQuadArgs)
-{
-    const ArgPtr a = kernel_args();
-    typedef const __attribute__((address_space(4))) int *ConstI32Ptr;
-    const int n = min(((ConstI32Ptr)(unsigned long long)&a->susp->n)[0], a->susp_cap);
-    const int slot = (int)blockIdx.x;
-    if (slot >= n)
-        return;
-    const ConstI32Ptr hdr = (ConstI32Ptr)(unsigned long long)&a->susp->slot[slot];
-    const int bl = hdr[0], qy = hdr[1], tx = hdr[2];
-    const ImageStats st = reduce_image_stats(a, bl / a->L, threadIdx.x & 63, a->zb != nullptr);
-    march_tile<TILE_W, EVEN_HALF, false, DEPTH, FUSE_SHADE, 1, false, false, 2>(a, bl, qy, tx, st, slot);
 }
 // k-split (tiny launches, one or two images): latency-bound, four gathers in flight per body, occupancy as it falls;
 // grid x = tile column, y = tile row, z = (image, light)
@@ -1790,8 +1712,6 @@ struct Knobs {
     int group = 4;       // samples per group (skip granularity / gathers in flight): 1, 2 or 4
     int ksplit = -1;     // sample-range split over the 4 waves of a workgroup: 0 off, 1 on, -1 auto
     int zbound = 1;      // depth-bound group skip (exact): 1 on, 0 off
-    int schedule = -1;   // 0 one launch (the grid), 1 two passes (budgeted grid march + resumed tail: one batch at a time), -1 auto
-    int twopass_bodies = 0, twopass_min_groups = 0;  // schedule 1: the first pass' budget (0 = defaults)
     int lds_stage = -1;  // mask bitmap + bounds records of the workgroup's image in LDS: 0 off, 1 on (where the shape allows), -1 auto
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     unsigned long long *counters = nullptr;
@@ -1806,18 +1726,14 @@ static int resolve_options(const gcfr_options *opt, Knobs &k)
     const int tw = opt->tile_w, g = opt->group;
     if ((tw != 0 && tw != 8 && tw != 16 && tw != 32 && tw != 64) || (g != 0 && g != 1 && g != 2 && g != 4) ||
         opt->ksplit < -1 || opt->ksplit > 1 || opt->depth_bound_skip < -1 || opt->depth_bound_skip > 1 ||
-        opt->schedule < -1 || opt->schedule > 1 || opt->tile_order < -1 || opt->tile_order > 0 || opt->lds_stage < -1 ||
-        opt->lds_stage > 1 || opt->twopass_bodies < 0 || opt->twopass_bodies > 4096 || opt->twopass_min_groups < 0 ||
-        opt->twopass_min_groups > 4096)
-        return GCFR_ERR_INVALID_ARGUMENT;  // (tile_order: kept for the struct layout)
+        opt->schedule < -1 || opt->schedule > 0 || opt->tile_order < -1 || opt->tile_order > 0 || opt->lds_stage < -1 ||
+        opt->lds_stage > 1)
+        return GCFR_ERR_INVALID_ARGUMENT;  // (schedule / tile_order: the grid is the only schedule; the fields keep the struct layout)
     k.tile_w = tw;
     k.group = g ? g : 4;
     k.ksplit = opt->ksplit;
     k.zbound = opt->depth_bound_skip < 0 ? 1 : opt->depth_bound_skip;
     k.lds_stage = opt->lds_stage;
-    k.schedule = opt->schedule;
-    k.twopass_bodies = opt->twopass_bodies;
-    k.twopass_min_groups = opt->twopass_min_groups;
     k.ev_start = (hipEvent_t)opt->event_start;
     k.ev_stop = (hipEvent_t)opt->event_stop;
     k.counters = (unsigned long long *)opt->counters;
@@ -1833,7 +1749,7 @@ extern "C" void gcfr_options_default(gcfr_options *opt)
     opt->ksplit = opt->depth_bound_skip = opt->schedule = opt->tile_order = opt->lds_stage = -1;
 }
 
-// workspace layout: [quad texels | partial boxes | depth-bounds records | partial depth ranges | tflag | all-ones flags | mask bitmaps | suspend area]
+// workspace layout: [quad texels | partial boxes | depth-bounds records | partial depth ranges | tflag | all-ones flags | mask bitmaps]
 extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
 {
     if (B <= 0 || H <= 0 || W <= 0)
@@ -1842,17 +1758,10 @@ extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
     return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4) + (size_t)B * n_stat * 4 * sizeof(int) +
            (size_t)B * (size_t)zb_stride(H, W) * sizeof(float4) + (size_t)B * n_stat * 2 * sizeof(int) +
            (kQueueSlot + 1) * sizeof(int) + 12 + (size_t)B * n_stat * sizeof(int) + 16 +
-           (((W & 31) == 0) ? (size_t)B * (size_t)bitmap_stride_bytes(H, W) : 0) +  // mask bitmaps (LDS-staged march)
-           16 + sizeof(SuspArea) + (size_t)(kSuspCap - 1) * sizeof(SuspSlot);             // suspended tiles (two-pass schedule)
+           (((W & 31) == 0) ? (size_t)B * (size_t)bitmap_stride_bytes(H, W) : 0);  // mask bitmaps (LDS-staged march)
 }
 
-#ifndef GCFR_TWOPASS_BODIES
-#define GCFR_TWOPASS_BODIES 6
-#endif
-#ifndef GCFR_TWOPASS_MIN_GROUPS
-#define GCFR_TWOPASS_MIN_GROUPS 6
-#endif
-enum Schedule { kGrid = kSchedGrid, kKSplit, kGridLds, kTwoPass };
+enum Schedule { kGrid = kSchedGrid, kKSplit, kGridLds };
 
 template <int TILE_W, int DEPTH, bool FUSE>
 static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argmin, Schedule sch, dim3 grid,
@@ -1885,16 +1794,6 @@ static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argm
                 GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, false, true, DEPTH, FUSE);
             else
                 GCFR_LAUNCH(shadow_fwd_quad_ksplit_kernel, false, false, DEPTH, FUSE);
-        }
-    } else if (sch == kTwoPass) {
-        if constexpr (TILE_W == 16 && DEPTH == 4) {  // (the default shape; inference kernels)
-            if (even_half) {
-                GCFR_LAUNCH(shadow_fwd_quad_budget_kernel, true, DEPTH, FUSE);
-                hipLaunchKernelGGL((shadow_fwd_quad_resume_kernel<TILE_W, true, DEPTH, FUSE>), dim3((unsigned)a.susp_cap), dim3(256), 0, st, a);
-            } else {
-                GCFR_LAUNCH(shadow_fwd_quad_budget_kernel, false, DEPTH, FUSE);
-                hipLaunchKernelGGL((shadow_fwd_quad_resume_kernel<TILE_W, false, DEPTH, FUSE>), dim3((unsigned)a.susp_cap), dim3(256), 0, st, a);
-            }
         }
     } else if (sch == kGridLds) {
         if constexpr (TILE_W == 16 && DEPTH == 4) {  // (the default shape: the one the LDS-staged kernels are built for)
@@ -2029,19 +1928,14 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
 #define GCFR_LDS_STAGE_AUTO 0
 #endif
         const bool lds_stage = !ksplit && lds_fits && (kn.lds_stage < 0 ? (GCFR_LDS_STAGE_AUTO != 0) : (kn.lds_stage == 1));
-        // two passes (schedule 1): inference kernels of the default shape; worth it only when one launch has the chip to itself
-        const bool two_pass = !ksplit && !lds_stage && kn.schedule == 1 && argmin == nullptr && TILE_W == 16 && kn.group == 4 &&
-                              kn.zbound && N >= 2 * 16;
-        const Schedule sch = ksplit ? kKSplit : (lds_stage ? kGridLds : (two_pass ? kTwoPass : kGrid));
-        SuspArea *susp = (SuspArea *)(((uintptr_t)((char *)bitmap + (((W & 31) == 0) ? (size_t)B * (size_t)bitmap_stride_bytes(H, W) : 0)) + 15u) & ~(uintptr_t)15u);
+        const Schedule sch = ksplit ? kKSplit : (lds_stage ? kGridLds : kGrid);
         const int quad_blocks = (texels + 255) / 256;
         const int zb_blocks = use_zb ? (zb_max_tiles(H, W) + 3) / 4 : 0;  // sized for the finest stride
         const int bitmap_blocks = lds_stage ? ((H * W) / 32 + 255) / 256 : 0;
         const int vec_ok = ((W & 15) == 0) && (((uintptr_t)depth & 15u) == 0) && (((uintptr_t)mask_u8 & 15u) == 0);
         hipLaunchKernelGGL(build_quad_kernel, dim3(zb_blocks + (int)n_stat + bitmap_blocks + quad_blocks, B), dim3(256), 0, st,
                            depth, (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox, zrange, mones, zb, zb_blocks,
-                           (int)n_stat, use_zb ? 1 : 0, vec_ok, N, t_table, kn.group, tflag, bitmap, bitmap_blocks,
-                           two_pass ? susp : nullptr);
+                           (int)n_stat, use_zb ? 1 : 0, vec_ok, N, t_table, kn.group, tflag, bitmap, bitmap_blocks);
         ShadowQuadArgs a = {};
         a.zb = use_zb ? zb : nullptr;
         a.zrange = zrange;
@@ -2052,10 +1946,6 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         a.bbox = bbox;
         a.mask = mask_u8;
         a.bitmap = bitmap;
-        a.susp = susp;
-        a.susp_cap = (int)(tiles_total < kSuspCap ? tiles_total : kSuspCap);
-        a.budget_bodies = kn.twopass_bodies > 0 ? kn.twopass_bodies : GCFR_TWOPASS_BODIES;
-        a.budget_min_groups = kn.twopass_min_groups > 0 ? kn.twopass_min_groups : GCFR_TWOPASS_MIN_GROUPS;
         a.light_pt = light_pt;
         a.t_table = t_table;
         a.counters = kn.counters;

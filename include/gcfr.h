@@ -61,20 +61,16 @@ typedef struct gcfr_options {
     int32_t group;             /* samples per skip group: 1, 2 or 4; 0 = auto (4) */
     int32_t ksplit;            /* split each tile's sample range over the 4 waves of a workgroup: 0, 1, -1 = auto by launch size */
     int32_t depth_bound_skip;  /* exact depth-bound group skip: 0, 1, -1 = auto (on) */
-    int32_t schedule;          /* 0 (= -1, auto): ONE launch of the 3-D grid, one workgroup per four adjacent tiles, image-major --
-                                  the throughput schedule.  1: TWO passes for one batch at a time (a launch ends when its heaviest
-                                  tile ends): the same grid march with a budget -- a tile that has executed `twopass_bodies`
-                                  sample groups and has `twopass_min_groups` to go is suspended -- then one workgroup per
-                                  suspended tile that resumes it four ways from the saved minima.  Inference kernels of the
-                                  default shape; elsewhere it falls back to 0.  (Round 2's six other schedules -- values 1 ... 6
-                                  of that round, profiles/r02_schedule_experiments.md -- left the library in round 3.) */
+    int32_t schedule;          /* how tiles reach waves: 0 (= -1, auto) the 3-D grid, one workgroup per four adjacent tiles,
+                                  image-major -- the only schedule.  Round 2 measured six alternatives (values 1 ... 6:
+                                  persistent waves, ordered grids, cooperating waves, work stealing, helping across the
+                                  chip; profiles/r02_schedule_experiments.md), all bit-identical and all slower; their code
+                                  left the library in round 3 and any other value is GCFR_ERR_INVALID_ARGUMENT */
     int32_t tile_order;        /* 0 or -1 (it ordered the queues of the removed schedules; kept for the struct layout) */
     int32_t lds_stage;         /* the march's workgroups copy their image's mask (as a bitmap) and depth-bounds records into
                                   LDS and read them there instead of gathering them through the texture path: 0 off, 1 on
                                   (wherever the shape allows: W % 32 == 0, 26 KiB per workgroup, default tile and group),
                                   -1 = auto */
-    int32_t twopass_bodies;    /* schedule 1: the first pass' budget in executed sample groups, 0 = default (6) */
-    int32_t twopass_min_groups;/* schedule 1: suspend only with at least this many groups to go, 0 = default (6) */
     void *event_start;         /* hipEvent_t recorded on `stream` immediately before the march kernel, or NULL */
     void *event_stop;          /* hipEvent_t recorded immediately after it, or NULL */
     uint64_t *counters;        /* DEVICE array of GCFR_N_COUNTERS + 4 * (number of tiles) u64: the march kernel adds its work

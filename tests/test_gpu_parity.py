@@ -563,46 +563,3 @@ def test_non_finite_inputs_never_make_the_skipping_kernels_differ_from_the_plain
         assert np.array_equal(a[ok], b[ok]), (zb, lds)
         assert np.array_equal(am.cpu().numpy()[ok], ref_am.cpu().numpy()[ok]), (zb, lds)
     assert np.isnan(ref_md.cpu().numpy()[3]).all() and np.isfinite(ref_md.cpu().numpy()[0]).all()
-
-
-@pytest.mark.parametrize("bodies,min_groups", [(0, 0), (1, 1), (3, 2), (12, 8)])
-def test_two_pass_schedule_is_bit_identical(bodies, min_groups):
-    """gcfr_options.schedule = 1 (round 3): a budgeted first pass suspends heavy tiles, a second launch resumes each of
-    them with four waves from the saved running minima.  A minimum needs no order: min_dist and every fused output equal
-    the one-launch march's bits -- for any budget, including one so small that more tiles are suspended than the suspend
-    area holds (the overflow keeps marching in pass 1), on smooth / rough / offset surfaces, ellipse / all-ones / random
-    masks, grazing and overhead lights."""
-    from geomconsistentfr_amd import RenderParams, _lib, light_prep, shadow_min_distance
-    from geomconsistentfr_amd.block import render_fwd
-    rng = np.random.default_rng(31 + bodies)
-    Hs, Ws, N, dt = 256, 256, 160, 0.005
-    r, c = np.mgrid[0:Hs, 0:Ws]
-    bump = 0.35 * Hs * np.exp(-(((c - 0.5 * Ws) / (0.25 * Ws)) ** 2 + ((r - 0.5 * Hs) / (0.3 * Hs)) ** 2))
-    depth = np.stack([bump, bump + 3 * rng.random((Hs, Ws)), 60 * rng.random((Hs, Ws)), bump - 0.15 * Hs, bump + 1000.0,
-                      bump + 10 * np.sin(c / 3.0)]).astype(np.float32)
-    B = depth.shape[0]
-    ell = ((((c - 0.5 * Ws) / (0.4 * Ws)) ** 2 + ((r - 0.5 * Hs) / (0.45 * Hs)) ** 2) < 1)
-    mask = np.stack([ell, ell, np.ones_like(ell), rng.random((Hs, Ws)) > 0.2, ell, np.ones_like(ell)]).astype(np.uint8)
-    lights = np.array([[[0.75, 0.0, 0.66], [0.1, -0.2, 0.97]]] * B, np.float32)
-    lights[1::2, 0] = [-0.5, 0.47, 0.72]
-    lights[2, 1] = [0.99, 0.05, 0.05]                                  # grazing
-    lights[5, 0] = [0.95, 0.2, 0.1]
-    prm = RenderParams(n_samples=N, t0=0.025, dt=dt)
-    _, pt = light_prep(to_dev(lights), prm)
-    ref, _ = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, want_argmin=False, use_workspace=True,
-                                 options=_lib.options(schedule=0, ksplit=0))
-    two, _ = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, want_argmin=False, use_workspace=True,
-                                 options=_lib.options(schedule=1, ksplit=0, twopass_bodies=bodies, twopass_min_groups=min_groups))
-    assert torch.equal(ref, two)
-    amb = to_dev((0.3 + 0.4 * rng.random((B, 2))).astype(np.float32))
-    nrm = to_dev(rng.standard_normal((B, 3, Hs, Ws)).astype(np.float32))
-    alb = to_dev(rng.random((B, 3, Hs, Ws)).astype(np.float32))
-    outs = [render_fwd(to_dev(depth), to_dev(mask), to_dev(lights), amb, nrm, alb, prm, want_argmin=False,
-                       options=_lib.options(schedule=sc, ksplit=0, twopass_bodies=bodies, twopass_min_groups=min_groups)) for sc in (0, 1, 1)]
-    for k in outs[0]:
-        if outs[0][k] is not None:
-            assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k]), k
-    # with argmin requested the library keeps the one-launch march (a first index needs the order): still the same bits
-    a0 = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, want_argmin=True, options=_lib.options(schedule=0, ksplit=0))
-    a1 = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, want_argmin=True, options=_lib.options(schedule=1, ksplit=0))
-    assert torch.equal(a0[0], a1[0]) and torch.equal(a0[1], a1[1])

@@ -16,7 +16,7 @@ for t in "$@"; do
               "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM SQ_BUSY_CYCLES" \
               "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"; do
     i=$((i+1))
-    timeout 300 rocprofv3 --pmc $pass --output-format csv -d /tmp/pq/p$i -o pq -- python $REPO/bench.py --no-cpu-baseline --no-worst-case --steps 10 --warmup 2 --streams 1 --no-graph --faces $F $PMC_EXTRA $extra > /tmp/pq_$i.log 2>&1 || tail -2 /tmp/pq_$i.log
+    timeout 300 rocprofv3 --pmc $pass --output-format csv -d /tmp/pq/p$i -o pq -- python $REPO/bench.py --no-cpu-baseline --no-worst-case --steps 10 --warmup 2 --streams 1 --no-graph --regions 1 --no-worst-case --faces $F $PMC_EXTRA $extra > /tmp/pq_$i.log 2>&1 || tail -2 /tmp/pq_$i.log
   done
   python - "$t" <<'PY'
 import csv, glob, sys, collections

@@ -5,7 +5,7 @@ if [ -n "$1" ] && [[ "$1" == *.so ]]; then export GCFR_HIP_LIB=$REPO/geomconsist
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ph
 for c in FETCH_SIZE WRITE_SIZE; do   # one counter per pass, un-overlapped launches (as tools/prof.sh)
-  timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/ph/$c -o ph -- python $REPO/bench.py --no-cpu-baseline --steps 10 --warmup 2 --streams 1 --no-graph "$@" > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/ph/$c -o ph -- python $REPO/bench.py --no-cpu-baseline --steps 10 --warmup 2 --streams 1 --no-graph --regions 1 --no-worst-case "$@" > /dev/null 2>&1
 done
 python - <<'PY'
 import csv, glob, collections

@@ -11,7 +11,7 @@ for t in "$@"; do
               "SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE" \
               "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_IFETCH"; do
     name=$(echo $pass | cut -c1-20 | tr ' ' '_')
-    timeout 300 rocprofv3 --pmc $pass --output-format csv -d /tmp/pq/$name -o pq -- python $REPO/bench.py --no-cpu-baseline --steps 10 --warmup 2 --streams 1 --no-graph --faces $F $extra > /dev/null 2>&1
+    timeout 300 rocprofv3 --pmc $pass --output-format csv -d /tmp/pq/$name -o pq -- python $REPO/bench.py --no-cpu-baseline --steps 10 --warmup 2 --streams 1 --no-graph --regions 1 --no-worst-case --faces $F $extra > /dev/null 2>&1
   done
   python - "$t" <<'PY'
 import csv, glob, sys, collections

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 if [ "$WHAT" = "bwd" ]; then
   CMD="python $REPO/tools/bwd_bench.py --iters 10 $*"
 else
-  CMD="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --streams 1 --no-graph $*"   # un-overlapped launches
+  CMD="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --streams 1 --no-graph --regions 1 --no-worst-case $*"   # un-overlapped launches
 fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 for pass in "FETCH_SIZE" "WRITE_SIZE" \

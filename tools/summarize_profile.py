@@ -43,6 +43,8 @@ CLASS_ROWS = {
 def cost_table(tag):
     """{class: nominal-2.4-GHz cycles per wave64 instruction per SIMD}, from the w=8 wall column of the ubench."""
     path = os.path.join(ROOT, "profiles", tag + "_ubench_valu.txt")
+    if not os.path.exists(path):      # the per-class issue costs are a property of the chip: round 2's table serves later rounds
+        path = os.path.join(ROOT, "profiles", "r02_ubench_valu.txt")
     rows = {}
     for line in open(path):
         m = re.match(r"(\S.*?)\s+w=1:", line)
@@ -102,9 +104,15 @@ def kernel_entry(name, c, cost):
 def main(tag):
     dst = os.path.join(ROOT, "profiles")
     cost, rows = cost_table(tag)
-    json.dump({"source": "profiles/%s_ubench_valu.txt, column w=8 'wall' (nominal 2.4 GHz cycles per wave64 instruction per SIMD)" % tag,
+    json.dump({"source": "profiles/%s_ubench_valu.txt (or round 2's when absent), column w=8 'wall' (nominal 2.4 GHz cycles per wave64 instruction per SIMD)" % tag,
                "per_class": cost, "ubench_rows": rows}, open(os.path.join(dst, tag + "_valu_cost_table.json"), "w"), indent=1)
-    summary = {"tag": tag, "n_simd": N_SIMD, "nominal_hz": NOMINAL_HZ, "kernels": {}}
+    # the instruction counts / traffic below belong to ONE build of the library: bench.py compares this hash with the loaded
+    # library's and marks its roofline `stale` when they differ
+    try:
+        lib_hash = open(os.path.join(ROOT, "geomconsistentfr_amd", "lib", "libgcfr_hip.srchash")).read().strip()
+    except OSError:
+        lib_hash = None
+    summary = {"tag": tag, "library_srchash": lib_hash, "n_simd": N_SIMD, "nominal_hz": NOMINAL_HZ, "kernels": {}}
     for leg, pick in (("fwd", "shadow_fwd_quad"), ("bwd", "render_bwd_single_light")):
         src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, leg))
         if not os.path.isdir(src):
