@@ -68,7 +68,8 @@ def synth_faces_sized(B, seed0, size, n_lights, mask_kind="ellipse", light_seed0
         d = s * (80 * np.sqrt(np.maximum(1 - (x / ax) ** 2 - (y / ay) ** 2, 0))
                  + nose * np.exp(-(x ** 2 / 288 + (y - 12) ** 2 / 648)) + 3 * np.sin(x / 7) * np.cos(y / 9))
         depth.append(d.astype(np.float32))
-        m = (((x / (ax - 8)) ** 2 + (y / (ay - 8)) ** 2) < 1) if mask_kind == "ellipse" else np.ones_like(x, bool)
+        m = (((x / (ax - 8)) ** 2 + (y / (ay - 8)) ** 2) < 1) if mask_kind == "ellipse" else (
+            np.ones_like(x, bool) if mask_kind == "ones" else np.zeros_like(x, bool))
         mask.append(m.astype(np.uint8))
         albedo.append((0.15 + 0.7 * rng.random((3, size, size))).astype(np.float32))
         gy, gx = np.gradient(d)
@@ -889,8 +890,9 @@ def main():
     ap.add_argument("--depth-noise", type=float, default=0.0,
                     help="worst case for the depth-bound skip: add uniform noise of this amplitude to the depth maps "
                          "(an untrained network's output; the bounds then never separate ray and surface)")
-    ap.add_argument("--mask", choices=["ellipse", "ones"], default="ellipse",
-                    help="'ones' = worst case: no fully masked wave-step exists, nothing is skipped")
+    ap.add_argument("--mask", choices=["ellipse", "ones", "zeros"], default="ellipse",
+                    help="'ones' = worst case: no fully masked wave-step exists, nothing is skipped; 'zeros' = nothing to march: "
+                         "the kernel's fixed cost per tile (prologue + epilogue)")
     ap.add_argument("--tune", type=str, default="",
                     help="A/B: comma list of gcfr_options knobs, e.g. tile_w=32,ksplit=1,depth_bound_skip=0,group=2 "
                          "(never changes a result bit)")

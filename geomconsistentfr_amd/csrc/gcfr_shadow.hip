@@ -479,7 +479,8 @@ __device__ inline void build_zbounds_block(int block, int b, const float *__rest
 // nothing to report), so an image has only P/16384 partials (4 at 256x256) and every march wave reduces them
 // itself with one load and six DPP minima -- no atomics to initialise, no workgroup barrier in the march (round 1
 // kept 256 partials per image and reduced them through LDS in every march workgroup's prologue).
-constexpr int kQueueSlot = 64;  // (workspace layout: the table flag keeps a 256-B line to itself)
+constexpr int kQueueSlot = 64;  // (workspace layout: the table record keeps a 256-B line to itself)
+enum { kTfOk = 0, kTfStride = 1, kTfTabs = 2, kTfTfirst = 3, kTfInvDt = 4 };  // tflag[]: per-launch facts about the sample table (prepass)
 constexpr int kStatChunk = 16384;
 __host__ __device__ inline int n_stat_chunks(int H, int W) { return (H * W + kStatChunk - 1) / kStatChunk; }
 
@@ -654,8 +655,20 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
             }
         }
         const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
             tflag[0] = all_ok ? 1 : 0;
+            // What every march tile derives from the sample table alone, once per launch instead of once per tile (round 3:
+            // gfx950 has no scalar float unit, so this wave-uniform arithmetic -- an f64 division among it -- ran on the
+            // VECTOR unit in every tile's prologue, ~3 % of the march's VALU instructions): the bounds grid's stride and
+            // whether a group's footprint always fits one tile, max |t|, and t -> sample-index conversion of the pruning.
+            bool fits = false;
+            const int ls = zb_log2_stride(H, W, N, t_table, group, &fits);
+            tflag[kTfStride] = ls | (fits ? 0x100 : 0);
+            const float t_first = (N >= 1) ? (float)t_table[0] : 0.0f, t_last = (N >= 1) ? (float)t_table[N - 1] : 0.0f;
+            tflag[kTfTabs] = __builtin_bit_cast(int, fmaxf(fabsf(t_first), fabsf(t_last)));
+            tflag[kTfTfirst] = __builtin_bit_cast(int, t_first);
+            tflag[kTfInvDt] = __builtin_bit_cast(int, (float)(N - 1) * __builtin_amdgcn_rcpf(t_last - t_first));
+        }
     }
     if (pl.light_raw && qb == 0) {
         for (int l = threadIdx.x; l < pl.L; l += blockDim.x)
@@ -959,7 +972,8 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     // the pruning / skipping machinery below reasons about an increasing, uniform sample table inside [0, 1]
     // (gcfr_sample_table with dt > 0, the reference's np.arange); anything else marches every sample, which is
     // always right
-    const bool t_increasing = (a->N >= 2) && (((ConstI32Ptr)(unsigned long long)a->tflag)[0] != 0);  // checked by the prepass (see its table check)
+    const ConstI32Ptr tfl = (ConstI32Ptr)(unsigned long long)a->tflag;  // the prepass' record about the sample table (scalar loads)
+    const bool t_increasing = (a->N >= 2) && (tfl[kTfOk] != 0);  // checked by the prepass (see its table check)
     bool use_zb = (a->zb != nullptr) && t_increasing;
     const int gz_lo_s = st.gz_lo_s, gz_nhi_s = st.gz_nhi_s;  // image depth range {z_min, -z_max} (sortable ints)
     int lane_last = a->N - 1;  // last sample of this lane that can be unmasked (mask bounding box), see below
@@ -989,8 +1003,8 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
                 empty = empty || (y < Y0) || (y > Y1);
             }
             if (!empty && ta <= tb) {
-                const float t_first = (float)tt[0];
-                const float inv_dt = (float)(a->N - 1) * __builtin_amdgcn_rcpf((float)tt[a->N - 1] - t_first);
+                const float t_first = __builtin_bit_cast(float, tfl[kTfTfirst]);  // (float)tt[0]
+                const float inv_dt = __builtin_bit_cast(float, tfl[kTfInvDt]);   // (N - 1) / (tt[N-1] - tt[0]), v_rcp_f32
                 const float ka = (ta - t_first) * inv_dt, kb = (tb - t_first) * inv_dt;
                 // clamp in float first: ta / tb may be +-3e38
                 lane_lo = (int)fminf(fmaxf(floorf(ka) - 1.0f, 0.0f), (float)a->N);
@@ -1028,8 +1042,10 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     // plane evaluation's terms); a lane votes "skip" only if the bound exceeds its running minimum by a further
     // 0.2 %, so a skipped sample could not have been taken and the minimum, its index and the tie predecessor
     // are what the full march gives.
-    bool zfits = false;
-    const int zls = use_zb ? __builtin_amdgcn_readfirstlane(zb_log2_stride(H, W, a->N, tt, DEPTH, &zfits)) : 3;
+    // (stride and fit of the bounds grid for groups of DEPTH samples: zb_log2_stride(), evaluated once by the prepass)
+    const int zrec = tfl[kTfStride];
+    const bool zfits = use_zb && ((zrec & 0x100) != 0);
+    const int zls = use_zb ? (zrec & 0xff) : 3;
     // With a checked table every sample lies on the segment pixel -> end point, i.e. inside the image, and the
     // stride was chosen so that a group's footprint fits the tile its lowest cell selects: no per-lane test.
     const bool zb_trusted = __builtin_amdgcn_readfirstlane((int)zfits) != 0;
@@ -1039,7 +1055,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     const float nrm = __builtin_sqrtf(BCx * BCx + BCy * BCy);
     const float c1 = BCz * ((dxf * BCx + dyf * BCy) / nrm);
     const float Qz = nrm * zb;
-    const float t_abs = fmaxf(fabsf((float)tt[0]), fabsf((float)tt[a->N - 1]));
+    const float t_abs = __builtin_bit_cast(float, tfl[kTfTabs]);  // max(|tt[0]|, |tt[N-1]|)
     // Give-up test (a heuristic about WORK, never about results: without the bounds every group is marched).  A group
     // can only be skipped while the ray's height over the pixel, c1 t / n, exceeds what the surface band leaves open,
     // about half its width; on a surface rougher than the rays rise (an untrained network's depth) no test can ever
