@@ -111,15 +111,21 @@ int main()
     hipStream_t st;
     CK(hipStreamCreate(&st));
 
+    // (0) the library implements the ABI revision this consumer was compiled against (a stale .so keeps every symbol NAME)
+    if (gcfr_abi_version() != GCFR_ABI_VERSION) {
+        std::fprintf(stderr, "ABI revision %d, header %d\n", (int)gcfr_abi_version(), (int)GCFR_ABI_VERSION);
+        return 1;
+    }
     // (1) one call
-    // per-call options: explicit knobs (grid schedule here; the NULL-options calls below use the defaults, i.e. the
-    // persistent tile queue) and an event pair the library records around the march kernel
+    // per-call options: explicit knobs (the grid schedule, LDS staging of the mask / bounds records; the NULL-options calls
+    // below use the defaults) and an event pair the library records around the march kernel
     gcfr_options opt;
     gcfr_options_default(&opt);
     hipEvent_t ev0, ev1;
     CK(hipEventCreate(&ev0));
     CK(hipEventCreate(&ev1));
     opt.schedule = 0;
+    opt.lds_stage = 1;   // (bit-identical by contract: the three-call forward below runs with the defaults and must agree)
     opt.event_start = ev0;
     opt.event_stop = ev1;
     GK(gcfr_render_fwd(d_light, 1, 0.0f, 4013.0f, d_depth, d_mask, B, d_normals, d_albedo, d_amb, B, L, H, W, N,
