@@ -46,3 +46,26 @@ def test_without_a_gpu_the_real_command_fails_loudly():
     p = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"])
     assert p.returncode != 0
     assert "needs a GPU" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,extra", [("render", ["--steps", "8", "--warmup", "2", "--regions", "2"]),
+                                            ("train", ["--steps", "2", "--faces", "4"])])
+def test_two_self_launched_ranks_run_the_real_workload_on_this_box(workload, extra):
+    """`python bench.py --gpus 2` end to end on whatever this box has: with two GPUs the ranks talk RCCL, with one they share it
+    over gloo (--oversubscribe: a rehearsal of the launch / fence / max-over-ranks path, flagged as such).  Both ranks ran the
+    kernels, took part in the collectives, and rank 0 printed ONE line."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    args = ["--gpus", "2", "--workload", workload, "--no-cpu-baseline", "--no-worst-case"] + extra
+    if n_dev < 2:
+        args.append("--oversubscribe")
+    p = _run(args, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["process_layout"]["ranks"] == 2 and d["process_layout"]["self_launched"] is True
+    assert len(d["per_rank"]) == 2 and all(r["seconds"] > 0 for r in d["per_rank"])
+    assert d["rccl_ranks"] == (2 if n_dev >= 2 else None)
+    assert d["value"] > 0 and d["config"]["parallelism"] == "dp2"
