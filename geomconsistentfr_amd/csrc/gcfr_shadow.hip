@@ -757,7 +757,7 @@ __device__ inline int lo32(double v)
 // Work counters of the counting build (-DGCFR_COUNTERS; tools/count_work.py): wave-uniform tallies, added to
 // gcfr_options.counters once per tile.  Compiled out of the product build.
 enum { kCntTiles, kCntGroupsNominal, kCntGroupsVisited, kCntBoundTests, kCntBodies, kCntLaneSamples, kCntEarlyExit,
-       kCntTieRemarch, kCntSamplesInRange, kCntBoundsGivenUp, kCntSteals, kCntStolenGroups, kCntUsed };
+       kCntTieRemarch, kCntSamplesInRange, kCntBoundsGivenUp, kCntVisitsAfterLastBody, kCntVisitsBeforeFirstBody, kCntUsed };
 #ifdef GCFR_COUNTERS
 #define GCFR_COUNT(i, n) (cnt[i] += (unsigned)(n))
 #else
@@ -914,6 +914,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     const int N = KSPLIT ? min(a->N, k_lo + chunk) : a->N;  // exclusive upper bound ("N" below)
 #ifdef GCFR_COUNTERS
     unsigned cnt[kCntUsed] = {};
+    unsigned cnt_since_body = 0, cnt_had_body = 0;  // visits since the last executed body / whether there was one
     // timeline record of this tile (tools/trace_timeline.py): constant 100 MHz clock + shader clock at entry
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime(), trace_c0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1258,6 +1259,9 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         constexpr bool LAZY = decltype(lazy)::value;
         if (!LAZY)
             GCFR_COUNT(kCntGroupsVisited, 1);
+#ifdef GCFR_COUNTERS
+        ++cnt_since_body;
+#endif
         bool none = true;
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
@@ -1277,6 +1281,12 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         constexpr int GCFR_BODY_CHUNK = KSPLIT ? DEPTH : 1;  // (KSPLIT here: SPLIT == 1 only)
         if (run_body) {
           GCFR_COUNT(kCntBodies, 1);
+#ifdef GCFR_COUNTERS
+          if (!cnt_had_body)
+              cnt[kCntVisitsBeforeFirstBody] += cnt_since_body - 1;
+          cnt_had_body = 1;
+          cnt_since_body = 0;
+#endif
 #ifdef GCFR_COUNTERS
 #pragma unroll
           for (int j = 0; j < DEPTH; ++j)
@@ -1569,6 +1579,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     }
 #ifdef GCFR_COUNTERS
     if (a->counters && lane == 0 && !(KSPLIT && wave != 0)) {
+        cnt[kCntVisitsAfterLastBody] += cnt_since_body;  // (tiles without any body: all their visits)
 #ifndef GCFR_TRACE_ONLY   // (ten same-address atomics per tile cost ~20 ns each: they distort the timeline)
 #pragma unroll
         for (int i = 0; i < kCntUsed; ++i)
