@@ -80,3 +80,40 @@ def test_batches_need_a_device(tmp_path):
         assemble_batch(z, z[..., 0], z[..., 0], z[..., 0])
     with pytest.raises(GcfrError):
         masked_metrics(z, z, z[..., 0])
+
+
+def test_reader_against_the_references_own_load_data(tmp_path, monkeypatch, capsys):
+    """Authoring container only (skipped without /root/reference): the reference's OWN `load_data()`
+    (train_raytracing_relighting_CelebAHQ_DSSIM_8x.py:527-558), imported unmodified through oracle/ref_shim.py and run in a
+    working directory whose 'MP_data/' is the synthetic dataset of this test.  Seams: `imageio.imread` -> Pillow (what
+    imageio uses for jpg / png), and `np.zeros` shrinks the hard-coded 29,890 leading dimension to the number of files (the
+    script allocates 110 GB of float64 up front).  Its six float64 arrays against the byte arrays of RelightDataset:
+    identical after the script's own conversions."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_shim
+    if not ref_shim.reference_available():
+        pytest.skip("/root/reference not present")
+    from PIL import Image
+    from geomconsistentfr_amd.dataset import RelightDataset
+    n = 4
+    root = tmp_path / "MP_data"
+    write_dataset(str(root), n)
+    T8 = ref_shim.load("T8")
+    import imageio
+    monkeypatch.setattr(imageio, "imread", lambda p: np.asarray(Image.open(p)), raising=False)
+    real_zeros = np.zeros
+    monkeypatch.setattr(np, "zeros", lambda shape, *a, **k: real_zeros((n,) + tuple(shape[1:]) if isinstance(shape, tuple) and shape and shape[0] == 29890 else shape, *a, **k))
+    monkeypatch.chdir(tmp_path)
+    images, lightings, depths, masks, albedo, fill = T8.load_data()              # prints the index of every face (T8:544)
+    capsys.readouterr()
+    ds = RelightDataset(str(root))
+    assert images.dtype == np.float64 and images.shape == (n, 256, 256, 3)
+    np.testing.assert_array_equal(ds.images / 255.0, images)                       # T8:550
+    np.testing.assert_array_equal(ds.masks[..., None].astype(np.float64), masks)   # T8:546
+    np.testing.assert_array_equal(ds.albedo.astype(np.float64), albedo)            # T8:551
+    np.testing.assert_array_equal(ds.depths.astype(np.float64), depths.astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(ds.lightings, lightings, rtol=1e-7)                 # ambient target 0.5 in column 0 (T8:542)
+    np.testing.assert_array_equal(np.where(np.maximum(ds.face_masks, ds.masks) > 128, 255.0, 0.0)[..., None], fill)   # T8:552-556
+    # and this test's line-for-line statement of load_data is the reference's function
+    for a, b in zip(load_data_statement(str(root)), (images, lightings, depths, masks, albedo, fill)):
+        np.testing.assert_array_equal(a, b)

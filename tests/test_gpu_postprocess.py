@@ -70,6 +70,17 @@ def test_kernel_on_the_reference_model_outputs_gives_the_reference_main_bytes(ta
         np.testing.assert_array_equal(got[k][0].cpu().numpy(), rgb(z[k + "_u8"]), err_msg=k)
 
 
+def test_kernel_gives_the_single_image_scripts_bytes():
+    """mask_f32 = 0 (the f64-mask flow of S1 / S8) against the bytes of the reference's own S1 main()
+    (tests/golden/s1_main.npz): every input of the composite is f32 or uint8, so every byte is identical."""
+    from geomconsistentfr_amd import postprocess as pp
+    z = np.load(os.path.join(GOLDEN, "s1_main.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    got = pp.inference_images_device(t((z["input_u8"] / 255.0).astype(np.float32)[None]), t(z["model_rendered_images"]),
+                                     t(z["mask_u8"]))
+    np.testing.assert_array_equal(got["rendered_image"][0].cpu().numpy(), z["rendered_image_u8"][..., ::-1])
+
+
 def _slt_model():
     from geomconsistentfr_amd.relightnet import RelightNetLightingTransfer
     sd = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "slt_checkpoint_epoch106.npz")).items()}

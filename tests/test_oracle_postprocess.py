@@ -146,3 +146,15 @@ def test_on_disk_formats(tmp_path):
     exp = np.where(tmp > 128, 255.0, 0.0)
     np.testing.assert_array_equal(got[..., 0], exp)
     assert set(np.unique(got)) <= {0.0, 255.0}
+
+
+def test_composite_statement_reproduces_the_single_image_scripts_main_bit_for_bit():
+    """tests/golden/s1_main.npz: the unmodified test_relight_single_image.py main() (S1:507-620; oracle/make_golden_s1_main.py),
+    whose mask is a float64 array / 255.0 (S1:563-567, 580) -- the other dtype flow of the image side."""
+    z = np.load(os.path.join(GOLDEN, "s1_main.npz"))
+    mask = z["mask_u8"].astype(np.float64) / 255.0
+    out = pp.composite_into_input(z["input_u8"] / 255.0, z["model_rendered_images"][0], mask)
+    assert out.dtype == np.float64
+    assert np.array_equal(out, z["rendered_image_f64"][..., ::-1])
+    np.testing.assert_array_equal(pp.to_uint8(out), z["rendered_image_u8"][..., ::-1])
+    assert (z["rendered_image_u8"] == 0).any()                                   # negative products saturate at 0
