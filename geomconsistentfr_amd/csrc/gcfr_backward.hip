@@ -350,7 +350,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
             ln = ln > 1e-12 ? ln : 1e-12;
             const double inv_ln = fast_rcp64(ln);
             const double u0 = lx * inv_ln, u1 = ly * inv_ln, u2 = lz * inv_ln;
-            const double dot = n0 * u0 + n1 * u1 + n2 * u2;
+            double dot = n0 * u0 + n1 * u1 + n2 * u2;
+            if (fabs(dot) < 1e-4)  // at the kink of max(n.l, 0) the forward's own f32 arithmetic decides the side (lambert_dot)
+                dot = (double)lambert_dot(x, y, zb, (float)nx, (float)ny, (float)nz, (float)Cx, (float)Cy, (float)Cz);
             const double full = amb + (double)a.intensity * (dot > 0.0 ? dot : 0.0);
             const double e = (double)expf(-a.min_dist[o]);  // the forward evaluates the transfer function in f32 too (T8:517)
             const double ope = 1.0 + e;
@@ -493,7 +495,9 @@ __attribute__((amdgpu_waves_per_eu(GCFR_BWD1_WAVES_PER_EU, GCFR_BWD1_WAVES_PER_E
             ln = ln > 1e-12f ? ln : 1e-12f;
             const float inv_ln = 1.0f / ln;
             const float u0 = lx * inv_ln, u1 = ly * inv_ln, u2 = lz * inv_ln;
-            const float dot = n0 * u0 + n1 * u1 + n2 * u2;
+            float dot = n0 * u0 + n1 * u1 + n2 * u2;
+            if (fabsf(dot) < 1e-4f)  // at the kink of max(n.l, 0) the forward's own arithmetic decides the side (lambert_dot)
+                dot = lambert_dot(x, y, zb, n[0], n[1], n[2], Cxf, Cyf, Czf);
             const float full = amb + a.intensity * (dot > 0.0f ? dot : 0.0f);
             const float e = expf(-a.min_dist[o]);  // T8:517
             const float ope = 1.0f + e;
@@ -806,7 +810,9 @@ __attribute__((amdgpu_waves_per_eu(GCFR_BWDL_WAVES_PER_EU, GCFR_BWDL_WAVES_PER_E
                 ln = ln > 1e-12f ? ln : 1e-12f;
                 const float inv_ln = 1.0f / ln;
                 const float u0 = lx * inv_ln, u1 = ly * inv_ln, u2 = lz * inv_ln;
-                const float dot = n0 * u0 + n1 * u1 + n2 * u2;
+                float dot = n0 * u0 + n1 * u1 + n2 * u2;
+                if (fabsf(dot) < 1e-4f)  // at the kink of max(n.l, 0) the forward's own arithmetic decides the side (lambert_dot)
+                    dot = lambert_dot(x, y, zb, n[0], n[1], n[2], Cxf, Cyf, Czf);
                 const float full = amb + a.intensity * (dot > 0.0f ? dot : 0.0f);
                 const float e = expf(-a.min_dist[o]);  // T8:517
                 const float ope = 1.0f + e;

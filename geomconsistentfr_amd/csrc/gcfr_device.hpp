@@ -113,8 +113,12 @@ __device__ inline float shadow_transfer(float d)
 struct Shaded {
     float w, full, fin;
 };
-__device__ inline Shaded shade_pixel(float x, float y, float zb, float nx, float ny, float nz, float Cx,
-                                     float Cy, float Cz, float amb, float intensity, float min_dist)
+// n_hat . l_hat of one pixel and one light, T8:364-366 -- the forward's own arithmetic (separately rounded, IEEE divisions).
+// Also called by the backward kernels where their fast evaluation of the same quantity comes out within 1e-4 of zero: the
+// Lambert term max(n.l, 0) has a kink there, and which side of it a pixel is on must be the FORWARD's decision (round 3: a
+// randomised soak found one pixel in 6000 cases where the multi-light backward's reciprocal-based dot had the other sign than
+// the forward's -- a gradient flowed through a term the forward had clamped to zero).
+__device__ inline float lambert_dot(float x, float y, float zb, float nx, float ny, float nz, float Cx, float Cy, float Cz)
 {
     // incident light direction, T8:364
     const float lx = Cx - x, ly = Cy - y, lz = Cz - zb;
@@ -125,7 +129,13 @@ __device__ inline Shaded shade_pixel(float x, float y, float zb, float nx, float
     float nn = norm3_torch(nx, ny, nz);
     nn = nn > 1e-12f ? nn : 1e-12f;
     const float n0 = nx / nn, n1 = ny / nn, n2 = nz / nn;
-    const float dot = (n0 * ux + n1 * uy) + n2 * uz;  // T8:366
+    return (n0 * ux + n1 * uy) + n2 * uz;  // T8:366
+}
+
+__device__ inline Shaded shade_pixel(float x, float y, float zb, float nx, float ny, float nz, float Cx,
+                                     float Cy, float Cz, float amb, float intensity, float min_dist)
+{
+    const float dot = lambert_dot(x, y, zb, nx, ny, nz, Cx, Cy, Cz);
     Shaded o;
     o.full = amb + intensity * (dot > 0.0f ? dot : 0.0f);  // T8:366-369
     o.w = shadow_transfer(min_dist);                        // T8:517

@@ -372,3 +372,18 @@ def test_config5_backward_18_lights_512_equals_eighteen_single_light_backwards()
     assert float(sum_depth.abs().max()) > 0
     assert float((g_alb - sum_alb).abs().max()) <= 1e-5 * float(sum_alb.abs().max())
     assert float((g_depth - sum_depth).abs().max()) <= 1e-5 * float(sum_depth.abs().max())
+
+
+def test_backward_soak_slice_fused_kernels_agree_with_each_other():
+    """tools/soak_backward.py, 1600 random cases of seed 12 (sizes 16 ... 160 with W % 16 != 0 mostly, one to three faces, random
+    masks / lights / upstream gradients): the fused single-light backward against the three-kernel path, the multi-light
+    fused backward against the sum of single-light runs.  Case 1519 of this sequence is where round 3 found a pixel with
+    n.l = 0 in the forward and a hair above it in the multi-light backward's reciprocal-based evaluation: the kink of
+    max(n.l, 0) is now decided by the forward's own arithmetic in every backward kernel."""
+    import json
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_backward.py"), "--cases", "1600", "--seed", "12"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["ok"], r["worst_relative_difference"]
