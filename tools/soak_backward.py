@@ -48,12 +48,67 @@ def rel(a, b, floor=0.0):
     return float((a - b).abs().max()) / max(s, 1e-12)
 
 
+def oracle_soak(a):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import materialised as M
+    from normals_restatement import depth_to_normals as oracle_normals
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(a.seed)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    names = ("depth", "albedo", "light", "ambient")
+    worst = dict.fromkeys(names, 0.0)
+    over, t0 = [], time.time()
+    for it in range(a.oracle):
+        B = int(rng.integers(1, 3))
+        H, W = 2 * int(rng.integers(8, 25)), 2 * int(rng.integers(8, 25))
+        N = int(rng.integers(8, 41))
+        depth, mask, albedo = random_inputs(rng, B, H, W)
+        f, zoff = float(rng.uniform(300, 2000)), float(rng.uniform(100, 2000))
+        light = rng.standard_normal((B, 3)).astype(np.float32)
+        light[:, 2] = np.abs(light[:, 2]) + 0.05
+        amb = (0.3 + 0.4 * rng.random(B)).astype(np.float32)
+        G = {k: rng.standard_normal(s_).astype(np.float32) for k, s_ in
+             [("shadow_mask_weights", (B, H, W)), ("final_shading", (B, H, W)), ("rendered_images", (B, 3, H, W))]}
+        prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
+        K = camera(f, H, W, "cpu")
+        # oracle: autograd on the host
+        cl = [torch.from_numpy(x).clone().requires_grad_() for x in (depth[:, None], albedo, light, amb)]
+        n = oracle_normals(cl[0] + zoff, K)
+        n = torch.cat([n[:, 0:1], -n[:, 1:2], n[:, 2:3]], 1)
+        o = M.render_block(cl[0], cl[1], cl[2], cl[3], n, torch.from_numpy(mask), M.BlockParams(n_samples=N, t0=0.025, dt=0.8 / N))
+        sum((o[k].reshape(g.shape) * torch.from_numpy(g)).sum() for k, g in G.items()).backward()
+        # product: fused forward + fused backward
+        gl = [t(x).requires_grad_() for x in (depth[:, None], albedo, light, amb)]
+        oh = R.render_from_depth(gl[0], gl[1], gl[2], gl[3], K.to(dev), zoff, t(mask), prm)
+        sum((oh[k] * t(g)).sum() for k, g in G.items()).backward()
+        for name, c_, g_ in zip(names, cl, gl):
+            e = rel(g_.grad.cpu().double(), c_.grad.double(), 2e-4 * B * H * W if name in ("light", "ambient") else 0.0)
+            worst[name] = max(worst[name], e)
+            # (the light-point gradient is a sum dominated by a few ill-conditioned pixels -- near-vertical rays when the light's
+            #  projection falls next to the image box, slopes of 1e3 ... 1e4 -- which the reference's autograd evaluates in f32 and
+            #  the kernels' chain rule in f64: on these 16 ... 48-pixel images the two differ by up to ~1 % there; on the 256 x 256
+            #  golden batches they agree to 1e-4, tests/test_gpu_backward.py)
+            if e > (2e-2 if name == "light" else 2e-4):
+                over.append(dict(case=it, what=name, rel=e, B=B, H=H, W=W, N=N, product=g_.grad.cpu().numpy().tolist() if name in ("light", "ambient") else None,
+                                 oracle=c_.grad.numpy().tolist() if name in ("light", "ambient") else None, light=light.tolist(),
+                                 light_pt=oh["unit_light_direction"].detach().reshape(B, 3).mul(4013.0).cpu().numpy().tolist()))
+    print(json.dumps({"mode": "fused single-light backward vs autograd through the materialised oracle", "cases": a.oracle, "seed": a.seed,
+                      "worst_relative_difference": worst, "gates": {"depth, albedo, ambient": 2e-4, "light": 2e-2}, "cases_over_the_gate": over, "ok": len(over) == 0,
+                      "seconds": time.time() - t0}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=400)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", type=int, default=-1, help="replay one case of the sequence and print its details")
+    ap.add_argument("--oracle", type=int, default=0,
+                    help="instead of the kernel-vs-kernel soak: this many SMALL random cases (sizes 16 ... 48, <= 40 samples) of the fused "
+                         "single-light backward against autograd through oracle/materialised.py + normals_restatement.py on the host "
+                         "-- the torch port that is bit-equal to the reference in forward and matches its autograd gradients")
     a = ap.parse_args()
+    if a.oracle > 0:
+        return oracle_soak(a)
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(a.seed)
     L_ = _lib.load()
