@@ -2,10 +2,20 @@
 
 hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box with the
 snapshot.  -ffp-contract=off is part of the numerical contract (see csrc/gcfr_device.hpp).
+
+The march kernels are templates over (tile width, samples per group); each shape is its own translation unit
+(csrc/gcfr_march_unit.hip compiled with -DGCFR_UNIT_TILE_W / -DGCFR_UNIT_GROUP) and the units compile in parallel:
+~95 s as one translation unit, ~20 s on 8 cores this way.
+
+    python geomconsistentfr_amd/build.py                          # the product library
+    python geomconsistentfr_amd/build.py --variant NAME -DMACRO   # lib/NAME.so (tools/build_variant.sh), select with GCFR_HIP_LIB
 """
+import concurrent.futures
 import os
 import shutil
 import subprocess
+import sys
+import tempfile
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
@@ -13,6 +23,9 @@ LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgcfr_hip.so")
 SOURCES = ["gcfr_shadow.hip", "gcfr_shade.hip", "gcfr_backward.hip", "gcfr_normals.hip", "gcfr_postprocess.hip",
            "gcfr_dataset.hip"]
+MARCH_UNIT = "gcfr_march_unit.hip"
+# (tile width, samples per group): the default shape first -- it is the largest unit (it also holds the LDS-staged kernels)
+MARCH_UNITS = [(16, 4), (16, 2), (16, 1), (8, 4), (8, 2), (8, 1), (32, 4), (32, 2), (32, 1), (64, 4), (64, 2), (64, 1)]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fno-fast-math", "-munsafe-fp-atomics", "-Wall"]
 
@@ -28,9 +41,9 @@ HASH_PATH = os.path.join(LIB_DIR, "libgcfr_hip.srchash")
 
 
 def source_hash() -> str:
-    """sha256 over the flags and every file the library is compiled from (csrc/*, include/gcfr.h)."""
+    """sha256 over the flags, the list of march units and every file the library is compiled from (csrc/*, include/gcfr.h)."""
     import hashlib
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + " " + repr(MARCH_UNITS)).encode())
     deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(PKG, "..", "include", "gcfr.h")]
     for d in deps:
         h.update(os.path.basename(d).encode())
@@ -48,18 +61,47 @@ def needs_build() -> bool:
         return f.read().strip() != source_hash()
 
 
+def compile_and_link(out: str, defines=(), verbose: bool = False, jobs=None) -> str:
+    """Every translation unit to an object (in parallel), then one link.  -DGCFR_FAST_BUILD: the default march shape only."""
+    hipcc = _hipcc()
+    defines = list(defines)
+    cflags = [f for f in FLAGS if f != "-shared"] + defines
+    units = MARCH_UNITS[:1] if "-DGCFR_FAST_BUILD" in defines else MARCH_UNITS
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with tempfile.TemporaryDirectory(prefix="gcfr_build_") as tmp:
+        jobs_list = [([hipcc] + cflags + ["-DGCFR_UNIT_TILE_W=%d" % tw, "-DGCFR_UNIT_GROUP=%d" % g, "-c",
+                      os.path.join(CSRC, MARCH_UNIT), "-o", os.path.join(tmp, "march_%d_%d.o" % (tw, g))]) for tw, g in units]
+        jobs_list += [([hipcc] + cflags + ["-c", os.path.join(CSRC, s), "-o", os.path.join(tmp, s.replace(".hip", ".o"))])
+                      for s in SOURCES]
+
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed (%d): %s\n%s" % (r.returncode, " ".join(cmd), r.stderr[-4000:]))
+            if r.stderr.strip():
+                sys.stderr.write(r.stderr)
+            return cmd[-1]
+
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(len(jobs_list), os.cpu_count() or 4)) as ex:
+            objs = list(ex.map(run, jobs_list))
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    compile_and_link(LIB_PATH, verbose=verbose)
     with open(HASH_PATH, "w") as f:
         f.write(source_hash() + "\n")
     return LIB_PATH
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    argv = sys.argv[1:]
+    if argv and argv[0] == "--variant":
+        print(compile_and_link(os.path.join(LIB_DIR, argv[1] + ".so"), defines=argv[2:], verbose=True))
+    else:
+        print(build(force=True, verbose=True))

@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
 """Register / scratch / occupancy table of the march kernels: tools/resusage.py [file.hip] [extra hipcc flags...] [--all]
-(hipcc -Rpass-analysis=kernel-resource-usage on csrc/gcfr_shadow.hip, condensed)."""
+(hipcc -Rpass-analysis=kernel-resource-usage on csrc/gcfr_march_unit.hip -- the default shape, 16 x 4 tiles and groups of
+four, unless -DGCFR_UNIT_TILE_W= / -DGCFR_UNIT_GROUP= say otherwise -- condensed; --all: every kernel of the unit)."""
 import os
 import re
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".hip") else "gcfr_shadow.hip"
+src = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".hip") else "gcfr_march_unit.hip"
 extra = [a for a in sys.argv[1:] if a != "--all" and not a.endswith(".hip")]
+if src == "gcfr_march_unit.hip":
+    extra += [d for d, key in (("-DGCFR_UNIT_TILE_W=16", "GCFR_UNIT_TILE_W"), ("-DGCFR_UNIT_GROUP=4", "GCFR_UNIT_GROUP"))
+              if not any(key in a for a in extra)]
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
        "-fno-fast-math", "-munsafe-fp-atomics", "-Rpass-analysis=kernel-resource-usage",
        os.path.join(ROOT, "geomconsistentfr_amd", "csrc", src), "-o", "/tmp/_resusage.so"] + extra
@@ -28,7 +32,7 @@ for line in out.splitlines():
 show_all = "--all" in sys.argv
 for r in rows:
     n = r["name"].replace("gcfr::", "").replace("void ", "").split("(")[0]
-    if not show_all and "quad" in n and not re.search(r"<8, true, (true, |false, )?4, true", n):
+    if not show_all and "quad" in n and not re.search(r"<\d+, true, (true, |false, )?\d, true", n):
         continue
     print("%-70s sgpr %3s vgpr %3s scratch %4s occ %s lds %s" % (n, r.get("TotalSGPRs"), r.get("VGPRs"), r.get("ScratchSize"),
                                                                  r.get("Occupancy"), r.get("LDS")))
