@@ -22,7 +22,8 @@ _p, _i, _f, _d = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_doubl
 
 N_COUNTERS = 16      # GCFR_N_COUNTERS
 COUNTER_NAMES = ("tiles", "groups_nominal", "groups_visited", "bound_tests", "bodies", "lane_samples", "early_exits",
-                 "tie_remarches", "samples_in_range", "bounds_given_up", "visits_after_last_body", "visits_before_first_body")
+                 "tie_remarches", "samples_in_range", "bounds_given_up", "visits_after_last_body", "visits_before_first_body",
+                 "trail_enter", "trail_skips", "trail_leave")
 
 
 class Options(ctypes.Structure):

@@ -208,6 +208,18 @@ __host__ __device__ inline int zb_stride(int H, int W) { return (zb_max_tiles(H,
 // mask bitmap of the LDS-staged march: one bit per cell (1 = mask cell non-zero), row-major, 32 cells per dword,
 // per-mask stride padded to 1 KiB; needs W % 32 == 0
 __host__ __device__ inline int bitmap_stride_bytes(int H, int W) { return (((H * W) >> 3) + 1023) & ~1023; }
+// "horizon" tables of the trailing loop's termination test (build_horizon_block): per image four arrays of running maxima
+// {col_pre, col_suf, row_pre, row_suf} of the depth an unmasked sample can read, each kHorizonDim entries and CENTRED: entry
+// kHorizonDim/2 + X belongs to image-plane column X = c - W/2 (row entry kHorizonDim/2 - Y to Y = H/2 - r), entries outside the
+// image repeat the nearest one -- so the march indexes them with compile-time constants only (its scalar registers are all
+// taken).  An entry is a float4: the values of the kHorizonBands row bands the prepass builds the tables from; the value proper
+// is their maximum.  The tables sit BEHIND the image's depth-bounds records, inside the same per-image slot, and are reached
+// through the buffer descriptor the march already holds for the records.
+constexpr int kHorizonDim = 1024;
+constexpr int kHorizonBands = 4;
+__host__ __device__ inline bool hz_shape_ok(int H, int W) { return ((W & 3) == 0) && W <= kHorizonDim && H <= kHorizonDim; }
+// per-image slot of [records | horizon tables], in records (float4), a whole number of 1-KiB pieces
+__host__ __device__ inline int zb_slot(int H, int W) { return hz_shape_ok(H, W) ? zb_stride(H, W) + 4 * kHorizonDim : zb_stride(H, W); }
 
 // Sum over each 16-lane row of the wave, result in every lane of the row's last lane ... read with readlane(row*16+15).
 __device__ inline float row_sum_f32(float v)
@@ -266,7 +278,7 @@ struct ShadowQuadArgs {
     const float *depth;     // (B,H,W)      own-pixel depth
     const float4 *quad;     // (B,H+1,W+1)  prepass output
     const int *bbox;        // (MB,n_stat,4) prepass output: partial mask bounding boxes {r_min, c_min, -r_max, -c_max}
-    const float4 *zb;       // (B,zb_stride) prepass output: depth bounds grid {a, b, c_lo, c_hi}, or null (skip off)
+    const float4 *zb;       // (B,zb_slot) prepass output: depth bounds grid {a, b, c_lo, c_hi}, or null (skip off)
     const int *zrange;      // (B,n_stat,2) prepass output: partial depth ranges {z_min, -z_max} (sortable ints)
     const int *mones;       // (MB,n_stat)  prepass output: 1 iff every mask cell of the chunk is non-zero
     int *tflag;             // [0] prepass output: 1 iff the sample table is increasing, inside [0,1] and uniform
@@ -278,6 +290,7 @@ struct ShadowQuadArgs {
     int32_t mask_batch, B, L, H, W, N;
     int32_t tiles_x, tiles_y;  // tiles per image row / column
     int32_t bl_offset;         // first (image, light) index of this launch (grid z is limited to 65535)
+    int32_t hz_off;            // byte offset of the horizon tables behind each image's depth-bounds records; -1: not built
     MarchEpilogueArgs epi;
 };
 
@@ -312,7 +325,8 @@ __device__ inline int lo32(double v)
 // Work counters of the counting build (-DGCFR_COUNTERS; tools/count_work.py): wave-uniform tallies, added to
 // gcfr_options.counters once per tile.  Compiled out of the product build.
 enum { kCntTiles, kCntGroupsNominal, kCntGroupsVisited, kCntBoundTests, kCntBodies, kCntLaneSamples, kCntEarlyExit,
-       kCntTieRemarch, kCntSamplesInRange, kCntBoundsGivenUp, kCntVisitsAfterLastBody, kCntVisitsBeforeFirstBody, kCntUsed };
+       kCntTieRemarch, kCntSamplesInRange, kCntBoundsGivenUp, kCntVisitsAfterLastBody, kCntVisitsBeforeFirstBody,
+       kCntTrailEnter, kCntTrailSkips, kCntTrailLeave, kCntUsed };
 #ifdef GCFR_COUNTERS
 #define GCFR_COUNT(i, n) (cnt[i] += (unsigned)(n))
 #else
@@ -422,7 +436,7 @@ __device__ inline void stage_lds(ArgPtr a, int b, bool with_bitmap)
     const int H = a->H, W = a->W;
     const int bm_bytes = bitmap_stride_bytes(H, W), zb_bytes = a->zb ? zb_stride(H, W) * 16 : 0;
     const char *gbm = (const char *)a->bitmap + (size_t)(a->mask_batch == 1 ? 0 : b) * bm_bytes;
-    const char *gzb = (const char *)a->zb + (size_t)b * zb_stride(H, W) * 16;
+    const char *gzb = (const char *)a->zb + (size_t)b * zb_slot(H, W) * 16;
     const int n_bm = with_bitmap ? (bm_bytes >> 10) : 0, n_zb = zb_bytes >> 10;
     for (int ch = wave; ch < n_bm + n_zb; ch += 4) {
         const bool is_bm = ch < n_bm;
@@ -464,6 +478,13 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // sample range of this wave
     constexpr bool KSPLIT = SPLIT == 1;
+#ifndef GCFR_TRAIL
+#define GCFR_TRAIL 1
+#endif
+#ifndef GCFR_HORIZON
+#define GCFR_HORIZON 1
+#endif
+    constexpr bool TRAIL = (GCFR_TRAIL != 0) && !KSPLIT && !ALL_ONES && !LDS;  // the trailing loop, see the sample loop
     const int chunk = KSPLIT ? (a->N + 3) >> 2 : a->N;
     const int k_lo = KSPLIT ? wave * chunk : 0;
     const int N = KSPLIT ? min(a->N, k_lo + chunk) : a->N;  // exclusive upper bound ("N" below)
@@ -607,9 +628,20 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     const bool zb_trusted = __builtin_amdgcn_readfirstlane((int)zfits) != 0;
     const int zntw = (W >> zls) + 1;
     const __amdgpu_buffer_rsrc_t zr =
-        make_rsrc(a->zb + (size_t)b * zb_stride(H, W), zb_max_tiles(H, W) * (int)sizeof(float4));
+        make_rsrc(a->zb + (size_t)b * zb_slot(H, W), zb_slot(H, W) * (int)sizeof(float4));  // (records, then the horizon tables)
     const float nrm = __builtin_sqrtf(BCx * BCx + BCy * BCy);
     const float c1 = BCz * ((dxf * BCx + dyf * BCy) / nrm);
+    // From here on the ray's f32 direction is RE-DERIVED from the f64 one where it is needed (the bounds test, the horizon
+    // look-up, the tie re-march): (float)dx64 == dxf for every finite ray, and a non-finite ray takes no decision from either
+    // (Kerr = +inf, c1 = NaN).  Two conversions per bounds test buy two registers -- the ones the six-wave kernel lacked with
+    // the trailing loop in place, when the allocator spilled an f64 ray constant into the bodies instead.  (Laundered: or the
+    // loop-invariant conversion is hoisted straight back into a register.)
+    auto dir_f32 = [&](float &dxl, float &dyl) {
+        double dx_l = dx64, dy_l = dy64;
+        asm volatile("" : "+v"(dx_l), "+v"(dy_l));
+        dxl = (float)dx_l;
+        dyl = (float)dy_l;
+    };
     const float Qz = nrm * zb;
     const float t_abs = __builtin_bit_cast(float, tfl[kTfTabs]);  // max(|tt[0]|, |tt[N-1]|)
     // Give-up test (a heuristic about WORK, never about results: without the bounds every group is marched).  A group
@@ -624,7 +656,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 #endif
     if (use_zb) {
         const int own = __mul24((qy * TILE_H) >> zls, zntw) + ((tx * TILE_W) >> zls);
-        const ConstF32Ptr rec = (ConstF32Ptr)(unsigned long long)a->zb + 4 * ((size_t)b * zb_stride(H, W) + own);
+        const ConstF32Ptr rec = (ConstF32Ptr)(unsigned long long)a->zb + 4 * ((size_t)b * zb_slot(H, W) + own);
         const float band = rec[3] - rec[2];  // c_hi - c_lo (wave-uniform address: scalar loads)
         const bool hopeless = !(fabsf(c1) * t_abs >= GCFR_GIVEUP_FACTOR * nrm * band);  // (NaN / inf bands: hopeless)
         if (__builtin_amdgcn_ballot_w64(!hopeless) == 0ull) {
@@ -639,7 +671,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     // its distance is certainly below the masked value 1e6 (safeS, wave-uniform).  A lane whose remaining
     // samples all lie outside the mask's bounding box is finished too (they are masked: any_masked).  When
     // every lane of the wave is finished the march stops -- it saves the mask gathers of the rest of the ray.
-    float Dcap = __builtin_inff();   // n (zcap - zb) + Kerr; +inf: never finished by the bound
+    float gz_cap = __builtin_inff();  // (wave-uniform) the cap: depth maximum over what a sample can read, >= 0; +inf: never finished by the bound
     float safeS = 0.0f;
     if (use_zb) {
         // r: bound on |BA|'s components over the whole image (x, y extent; depth range incl. the sampled 0)
@@ -652,9 +684,16 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         const float K = __builtin_fmaf(K2, rr, K1) + nrm * (1.2e-2f + 8e-6f * (float)max(H, W));
         if ((nrm > 0.0f) && finite_ray && (K - K == 0.0f)) {
             Kerr = K;
-            if (c1 > 0.0f)
-                Dcap = __builtin_fmaf(nrm, fmaxf(gz_hi, 0.0f), -Qz) + K;  // NaN / inf: the test below fails
         }
+        // the cap: the depth maximum over what an unmasked sample can read where the prepass built the horizon tables
+        // (col_suf[0], see build_horizon_block), else over the whole image; either way >= 0 (NaN / inf: the test fails)
+        if (a->hz_off >= 0) {  // col_suf's first entry: the maximum over every column (of each band)
+            const ConstF32Ptr e = (ConstF32Ptr)(unsigned long long)a->zb + 4 * ((size_t)b * zb_slot(H, W) + zb_stride(H, W) + kHorizonDim);
+            gz_cap = fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3]));
+        } else {
+            gz_cap = fmaxf(gz_hi, 0.0f);
+        }
+        gz_cap = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gz_cap)));  // (an SGPR, for the compiler)
         // d = sqrt(S)/den < 1e6 for certain when S < 0.98e12 den^2; wave minimum -> SGPR
         const float den2 = (BCx * BCx + BCy * BCy) + BCz * BCz;
         const float s_lane = (den2 - den2 == 0.0f) ? 0.98e12f * den2 : 0.0f;
@@ -775,9 +814,13 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     auto finish_check = [&](int k0, double tn64, bool check_finished) -> bool {
         if (check_finished && use_zb && k0 + DEPTH < k_end) {
             const float tn = (float)tn64;  // tt[k0 + DEPTH]: the next group's first value
-            const float gd = __builtin_fmaf(c1, tn, -Dcap);
+            // (n (cap - zb) + Kerr re-evaluated per test: as a per-lane constant it was one register more than the six-wave
+            //  kernel has once the trailing loop is in place; Kerr = +inf where the bound is not valid: gd = -inf)
+            float nrm_l = nrm;  // (laundered: or the loop-invariant sub-expression is hoisted back into a register and spilled)
+            asm volatile("" : "+v"(nrm_l));
+            const float gd = __builtin_fmaf(c1, tn, -(__builtin_fmaf(nrm_l, gz_cap, -(nrm_l * zb)) + Kerr));
             const float bS = bestS;
-            const bool finished = ((gd > 0.0f) && (gd * gd * 0.998f > bS) && (bS < safeS)) ||
+            const bool finished = ((c1 > 0.0f) && (gd > 0.0f) && (gd * gd * 0.998f > bS) && (bS < safeS)) ||
                                   (lane_last < k0 + DEPTH);
             if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) {
                 any_masked |= (lane_last < k0 + DEPTH);
@@ -792,11 +835,19 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     auto bound_cw = [&](const f32x4 &cz, double ta64, double tb64) -> bool {
             GCFR_COUNT(kCntBoundTests, 1);
             const float ta = (float)ta64, tb = (float)tb64;  // tt[k0], tt[clampk(k0 + DEPTH - 1)]
+            // (n zb re-multiplied per test from a laundered zb: hoisted out of the loops it is one more live register than the
+            //  inference kernel has at six waves -- with the trailing loop in place the allocator spilled Dcap for it)
+            float zb_l = zb;
+            if (TRAIL && !WANT_ARGMIN)
+                asm volatile("" : "+v"(zb_l));
+            const float Qz = nrm * zb_l;
             const float Ta = c1 * ta, Tb = c1 * tb;
             const float Tlo = fminf(Ta, Tb), Thi = fmaxf(Ta, Tb);
             // surface band at the sample position s(t) = (x, y) + t d:  z in A0 + t A1 + [c_lo, c_hi], so
             // G(t) = n (z - zb) - c1 t  lies in  [F_lo + t E, F_hi + t E]: linear in t, extremes at the group's ends
-            const float A0 = __builtin_fmaf(cz.x, x, cz.y * y), A1 = __builtin_fmaf(cz.x, dxf, cz.y * dyf);
+            float dxl, dyl;
+            dir_f32(dxl, dyl);
+            const float A0 = __builtin_fmaf(cz.x, x, cz.y * y), A1 = __builtin_fmaf(cz.x, dxl, cz.y * dyl);
             const float E = __builtin_fmaf(nrm, A1, -c1);
             const float Flo = __builtin_fmaf(nrm, A0 + cz.z, -Qz), Fhi = __builtin_fmaf(nrm, A0 + cz.w, -Qz);
             const float eA = ta * E, eB = tb * E;
@@ -809,9 +860,12 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     // group's bounds record, tested here if some lane has an unmasked sample; LAZY = true (LDS-staged variant): the
     // caller has tested it already and passes the lane's verdict in `cw_in`.  ta64 / tb64: the group's first / last
     // table value; tn64: the next group's first one.
+    bool all_lazy = false;  // (wave-uniform) set by consume(): the group just consumed could have been skipped without its mask
     auto consume = [&](int k0, const uint32_t (&cm)[DEPTH], const f32x4 &cz, double ta64, double tb64, double tn64,
                        bool check_finished, auto lazy, bool cw_in) -> bool {
         constexpr bool LAZY = decltype(lazy)::value;
+        if (TRAIL)
+            all_lazy = false;
         if (!LAZY)
             GCFR_COUNT(kCntGroupsVisited, 1);
 #ifdef GCFR_COUNTERS
@@ -829,6 +883,8 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         } else if (run_body && use_zb) {
             const bool cannot_win = bound_cw(cz, ta64, tb64);
             run_body = __builtin_amdgcn_ballot_w64(!none && !cannot_win) != 0ull;
+            if (TRAIL)  // (see the trailing loop below) nothing of this group mattered to any lane, masked or not
+                all_lazy = !run_body && __builtin_amdgcn_ballot_w64(!((cannot_win && (bestS < safeS)) || (lane_last < k0))) == 0ull;
         }
         // samples of the group evaluated together (texel gathers in flight): one at a time in the throughput
         // variants (fewer live registers -> forced occupancy, see the __global__ wrappers), the whole group in the
@@ -990,13 +1046,113 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         prefetch(bufA);
         load_tq(k_first + DEPTH);
     }
+    int k_trail = k_end;  // where the trailing loop takes over (k_end: nowhere)
+    f32x4 zcur = bufA.z;  // ... and the bounds record of that group
     for (int k0 = k_first; k0 < k_end; k0 += 2 * DEPTH) {
         if (!group(k0, bufA, bufB, false))
             break;
         if (k0 + DEPTH >= k_end)
             break;
+        if (TRAIL && all_lazy) {
+            k_trail = k0 + DEPTH;
+            zcur = bufB.z;
+            break;
+        }
         if (!group(k0 + DEPTH, bufB, bufA, true))  // the termination test runs every other group (it costs ~18 VALU)
             break;
+        if (TRAIL && all_lazy && k0 + 2 * DEPTH < k_end) {
+            k_trail = k0 + 2 * DEPTH;
+            zcur = bufA.z;
+            break;
+        }
+    }
+    // Trailing loop (round 3).  72 % of the groups a tile visits on face-shaped data come AFTER its last body: the rays run on
+    // above the surface, the bounds test rejects group after group, and each of them still paid for four f64 sample
+    // positions and four mask gathers one group ahead.  Once the test of a group has come out "nothing here matters to
+    // any lane" -- every lane either cannot win and holds a minimum certainly below the masked value 1e6 (bestS < safeS:
+    // its `any_masked` is irrelevant, see the early termination), or has left the mask's bounding box for good (its
+    // samples are masked: any_masked) -- the wave predicts the same for the groups that follow (measured on the bench
+    // faces: 53 % of all visited groups are walked this way, and of 4,915 tiles that make the prediction 402 ever meet a
+    // group that breaks it) and walks them with the bounds records alone: first and last cell of the group, one record
+    // gather a group ahead, the test; no mask, no middle positions.  A group whose test does NOT come out that way gets
+    // its mask bytes on the spot (one exposed gather latency) and the ordinary treatment.  Exact: a group is only ever
+    // skipped on the strength of the same test the main loop applies, and then the mask decides nothing for it.
+    if (TRAIL) {
+        if (k_trail < k_end)
+            GCFR_COUNT(kCntTrailEnter, 1);
+        auto record_of = [&](double t_first, double t_last) -> f32x4 {  // the bounds record of the group with these table values
+            int ca, ra, cb, rb;
+            (void)mask_offset(x64 + t_first * dx64, y64 + t_first * dy64, ca, ra);
+            (void)mask_offset(x64 + t_last * dx64, y64 + t_last * dy64, cb, rb);
+            return zb_fetch(ca, ra, cb, rb);
+        };
+        // here: zcur = the record of group k_trail, tc0 / tc3 = its first / last table value, tq = the table values of the group after it
+        // Termination in this loop: the same test as finish_check(), with the cap taken from the horizon tables where the
+        // prepass built them -- the maximum over the columns AND over the rows the rest of this lane's ray can still touch
+        // (running maxima from the next sample's cell towards the side the ray is heading for; two cells of slack cover the
+        // bilinear corners and the f32 position), instead of the image-wide maximum.
+        for (int k0 = k_trail; k0 < k_end; k0 += DEPTH) {
+            const double ta64 = tc0, tb64 = tc3;
+            tc0 = tq[0];
+            tc3 = tq[DEPTH - 1];
+            const f32x4 znext = record_of(tc0, tc3);  // group k0 + DEPTH, one group ahead
+            load_tq(k0 + 2 * DEPTH);
+            const bool check = (((k0 - k_trail) / DEPTH) & 1) != 0;
+            // (the tables' offset is read from the kernel arguments at every use -- a scalar load -- rather than kept in a register)
+            const int hz_off = (GCFR_HORIZON != 0) && check && (k0 + DEPTH < k_end) ? launder(a)->hz_off : -1;
+            const bool check_hz = hz_off >= 0;
+            const float tn = (float)tc0;  // the next group's first table value
+            const bool cw = bound_cw(zcur, ta64, tb64);
+            const bool gone = lane_last < k0;
+            GCFR_COUNT(kCntGroupsVisited, 1);
+            if (__builtin_amdgcn_ballot_w64(!((cw && (bestS < safeS)) || gone)) == 0ull) {
+                any_masked |= gone;
+                GCFR_COUNT(kCntTrailSkips, 1);
+#ifdef GCFR_COUNTERS
+                ++cnt_since_body;
+#endif
+                if (check_hz) {
+                    // (the two gathers are issued here, not a group ahead: eight more live registers across the bounds test
+                    //  spill in the six-wave kernel; the wave waits for them once per two groups of this loop)
+                    float dxl, dyl;
+                    dir_f32(dxl, dyl);
+                    const int ci = (int)__builtin_floorf(__builtin_fmaf(tn, dxl, x)), ri = (int)__builtin_floorf(-__builtin_fmaf(tn, dyl, y));
+                    constexpr int C = kHorizonDim / 2, M = kHorizonDim - 1;
+                    const int ic = (dxl >= 0.0f) ? kHorizonDim + min(max(ci + (C - 2), 0), M) : min(max(ci + (C + 3), 0), M);               // col_suf : col_pre
+                    const int ir = (dyl > 0.0f) ? 2 * kHorizonDim + min(max(ri + (C + 3), 0), M) : 3 * kHorizonDim + min(max(ri + (C - 2), 0), M);  // row_pre : row_suf
+                    const f32x4 zc4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, hz_off + (ic << 4), 0, 0));
+                    const f32x4 zr4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, hz_off + (ir << 4), 0, 0));
+                    const float zc = fmaxf(fmaxf(zc4.x, zc4.y), fmaxf(zc4.z, zc4.w)), zr_ = fmaxf(fmaxf(zr4.x, zr4.y), fmaxf(zr4.z, zr4.w));
+                    float nrm_l = nrm;  // (laundered, see finish_check)
+                    asm volatile("" : "+v"(nrm_l));
+                    const float Dc = __builtin_fmaf(nrm_l, fminf(zc, zr_), -(nrm_l * zb)) + Kerr;  // (Kerr = inf: never finished)
+                    const float gd = __builtin_fmaf(c1, tn, -Dc);
+                    const bool past = lane_last < k0 + DEPTH;
+                    const bool finished = ((c1 > 0.0f) && (gd > 0.0f) && (gd * gd * 0.998f > bestS) && (bestS < safeS)) || past;
+                    if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) {
+                        any_masked |= past;
+                        GCFR_COUNT(kCntEarlyExit, 1);
+                        break;
+                    }
+                } else if (!finish_check(k0, tc0, check)) {
+                    break;
+                }
+            } else {  // some lane needs this group: its mask bytes now, then as in the main loop
+                GCFR_COUNT(kCntTrailLeave, 1);
+                uint32_t cm[DEPTH];
+#pragma unroll
+                for (int j = 0; j < DEPTH; ++j) {
+                    const double tj = (j == 0) ? ta64 : ((j == DEPTH - 1) ? tb64 : (double)tt[clampk(k0 + j)]);
+                    int cj, rj;
+                    cm[j] = buf_load_u8(mr, mask_offset(x64 + tj * dx64, y64 + tj * dy64, cj, rj));
+                }
+                if (!consume(k0, cm, zcur, ta64, tb64, tc0, check, std::true_type{}, cw))
+                    break;
+                zcur = record_of(tc0, tc3);  // (fetched again rather than kept in registers across the bodies)
+                continue;
+            }
+            zcur = znext;
+        }
     }
     }
 
@@ -1047,8 +1203,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
             rc.x = x;
             rc.y = y;
             rc.zb = zb;
-            rc.dx = dxf;
-            rc.dy = dyf;
+            dir_f32(rc.dx, rc.dy);
             rc.BCx = BCx;
             rc.BCy = BCy;
             rc.BCz = BCz;

@@ -168,7 +168,7 @@ __device__ inline void build_zbounds_block(int block, int b, const float *__rest
     const int ntw = (W >> ls) + 1, nth = (H >> ls) + 1;
     const int tile = block * 4 + (int)(threadIdx.x >> 6);
     if (block == 0 && threadIdx.x == 0)
-        zb[(size_t)b * zb_stride(H, W) + zb_max_tiles(H, W) - 1] =
+        zb[(size_t)b * zb_slot(H, W) + zb_max_tiles(H, W) - 1] =
             make_float4(0.0f, 0.0f, -__builtin_inff(), __builtin_inff());
     if (tile >= nth * ntw)
         return;
@@ -207,7 +207,7 @@ __device__ inline void build_zbounds_block(int block, int b, const float *__rest
         const float wlo = f32_unsortable(wave_min_i32(f32_sortable(lo)));
         const float whi = -f32_unsortable(wave_min_i32(f32_sortable(-hi)));
         if (lane == 0)
-            zb[(size_t)b * zb_stride(H, W) + tile] = make_float4(pa, pb, wlo, whi);
+            zb[(size_t)b * zb_slot(H, W) + tile] = make_float4(pa, pb, wlo, whi);
         return;
     }
     // pass 1: slopes from the means of the tile's four s x s quadrants (finite proper cells only).  Row q of
@@ -256,7 +256,7 @@ __device__ inline void build_zbounds_block(int block, int b, const float *__rest
     const float wlo = f32_unsortable(wave_min_i32(f32_sortable(lo)));
     const float whi = -f32_unsortable(wave_min_i32(f32_sortable(-hi)));
     if (lane == 0)
-        zb[(size_t)b * zb_stride(H, W) + tile] = make_float4(pa, pb, wlo, whi);
+        zb[(size_t)b * zb_slot(H, W) + tile] = make_float4(pa, pb, wlo, whi);
 }
 
 __device__ inline void stat_mask_dword(uint32_t d, int r, int c, int &rmin, int &cmin, int &nrmax, int &ncmax, int &all_set)
@@ -387,6 +387,143 @@ __device__ inline void build_bitmap_block(int block, int b, const uint8_t *__res
     bitmap[(size_t)b * (bitmap_stride_bytes(H, W) >> 2) + i] = bits;
 }
 
+// Horizon tables (round 3).  The march's early termination asks "is the ray, from here on, above everything it could still
+// sample?" and answers with the image's depth maximum -- one number, so a ray that has cleared the nose keeps marching over
+// the cheek until it is higher than the nose.  Sharper, and still one comparison: the maximum over the columns (rows) the
+// REST of the ray can touch.  A ray runs monotonically in x and in y, so those are running maxima from its current column
+// towards the side it is heading for: four tables per image,
+//     col_pre[c] = max over columns <= c,  col_suf[c] = max over columns >= c,  row_pre / row_suf likewise
+// (each kHorizonDim entries, centred, behind the image's depth-bounds records: see zb_slot), of
+//     colmax[c] = max over the column's LIVE cells of max(depth, 0)  (rowmax likewise).
+// A cell is live if an unmasked sample can read it: a sample's four bilinear corners lie within one cell of its rounded cell
+// (T8:472-494), so the live cells are the mask's non-zero cells dilated by one -- here by up to one dword of columns more
+// (the dilation works on ballots of "this lane's four mask bytes are not all zero"), a superset, which only makes the tables
+// larger: still bounds.  The corners' wrap partners (column / row -1 reads the last one, the texel grid's last column / row
+// pairs with the first) are in every entry: prefix tables include the last column / row, suffix tables the first.  0 is
+// included because integral sample positions read z = 0 (see the depth-bound skip).  NaN cells are dropped (a NaN sample never
+// wins), +inf stays +inf (never terminates).
+// Parallel without a combining pass: the image's rows are split into kHorizonBands bands and a block (one per band and kind
+// -- column tables / row tables) computes the tables OF ITS BAND ALONE (the column maxima over its rows; its own rows'
+// maxima, zero elsewhere).  Maximum commutes with the running maxima, so the table proper is the element-wise maximum of the
+// bands' tables -- which the march takes at look-up time: entry i is ONE float4 holding the four bands' values (one 16-byte
+// gather).  Each block reads a quarter of the depth and mask planes (float4 / dword per lane and row, all loads of a round in
+// flight), reduces into LDS and scans there.  Needs W % 4 == 0, 16-byte aligned planes and H, W <= kHorizonDim.
+__device__ inline void build_horizon_block(int job, int b, const float *__restrict__ depth, const uint8_t *__restrict__ mask,
+                                           int mask_batch, int H, int W, float4 *__restrict__ zb)
+{
+    __shared__ int s_val[kHorizonDim];  // colmax over the band's rows / rowmax of the band's rows, as int bits (>= 0: integer order == float order)
+    __shared__ int s_pre[kHorizonDim], s_suf[kHorizonDim];
+    const int kind = job / kHorizonBands, k = job - kind * kHorizonBands;  // kind 0: column tables, 1: row tables; k: the band
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bandrows = (H + kHorizonBands - 1) / kHorizonBands, b_lo = min(H, k * bandrows), b_hi = min(H, b_lo + bandrows);
+    const int n = kind == 0 ? W : (b_hi - b_lo);  // entries this block reduces into: its columns / its rows
+    for (int i = tid; i < kHorizonDim; i += 256)
+        s_val[i] = 0;
+    __syncthreads();
+    const size_t P = (size_t)H * W;
+    const float *z = depth + (size_t)b * P;
+    const uint8_t *m = mask + (size_t)(mask_batch == 1 ? 0 : b) * P;
+    const int wrows = (b_hi - b_lo + 3) >> 2, r_lo = min(b_hi, b_lo + wave * wrows), r_hi = min(b_hi, r_lo + wrows);  // this wave's rows
+    const int segs = (W + 255) >> 8;                                                                                  // 256 columns (64 lanes x 4) per segment
+    constexpr int RB = 16;  // rows per round: their 18 mask dwords and 16 depth float4 are all in flight before the first is used
+    for (int sg = 0; sg < segs; ++sg) {
+        const int c = (sg << 8) + (lane << 2);
+        const bool in_w = c < W;
+        const int cc = in_w ? c : 0;  // (loads stay inside the plane; their values are dropped)
+        // dilation across the segment's edges is not looked up: with more than one segment the edge lanes are always live
+        const unsigned long long edge = segs > 1 ? 0x8000000000000001ull : 0ull;
+        float4 cm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // column job: running maxima of this lane's four columns
+        for (int r0 = r_lo; r0 < r_hi; r0 += RB) {
+            uint32_t md[RB + 2];
+            float4 dv[RB];
+#pragma unroll
+            for (int j = 0; j < RB + 2; ++j) {
+                const int r = r0 - 1 + j;
+                md[j] = *(const uint32_t *)(m + (size_t)min(max(r, 0), H - 1) * W + cc);
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+                dv[j] = *(const float4 *)(z + (size_t)min(r0 + j, H - 1) * W + cc);
+            unsigned long long bits[RB + 2];  // lanes whose four mask cells of the row are not all zero
+#pragma unroll
+            for (int j = 0; j < RB + 2; ++j) {
+                const int r = r0 - 1 + j;
+                bits[j] = __builtin_amdgcn_ballot_w64(in_w && r >= 0 && r < H && md[j] != 0);
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int r = r0 + j;
+                const unsigned long long v3 = bits[j] | bits[j + 1] | bits[j + 2];
+                const unsigned long long live = v3 | (v3 << 1) | (v3 >> 1) | edge;
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (in_w && r < r_hi && ((live >> lane) & 1ull))  // (fmaxf drops NaN)
+                    v = make_float4(fmaxf(dv[j].x, 0.0f), fmaxf(dv[j].y, 0.0f), fmaxf(dv[j].z, 0.0f), fmaxf(dv[j].w, 0.0f));
+                if (kind == 0) {
+                    cm = make_float4(fmaxf(cm.x, v.x), fmaxf(cm.y, v.y), fmaxf(cm.z, v.z), fmaxf(cm.w, v.w));
+                } else if (r < r_hi) {  // (wave-uniform)
+                    const float rm = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+                    const int wmax = -wave_min_i32(-__builtin_bit_cast(int, rm));  // (bits of a float >= 0)
+                    if (lane == 0)
+                        atomicMax(&s_val[r - b_lo], wmax);  // (one writer per row and segment; max across the segments)
+                }
+            }
+        }
+        if (kind == 0 && in_w) {
+            atomicMax(&s_val[c + 0], __builtin_bit_cast(int, cm.x));
+            atomicMax(&s_val[c + 1], __builtin_bit_cast(int, cm.y));
+            atomicMax(&s_val[c + 2], __builtin_bit_cast(int, cm.z));
+            atomicMax(&s_val[c + 3], __builtin_bit_cast(int, cm.w));
+        }
+    }
+    __syncthreads();
+    // running maxima over the n entries from either end: wave 0 the prefix, wave 1 the suffix; a lane owns E consecutive entries
+    if (wave < 2) {
+        const int E = (n + 63) >> 6, i0 = lane * E;
+        int run = 0;
+        for (int e = 0; e < E; ++e) {
+            const int i = i0 + e;  // position along the scan's direction
+            if (i < n) {
+                run = max(run, s_val[wave == 0 ? i : n - 1 - i]);
+                (wave == 0 ? s_pre : s_suf)[wave == 0 ? i : n - 1 - i] = run;
+            }
+        }
+        int incl = run;  // inclusive scan of the lanes' totals, then the exclusive one
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off);
+            if (lane >= off)
+                incl = max(incl, o);
+        }
+        int excl = __shfl_up(incl, 1);
+        if (lane == 0)
+            excl = 0;
+        for (int e = 0; e < E; ++e) {
+            const int i = i0 + e;
+            if (i < n) {
+                int *p = &(wave == 0 ? s_pre : s_suf)[wave == 0 ? i : n - 1 - i];
+                *p = max(*p, excl);
+            }
+        }
+    }
+    __syncthreads();
+    // centred tables: entry kHorizonDim/2 + (j - N/2) belongs to column / row j of the N the image has; entries outside repeat
+    // the nearest one.  Component k of the entry's float4 is this band's value.
+    constexpr int S = kHorizonDim;
+    float *out = (float *)(zb + (size_t)b * zb_slot(H, W) + zb_stride(H, W)) + (size_t)(kind == 0 ? 0 : 2 * S) * 4 + k;
+    const int N = kind == 0 ? W : H;
+    // the wrap partners: every prefix entry includes the image's last column / row, every suffix entry its first (of THIS band's values)
+    const int j_first = kind == 0 ? 0 : 0 - b_lo, j_last = kind == 0 ? W - 1 : H - 1 - b_lo;  // their positions among this block's n entries
+    const int add_pre = (n > 0 && j_last >= 0 && j_last < n) ? s_val[j_last] : 0;
+    const int add_suf = (n > 0 && j_first >= 0 && j_first < n) ? s_val[j_first] : 0;
+    const int total = n > 0 ? s_pre[n - 1] : 0;
+    for (int i = tid; i < S; i += 256) {
+        const int j = min(max(i - S / 2 + N / 2, 0), N - 1) - (kind == 0 ? 0 : b_lo);  // position among this block's entries (rows: may lie outside the band)
+        const int pre = n <= 0 ? 0 : (j < 0 ? 0 : (j >= n ? total : s_pre[j]));
+        const int suf = n <= 0 ? 0 : (j < 0 ? total : (j >= n ? 0 : s_suf[j]));
+        out[(size_t)i * 4] = __builtin_bit_cast(float, max(pre, add_pre));
+        out[(size_t)(S + i) * 4] = __builtin_bit_cast(float, max(suf, add_suf));
+    }
+}
+
 __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict__ depth,
                                                          float4 *__restrict__ quad, int H, int W,
                                                          PrepassLights pl,
@@ -397,25 +534,30 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
                                                          int want_z, int vec_ok, int N,
                                                          const double *__restrict__ t_table, int group,
                                                          int *__restrict__ tflag, uint32_t *__restrict__ bitmap,
-                                                         int bitmap_blocks)
+                                                         int bitmap_blocks, int hz_blocks)
 {
     const int Wp = W + 1, Hp = H + 1;
     const int b = blockIdx.y;
-    if ((int)blockIdx.x < zb_blocks) {
-        build_zbounds_block((int)blockIdx.x, b, depth, zb, H, W, N, t_table, group);
+    if ((int)blockIdx.x < hz_blocks) {  // (head of the grid: the longest job of the prepass; one block per image, kind and band)
+        build_horizon_block((int)blockIdx.x, b, depth, mask, mask_batch, H, W, zb);
         return;
     }
-    if ((int)blockIdx.x < zb_blocks + stat_blocks) {
-        build_stats_block((int)blockIdx.x - zb_blocks, b, depth, mask, mask_batch, H, W, bbox, zrange, mones,
+    const int bx = (int)blockIdx.x - hz_blocks;
+    if (bx < zb_blocks) {
+        build_zbounds_block(bx, b, depth, zb, H, W, N, t_table, group);
+        return;
+    }
+    if (bx < zb_blocks + stat_blocks) {
+        build_stats_block(bx - zb_blocks, b, depth, mask, mask_batch, H, W, bbox, zrange, mones,
                           want_z != 0, vec_ok != 0);
         return;
     }
-    if ((int)blockIdx.x < zb_blocks + stat_blocks + bitmap_blocks) {
+    if (bx < zb_blocks + stat_blocks + bitmap_blocks) {
         if (b < mask_batch)
-            build_bitmap_block((int)blockIdx.x - zb_blocks - stat_blocks, b, mask, H, W, bitmap);
+            build_bitmap_block(bx - zb_blocks - stat_blocks, b, mask, H, W, bitmap);
         return;
     }
-    const int qb = (int)blockIdx.x - zb_blocks - stat_blocks - bitmap_blocks;
+    const int qb = bx - zb_blocks - stat_blocks - bitmap_blocks;
     const int i = qb * blockDim.x + threadIdx.x;
     if (qb == 0 && b == 0 && threadIdx.x < 64) {
         // Is the sample table what the march's pruning / skipping reasons about -- increasing, inside [0, 1]
@@ -555,14 +697,14 @@ extern "C" void gcfr_options_default(gcfr_options *opt)
     opt->ksplit = opt->depth_bound_skip = opt->schedule = opt->tile_order = opt->lds_stage = -1;
 }
 
-// workspace layout: [quad texels | partial boxes | depth-bounds records | partial depth ranges | tflag | all-ones flags | mask bitmaps]
+// workspace layout: [quad texels | partial boxes | per image: depth-bounds records, horizon tables | partial depth ranges | tflag | all-ones flags | mask bitmaps]
 extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
 {
     if (B <= 0 || H <= 0 || W <= 0)
         return 0;
     const size_t n_stat = (size_t)n_stat_chunks(H, W);
     return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4) + (size_t)B * n_stat * 4 * sizeof(int) +
-           (size_t)B * (size_t)zb_stride(H, W) * sizeof(float4) + (size_t)B * n_stat * 2 * sizeof(int) +
+           (size_t)B * (size_t)zb_slot(H, W) * sizeof(float4) + (size_t)B * n_stat * 2 * sizeof(int) +
            (kQueueSlot + 1) * sizeof(int) + 12 + (size_t)B * n_stat * sizeof(int) + 16 +
            (((W & 31) == 0) ? (size_t)B * (size_t)bitmap_stride_bytes(H, W) : 0);  // mask bitmaps (LDS-staged march)
 }
@@ -664,7 +806,7 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         const size_t n_stat = (size_t)n_stat_chunks(H, W);
         int *bbox = (int *)((char *)workspace + (size_t)B * texels * sizeof(float4));
         float4 *zb = (float4 *)((char *)bbox + (size_t)B * n_stat * 4 * sizeof(int));
-        int *zrange = (int *)(zb + (size_t)B * zb_stride(H, W));  // (B, n_stat, 2)
+        int *zrange = (int *)(zb + (size_t)B * zb_slot(H, W));  // (B, n_stat, 2)
         int *tflag = zrange + (size_t)B * n_stat * 2;                 // [0] table flag
         int *mones = tflag + kQueueSlot + 4;                          // (B, n_stat) all-ones flags of the mask chunks
         uint32_t *bitmap = (uint32_t *)(((uintptr_t)(mones + (size_t)B * n_stat) + 15u) & ~(uintptr_t)15u);  // (MB, stride) 16-B aligned
@@ -686,10 +828,15 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         const int quad_blocks = (texels + 255) / 256;
         const int zb_blocks = use_zb ? (zb_max_tiles(H, W) + 3) / 4 : 0;  // sized for the finest stride
         const int bitmap_blocks = lds_stage ? ((H * W) / 32 + 255) / 256 : 0;
+        // horizon tables: for the trailing loop of the grid schedule's bounds-skipping march (not the k-split's quarter
+        // ranges, not the LDS-staged variant), where the shape and the planes' alignment allow vector loads
+        const bool horizon = (GCFR_HORIZON != 0) && use_zb && sch == kGrid && hz_shape_ok(H, W) && (((uintptr_t)depth & 15u) == 0) &&
+                             (((uintptr_t)mask_u8 & 3u) == 0);
+        const int hz_blocks = horizon ? 2 * kHorizonBands : 0;
         const int vec_ok = ((W & 15) == 0) && (((uintptr_t)depth & 15u) == 0) && (((uintptr_t)mask_u8 & 15u) == 0);
-        hipLaunchKernelGGL(build_quad_kernel, dim3(zb_blocks + (int)n_stat + bitmap_blocks + quad_blocks, B), dim3(256), 0, st,
+        hipLaunchKernelGGL(build_quad_kernel, dim3(hz_blocks + zb_blocks + (int)n_stat + bitmap_blocks + quad_blocks, B), dim3(256), 0, st,
                            depth, (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox, zrange, mones, zb, zb_blocks,
-                           (int)n_stat, use_zb ? 1 : 0, vec_ok, N, t_table, kn.group, tflag, bitmap, bitmap_blocks);
+                           (int)n_stat, use_zb ? 1 : 0, vec_ok, N, t_table, kn.group, tflag, bitmap, bitmap_blocks, hz_blocks);
         ShadowQuadArgs a = {};
         a.zb = use_zb ? zb : nullptr;
         a.zrange = zrange;
@@ -700,6 +847,7 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         a.bbox = bbox;
         a.mask = mask_u8;
         a.bitmap = bitmap;
+        a.hz_off = horizon ? zb_stride(H, W) * 16 : -1;
         a.light_pt = light_pt;
         a.t_table = t_table;
         a.counters = kn.counters;

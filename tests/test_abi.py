@@ -40,8 +40,9 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert L.gcfr_shadow_fwd(None, None, 1, None, 1, 1, 256, 256, 160, None, 0.0, None, None, None, None, 0, None, None) == -1
     # workspace: quad texels + 4 statistics chunks per 256x256 image (box 16 B + depth range 8 B) + depth-bounds records
     # (round 3: the records' per-image stride is a whole number of 1-KiB pieces -- 1090 -> 1152 records -- and one mask bitmap of
-    #  H*W/8 bytes per image follows, both for the LDS-staged march)
-    assert L.gcfr_shadow_workspace_bytes(8, 256, 256) == (8 * 257 * 257 * 16 + 8 * 4 * 16 + 8 * 1152 * 16 + 8 * 4 * 8 + 65 * 4 + 12
+    #  H*W/8 bytes per image follows, both for the LDS-staged march; behind each image's records 4 x 1024 float4 of horizon
+    #  tables for the trailing loop's termination test)
+    assert L.gcfr_shadow_workspace_bytes(8, 256, 256) == (8 * 257 * 257 * 16 + 8 * 4 * 16 + 8 * (1152 + 4096) * 16 + 8 * 4 * 8 + 65 * 4 + 12
                                                           + 8 * 4 * 4 + 16 + 8 * 8192)
     assert L.gcfr_light_prep(None, 1, 1, 0.0, 4013.0, None, None, None) == -1
     assert L.gcfr_shade_fwd(None, None, None, None, None, None, 1, 1, 8, 8, 0.5, None, None, None, None, None) == -1
