@@ -407,7 +407,7 @@ __device__ inline void build_bitmap_block(int block, int b, const uint8_t *__res
 // maxima, zero elsewhere).  Maximum commutes with the running maxima, so the table proper is the element-wise maximum of the
 // bands' tables -- which the march takes at look-up time: entry i is ONE float4 holding the four bands' values (one 16-byte
 // gather).  Each block reads a quarter of the depth and mask planes (float4 / dword per lane and row, all loads of a round in
-// flight), reduces into LDS and scans there.  Needs W % 4 == 0, 16-byte aligned planes and H, W <= kHorizonDim.
+// flight: GCFR_HORIZON_RB), reduces into LDS and scans there.  Needs W % 4 == 0, 16-byte aligned planes and H, W <= kHorizonDim.
 __device__ inline void build_horizon_block(int job, int b, const float *__restrict__ depth, const uint8_t *__restrict__ mask,
                                            int mask_batch, int H, int W, float4 *__restrict__ zb)
 {
@@ -425,7 +425,13 @@ __device__ inline void build_horizon_block(int job, int b, const float *__restri
     const uint8_t *m = mask + (size_t)(mask_batch == 1 ? 0 : b) * P;
     const int wrows = (b_hi - b_lo + 3) >> 2, r_lo = min(b_hi, b_lo + wave * wrows), r_hi = min(b_hi, r_lo + wrows);  // this wave's rows
     const int segs = (W + 255) >> 8;                                                                                  // 256 columns (64 lanes x 4) per segment
-    constexpr int RB = 16;  // rows per round: their 18 mask dwords and 16 depth float4 are all in flight before the first is used
+#ifndef GCFR_HORIZON_RB
+#define GCFR_HORIZON_RB 8
+#endif
+    // rows per round: their RB + 2 mask dwords and RB depth float4 are all in flight before the first is used.  8: the most that
+    // keeps the prepass kernel at 60 VGPRs = eight waves per SIMD -- with 16 (100 VGPRs, four waves) this job was a round
+    // shorter and every OTHER job of the prepass slower: -6 % on the bench with four batches in flight
+    constexpr int RB = GCFR_HORIZON_RB;
     for (int sg = 0; sg < segs; ++sg) {
         const int c = (sg << 8) + (lane << 2);
         const bool in_w = c < W;
