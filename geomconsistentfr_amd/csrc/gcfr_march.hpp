@@ -484,7 +484,11 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 #ifndef GCFR_HORIZON
 #define GCFR_HORIZON 1
 #endif
-    constexpr bool TRAIL = (GCFR_TRAIL != 0) && !KSPLIT && !ALL_ONES && !LDS;  // the trailing loop, see the sample loop
+#ifndef GCFR_TRAIL_ALL_ONES
+#define GCFR_TRAIL_ALL_ONES 1
+#endif
+    // the trailing loop, see the sample loop (all-ones masks: there is no mask work to save, but its termination test is the sharper one)
+    constexpr bool TRAIL = (GCFR_TRAIL != 0) && !KSPLIT && !LDS && (!ALL_ONES || (GCFR_TRAIL_ALL_ONES != 0));
     const int chunk = KSPLIT ? (a->N + 3) >> 2 : a->N;
     const int k_lo = KSPLIT ? wave * chunk : 0;
     const int N = KSPLIT ? min(a->N, k_lo + chunk) : a->N;  // exclusive upper bound ("N" below)
@@ -1097,7 +1101,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
             tc3 = tq[DEPTH - 1];
             const f32x4 znext = record_of(tc0, tc3);  // group k0 + DEPTH, one group ahead
             load_tq(k0 + 2 * DEPTH);
-            const bool check = (((k0 - k_trail) / DEPTH) & 1) != 0;
+            const bool check = (((k0 - k_trail) / DEPTH) & 1) != 0;  // every other group, as in the main loop (every group: measured level, -0.5 %)
             // (the tables' offset is read from the kernel arguments at every use -- a scalar load -- rather than kept in a register)
             const int hz_off = (GCFR_HORIZON != 0) && check && (k0 + DEPTH < k_end) ? launder(a)->hz_off : -1;
             const bool check_hz = hz_off >= 0;
@@ -1144,7 +1148,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
                 for (int j = 0; j < DEPTH; ++j) {
                     const double tj = (j == 0) ? ta64 : ((j == DEPTH - 1) ? tb64 : (double)tt[clampk(k0 + j)]);
                     int cj, rj;
-                    cm[j] = buf_load_u8(mr, mask_offset(x64 + tj * dx64, y64 + tj * dy64, cj, rj));
+                    cm[j] = ALL_ONES ? 1u : buf_load_u8(mr, mask_offset(x64 + tj * dx64, y64 + tj * dy64, cj, rj));
                 }
                 if (!consume(k0, cm, zcur, ta64, tb64, tc0, check, std::true_type{}, cw))
                     break;
