@@ -890,10 +890,12 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
             if (TRAIL)  // (see the trailing loop below) nothing of this group mattered to any lane, masked or not
                 all_lazy = !run_body && __builtin_amdgcn_ballot_w64(!((cannot_win && (bestS < safeS)) || (lane_last < k0))) == 0ull;
         }
-        // samples of the group evaluated together (texel gathers in flight): one at a time in the throughput
-        // variants (fewer live registers -> forced occupancy, see the __global__ wrappers), the whole group in the
-        // k-split variant, whose launches are tiny and latency-bound
-        constexpr int GCFR_BODY_CHUNK = KSPLIT ? DEPTH : 1;  // (KSPLIT here: SPLIT == 1 only)
+        // samples of the group evaluated together (texel gathers in flight): one at a time in the six-wave inference
+        // variant (fewer live registers -> forced occupancy, see the __global__ wrappers), two in the argmin variant, the
+        // whole group in the k-split variant, whose launches are tiny and latency-bound
+        // (the argmin variant runs at five waves per SIMD and has the registers for two gathers in flight: +5 % on smooth and on
+        //  rough depth, round 3; the six-wave inference variant at five waves with two in flight: -2 ... -3 %)
+        constexpr int GCFR_BODY_CHUNK = KSPLIT ? DEPTH : (WANT_ARGMIN && DEPTH >= 2 ? 2 : 1);  // (KSPLIT here: SPLIT == 1 only)
         if (run_body) {
           GCFR_COUNT(kCntBodies, 1);
 #ifdef GCFR_COUNTERS
