@@ -40,15 +40,42 @@ def _hipcc() -> str:
 HASH_PATH = os.path.join(LIB_DIR, "libgcfr_hip.srchash")
 
 
+def _code_only(text: str) -> str:
+    """C / C++ source without comments and without blank lines or trailing blanks: what the compiler sees.  The content hash is
+    taken over this, so that editing a comment neither forces a rebuild nor marks the committed profiles as stale."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":                      # string / character literal: copied verbatim
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            out.append(" ")
+            i = n if j < 0 else j + 2
+        else:
+            out.append(c)
+            i += 1
+    lines = [ln.rstrip() for ln in "".join(out).split("\n")]
+    return "\n".join(ln for ln in lines if ln.strip())
+
+
 def source_hash() -> str:
-    """sha256 over the flags, the list of march units and every file the library is compiled from (csrc/*, include/gcfr.h)."""
+    """sha256 over the flags, the list of march units and the CODE (comments stripped) of every file the library is compiled
+    from (csrc/*, include/gcfr.h)."""
     import hashlib
     h = hashlib.sha256((" ".join(FLAGS) + " " + repr(MARCH_UNITS)).encode())
     deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(PKG, "..", "include", "gcfr.h")]
     for d in deps:
         h.update(os.path.basename(d).encode())
-        with open(d, "rb") as f:
-            h.update(f.read())
+        with open(d, "r", encoding="utf-8") as f:
+            h.update(_code_only(f.read()).encode())
     return h.hexdigest()
 
 

@@ -112,3 +112,13 @@ def test_stale_library_abi_is_refused(monkeypatch):
     monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
     with pytest.raises(_lib.GcfrError, match="ABI revision"):
         _lib.load()
+
+
+def test_source_hash_ignores_comments_and_sees_code(tmp_path, monkeypatch):
+    """The library's content hash (stale-library check at load, `roofline.stale` in bench.py) is taken over the code, not the
+    comments: editing a comment must not mark the committed profiles stale, editing a token must."""
+    from geomconsistentfr_amd import build
+    code = 'int a; // one\n/* two */ int b = 1; const char *s = "// kept /* kept */";\n\n   int c;   \n#define Q \'"\'\n'
+    assert build._code_only(code) == 'int a;\n  int b = 1; const char *s = "// kept /* kept */";\n   int c;\n#define Q \'"\''
+    assert build._code_only(code.replace("one", "another remark").replace("two", "2")) == build._code_only(code)
+    assert build._code_only(code.replace("b = 1", "b = 2")) != build._code_only(code)
