@@ -652,6 +652,18 @@ def run_render(a, rk):
                          "(what an untrained network emits: the depth bounds never separate ray and surface), the three "
                          "checkpoint-derived FFHQ fixture faces tiled to the batch (--data ffhq), and the training step's "
                          "march -- batch 32, argmin variant, normals fused, depth of a freshly initialised RelightNet")
+    # the dominant kernel on a launch long enough that its tail does not matter (128 faces, one launch at a time): how busy
+    # the VALU issue ports are when the chip is full -- one launch of 8 faces ends with its heaviest tiles, most SIMDs idle
+    saturated_ms = None
+    if headline and world == 1 and not a.no_worst_case:
+        try:
+            r3 = RenderRig(rk, 128, streams=1)
+            for i in range(5):
+                r3.issue(i, 1)
+            saturated_ms = r3.kernel_launch_ms(ev, 20)
+            del r3
+        except Exception:
+            saturated_ms = None
     if rank != 0:
         return None
     algo_bytes = rsps * ALGO_BYTES_PER_RAY_STEP                              # per launch (one rank)
@@ -681,6 +693,18 @@ def run_render(a, rk):
         # the same mix against the overlapped rate: what the chip's VALU does when `streams` launches share it
         roof["frac_at_throughput"] = fwd["valu"]["issue_cycles_per_launch"] / (N_SIMD * NOMINAL_HZ * elapsed / a.steps)
         roof["frac_spec_at_throughput"] = spec_cycles / (N_SIMD * NOMINAL_HZ * elapsed / a.steps)
+        f128 = pm.get("kernels", {}).get("fwd_b128")
+        if saturated_ms and f128:
+            spec128 = sum(f128["valu"]["by_class"].get(k, 0.0) * c for k, c in SPEC_CYCLES.items())
+            roof["saturated"] = {
+                "faces_per_launch": 128, "avg_launch_ms": saturated_ms[0], "avg_launch_ms_min_max": list(saturated_ms[1:]),
+                "valu_insts_per_launch": f128["valu"]["insts_per_launch"],
+                "frac": f128["valu"]["issue_cycles_per_launch"] / (N_SIMD * NOMINAL_HZ * saturated_ms[0] * 1e-3),
+                "frac_spec": spec128 / (N_SIMD * NOMINAL_HZ * saturated_ms[0] * 1e-3),
+                "kernel_ray_steps_per_sec": 128 * 256 * 256 * 160 / (saturated_ms[0] * 1e-3),
+                "note": "the same kernel on ONE launch of 128 faces, un-overlapped (library events, 20 calls): long enough that "
+                        "the launch's tail -- a launch ends with its heaviest tiles, §4.1 -- does not matter; instruction mix from "
+                        "a PMC pass of exactly that launch (profiles/pmc_summary.json kernels.fwd_b128)"}
         # instruction counts / traffic come from the committed PMC passes (rocprofv3 cannot run inside the timed run):
         # they are only valid for the library they were collected on
         lib_hash, pmc_hash = library_srchash(), pm.get("library_srchash")

@@ -122,8 +122,11 @@ int gcfr_light_prep(const float *light_raw, int32_t n, int32_t clamp_z, float cl
  *               With a workspace the depth maps are first repacked into 2x2-neighbourhood texels
  *               (one 16-byte gather per ray-step instead of four 4-byte gathers) and a coarse grid of
  *               depth bounds lets the march skip sample groups that provably cannot lower a
- *               pixel's running minimum; results are bit-identical to the NULL-workspace path, only
- *               faster.  Contents are scratch.
+ *               pixel's running minimum; since round 3 the prepass also leaves, per image, running column / row
+ *               maxima of the depth an unmasked sample can read ("horizon tables", shapes with W % 4 == 0 and
+ *               H, W <= 1024), against which a ray that has passed its last candidate stops marching; results are
+ *               bit-identical to the NULL-workspace path, only faster.  Contents are scratch: rewritten by every
+ *               call, nothing in it needs initialising.
  * Supported: 2 <= H,W <= 4096, even; 1 <= N <= 4096.
  */
 size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W);

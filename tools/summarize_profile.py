@@ -16,7 +16,7 @@ clock at the nominal 2.4 GHz -- i.e. DVFS-inclusive).  issue_cycles_per_launch =
 SIMD time the kernel's instruction mix needs at those rates; against 1024 SIMDs * 2.4 GHz * launch duration it is the
 fraction of the chip's VALU issue capacity the kernel uses -- <= 1 by construction, and the honest "how close to a
 hardware limit" for a kernel whose gathers are cache-served.
-usage: tools/summarize_profile.py <tag>      (expects gpurun_out/prof_<tag>_fwd, optionally prof_<tag>_bwd,
+usage: tools/summarize_profile.py <tag>      (expects gpurun_out/prof_<tag>_fwd, optionally prof_<tag>_bwd, prof_<tag>_fwd128,
        profiles/<tag>_ubench_valu.txt, profiles/<tag>_work_counts.json)
 """
 import collections
@@ -113,7 +113,9 @@ def main(tag):
     except OSError:
         lib_hash = None
     summary = {"tag": tag, "library_srchash": lib_hash, "n_simd": N_SIMD, "nominal_hz": NOMINAL_HZ, "kernels": {}}
-    for leg, pick in (("fwd", "shadow_fwd_quad"), ("bwd", "render_bwd_single_light")):
+    # fwd128: the same march on a launch of 128 faces (tools/prof.sh <tag>_fwd128 fwd --faces 128) -- a launch long enough that its
+    # tail does not matter: the instruction count behind bench.py's `roofline.saturated`
+    for leg, pick in (("fwd", "shadow_fwd_quad"), ("bwd", "render_bwd_single_light"), ("fwd128", "shadow_fwd_quad")):
         src = os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, leg))
         if not os.path.isdir(src):
             continue
@@ -122,7 +124,9 @@ def main(tag):
         json.dump(means, open(os.path.join(dst, "%s_%s_pmc.json" % (tag, leg)), "w"), indent=1, sort_keys=True)
         for k, c in means.items():
             if pick in k and "SQ_INSTS_VALU" in c:
-                summary["kernels"][leg] = kernel_entry(k, c, cost)
+                summary["kernels"]["fwd_b128" if leg == "fwd128" else leg] = kernel_entry(k, c, cost)
+                if leg == "fwd128":
+                    summary["kernels"]["fwd_b128"]["faces_per_launch"] = 128
             if leg == "bwd" and "shadow_fwd_quad_argmin" in k and "SQ_INSTS_VALU" in c:
                 summary["kernels"]["fwd_training_march"] = kernel_entry(k, c, cost)
     wc = os.path.join(dst, tag + "_work_counts.json")
