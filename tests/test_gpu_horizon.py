@@ -99,3 +99,37 @@ def test_horizon_tables_match_their_definition(B, H, W):
             assert np.array_equal(got[k], want[k]), (b, name, np.flatnonzero(got[k] != want[k])[:8])
             assert (got[k] >= tight[k]).all(), (b, name)
     assert float(got[1][0]) == float(want[1].max())   # col_suf's first entry: the cap of the main loop's termination test
+
+
+@pytest.mark.parametrize("H,W", [(2, 4), (4, 8), (6, 12), (10, 20), (34, 36), (18, 260)])
+def test_tiny_and_odd_shapes_march_bit_identically_with_the_tables(H, W):
+    """Shapes whose row bands are empty or one row high, a width with a partial and a second 256-column segment: the grid
+    schedule (trailing loop + horizon tables, forced -- launches this small would pick the k-split) against the C oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import c_oracle
+    from geomconsistentfr_amd import _lib, RenderParams, light_prep, shadow_min_distance
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(H * 1000 + W)
+    B, N = 6, 40
+    r, c = np.mgrid[0:H, 0:W]
+    depth = (0.4 * H * np.exp(-(((c - 0.5 * W) / (0.3 * W)) ** 2 + ((r - 0.5 * H) / (0.3 * H)) ** 2)))[None].repeat(B, 0)
+    depth = (depth + rng.random((B, H, W)) * 0.5).astype(np.float32)
+    depth[1] = -depth[1]
+    depth[2, 0, :] += 50.0                                  # a wall along the top row (wrap partner of the bottom one)
+    mask = (rng.random((B, H, W)) < 0.7).astype(np.uint8)
+    mask[3] = 1
+    mask[4, :, : W // 2] = 0
+    lights = rng.standard_normal((B, 3)).astype(np.float32)
+    lights[5] = (0.0, 0.3, 0.9)
+    prm = RenderParams(n_samples=N, dt=0.8 / N)
+    _, pt = light_prep(torch.from_numpy(lights).to(dev), prm)
+    md, am = shadow_min_distance(torch.from_numpy(depth).to(dev), torch.from_numpy(mask).to(dev), pt.reshape(B, 1, 3), prm,
+                                 options=_lib.options(ksplit=0))
+    _, pt_o = c_oracle.light_prep(lights, clamp_z_min=0.0)
+    md_o, am_o = c_oracle.shadow_min_distance(depth, mask, pt_o[:, None, :], c_oracle.sample_table(0.025, 0.8 / N, N))
+    md, am = md.cpu().numpy(), am.cpu().numpy()
+    assert np.array_equal(md, md_o)
+    lit = md_o < 1e5
+    assert np.array_equal(am[lit], am_o[lit])
