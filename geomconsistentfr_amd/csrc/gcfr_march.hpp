@@ -646,7 +646,6 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         dxl = (float)dx_l;
         dyl = (float)dy_l;
     };
-    const float Qz = nrm * zb;
     const float t_abs = __builtin_bit_cast(float, tfl[kTfTabs]);  // max(|tt[0]|, |tt[N-1]|)
     // Give-up test (a heuristic about WORK, never about results: without the bounds every group is marched).  A group
     // can only be skipped while the ray's height over the pixel, c1 t / n, exceeds what the surface band leaves open,

@@ -160,16 +160,10 @@ __global__ __launch_bounds__(256) void shadow_fwd_kernel(ShadowArgs a)
     }
 }
 
-__device__ inline void build_zbounds_block(int block, int b, const float *__restrict__ depth,
-                                           float4 *__restrict__ zb, int H, int W, int N,
-                                           const double *__restrict__ t_table, int group)
+__device__ inline void build_zbounds_tile(int tile, int ls, int b, const float *__restrict__ depth,
+                                          float4 *__restrict__ zb, int H, int W)
 {
-    const int ls = zb_log2_stride(H, W, N, t_table, group);
     const int ntw = (W >> ls) + 1, nth = (H >> ls) + 1;
-    const int tile = block * 4 + (int)(threadIdx.x >> 6);
-    if (block == 0 && threadIdx.x == 0)
-        zb[(size_t)b * zb_slot(H, W) + zb_max_tiles(H, W) - 1] =
-            make_float4(0.0f, 0.0f, -__builtin_inff(), __builtin_inff());
     if (tile >= nth * ntw)
         return;
     const int lane = threadIdx.x & 63;
@@ -257,6 +251,25 @@ __device__ inline void build_zbounds_block(int block, int b, const float *__rest
     const float whi = -f32_unsortable(wave_min_i32(f32_sortable(-hi)));
     if (lane == 0)
         zb[(size_t)b * zb_slot(H, W) + tile] = make_float4(pa, pb, wlo, whi);
+}
+
+// kZbTilesPerWave tiles per wave, one after the other: a block per four tiles was 273 blocks per 256 x 256 image, half of the
+// prepass' workgroups -- and the prepass runs at the pace they are dispatched (see the repack job)
+#ifndef GCFR_ZB_TILES_PER_WAVE
+#define GCFR_ZB_TILES_PER_WAVE 2
+#endif
+constexpr int kZbTilesPerWave = GCFR_ZB_TILES_PER_WAVE;
+__device__ inline void build_zbounds_block(int block, int b, const float *__restrict__ depth,
+                                           float4 *__restrict__ zb, int H, int W, int N,
+                                           const double *__restrict__ t_table, int group)
+{
+    const int ls = zb_log2_stride(H, W, N, t_table, group);
+    if (block == 0 && threadIdx.x == 0)
+        zb[(size_t)b * zb_slot(H, W) + zb_max_tiles(H, W) - 1] =
+            make_float4(0.0f, 0.0f, -__builtin_inff(), __builtin_inff());
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int t = 0; t < kZbTilesPerWave; ++t)
+        build_zbounds_tile((block * kZbTilesPerWave + t) * 4 + wave, ls, b, depth, zb, H, W);
 }
 
 __device__ inline void stat_mask_dword(uint32_t d, int r, int c, int &rmin, int &cmin, int &nrmax, int &ncmax, int &all_set)
@@ -402,29 +415,32 @@ __device__ inline void build_bitmap_block(int block, int b, const uint8_t *__res
 // pairs with the first) are in every entry: prefix tables include the last column / row, suffix tables the first.  0 is
 // included because integral sample positions read z = 0 (see the depth-bound skip).  NaN cells are dropped (a NaN sample never
 // wins), +inf stays +inf (never terminates).
-// Parallel without a combining pass: the image's rows are split into kHorizonBands bands and a block (one per band and kind
-// -- column tables / row tables) computes the tables OF ITS BAND ALONE (the column maxima over its rows; its own rows'
-// maxima, zero elsewhere).  Maximum commutes with the running maxima, so the table proper is the element-wise maximum of the
+// Parallel without a combining pass: the image's rows are split into kHorizonBands bands and a block per band computes the
+// four tables OF ITS BAND ALONE (the column maxima over its rows; its own rows' maxima, zero elsewhere).  Maximum commutes with the running maxima, so the table proper is the element-wise maximum of the
 // bands' tables -- which the march takes at look-up time: entry i is ONE float4 holding the four bands' values (one 16-byte
-// gather).  Each block reads a quarter of the depth and mask planes (float4 / dword per lane and row, all loads of a round in
+// gather).  Each block reads its quarter of the depth and mask planes once (float4 / dword per lane and row, all loads of a round in
 // flight: GCFR_HORIZON_RB), reduces into LDS and scans there.  Needs W % 4 == 0, 16-byte aligned planes and H, W <= kHorizonDim.
-__device__ inline void build_horizon_block(int job, int b, const float *__restrict__ depth, const uint8_t *__restrict__ mask,
+__device__ inline void build_horizon_block(int k, int b, const float *__restrict__ depth, const uint8_t *__restrict__ mask,
                                            int mask_batch, int H, int W, float4 *__restrict__ zb)
 {
-    __shared__ int s_val[kHorizonDim];  // colmax over the band's rows / rowmax of the band's rows, as int bits (>= 0: integer order == float order)
-    __shared__ int s_pre[kHorizonDim], s_suf[kHorizonDim];
-    const int kind = job / kHorizonBands, k = job - kind * kHorizonBands;  // kind 0: column tables, 1: row tables; k: the band
+    // column maxima over the band's rows / row maxima of the band's rows, as int bits (>= 0: integer order == float order),
+    // and their running maxima from either end
+    constexpr int kBandRows = kHorizonDim / kHorizonBands;
+    __shared__ int s_col[kHorizonDim], s_cpre[kHorizonDim], s_csuf[kHorizonDim];
+    __shared__ int s_row[kBandRows], s_rpre[kBandRows], s_rsuf[kBandRows];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bandrows = (H + kHorizonBands - 1) / kHorizonBands, b_lo = min(H, k * bandrows), b_hi = min(H, b_lo + bandrows);
-    const int n = kind == 0 ? W : (b_hi - b_lo);  // entries this block reduces into: its columns / its rows
+    const int nr = b_hi - b_lo;  // this band's rows (<= kBandRows)
     for (int i = tid; i < kHorizonDim; i += 256)
-        s_val[i] = 0;
+        s_col[i] = 0;
+    if (tid < kBandRows)
+        s_row[tid] = 0;
     __syncthreads();
     const size_t P = (size_t)H * W;
     const float *z = depth + (size_t)b * P;
     const uint8_t *m = mask + (size_t)(mask_batch == 1 ? 0 : b) * P;
-    const int wrows = (b_hi - b_lo + 3) >> 2, r_lo = min(b_hi, b_lo + wave * wrows), r_hi = min(b_hi, r_lo + wrows);  // this wave's rows
-    const int segs = (W + 255) >> 8;                                                                                  // 256 columns (64 lanes x 4) per segment
+    const int wrows = (nr + 3) >> 2, r_lo = min(b_hi, b_lo + wave * wrows), r_hi = min(b_hi, r_lo + wrows);  // this wave's rows
+    const int segs = (W + 255) >> 8;                                                                        // 256 columns (64 lanes x 4) per segment
 #ifndef GCFR_HORIZON_RB
 #define GCFR_HORIZON_RB 8
 #endif
@@ -438,7 +454,7 @@ __device__ inline void build_horizon_block(int job, int b, const float *__restri
         const int cc = in_w ? c : 0;  // (loads stay inside the plane; their values are dropped)
         // dilation across the segment's edges is not looked up: with more than one segment the edge lanes are always live
         const unsigned long long edge = segs > 1 ? 0x8000000000000001ull : 0ull;
-        float4 cm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // column job: running maxima of this lane's four columns
+        float4 cm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // running maxima of this lane's four columns
         for (int r0 = r_lo; r0 < r_hi; r0 += RB) {
             uint32_t md[RB + 2];
             float4 dv[RB];
@@ -464,33 +480,36 @@ __device__ inline void build_horizon_block(int job, int b, const float *__restri
                 float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (in_w && r < r_hi && ((live >> lane) & 1ull))  // (fmaxf drops NaN)
                     v = make_float4(fmaxf(dv[j].x, 0.0f), fmaxf(dv[j].y, 0.0f), fmaxf(dv[j].z, 0.0f), fmaxf(dv[j].w, 0.0f));
-                if (kind == 0) {
-                    cm = make_float4(fmaxf(cm.x, v.x), fmaxf(cm.y, v.y), fmaxf(cm.z, v.z), fmaxf(cm.w, v.w));
-                } else if (r < r_hi) {  // (wave-uniform)
+                cm = make_float4(fmaxf(cm.x, v.x), fmaxf(cm.y, v.y), fmaxf(cm.z, v.z), fmaxf(cm.w, v.w));
+                if (r < r_hi) {  // (wave-uniform)
                     const float rm = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
                     const int wmax = -wave_min_i32(-__builtin_bit_cast(int, rm));  // (bits of a float >= 0)
-                    if (lane == 0)
-                        atomicMax(&s_val[r - b_lo], wmax);  // (one writer per row and segment; max across the segments)
+                    if (lane == 0 && wmax != 0)
+                        atomicMax(&s_row[r - b_lo], wmax);  // (one writer per row and segment; max across the segments)
                 }
             }
         }
-        if (kind == 0 && in_w) {
-            atomicMax(&s_val[c + 0], __builtin_bit_cast(int, cm.x));
-            atomicMax(&s_val[c + 1], __builtin_bit_cast(int, cm.y));
-            atomicMax(&s_val[c + 2], __builtin_bit_cast(int, cm.z));
-            atomicMax(&s_val[c + 3], __builtin_bit_cast(int, cm.w));
+        if (in_w) {
+            atomicMax(&s_col[c + 0], __builtin_bit_cast(int, cm.x));
+            atomicMax(&s_col[c + 1], __builtin_bit_cast(int, cm.y));
+            atomicMax(&s_col[c + 2], __builtin_bit_cast(int, cm.z));
+            atomicMax(&s_col[c + 3], __builtin_bit_cast(int, cm.w));
         }
     }
     __syncthreads();
-    // running maxima over the n entries from either end: wave 0 the prefix, wave 1 the suffix; a lane owns E consecutive entries
-    if (wave < 2) {
+    // running maxima from either end, one wave per scan: columns prefix / suffix, rows prefix / suffix; a lane owns E consecutive entries
+    {
+        const bool rows = wave >= 2, rev = (wave & 1) != 0;
+        const int n = rows ? nr : W;
+        const int *src = rows ? s_row : s_col;
+        int *dst = rows ? (rev ? s_rsuf : s_rpre) : (rev ? s_csuf : s_cpre);
         const int E = (n + 63) >> 6, i0 = lane * E;
         int run = 0;
         for (int e = 0; e < E; ++e) {
             const int i = i0 + e;  // position along the scan's direction
             if (i < n) {
-                run = max(run, s_val[wave == 0 ? i : n - 1 - i]);
-                (wave == 0 ? s_pre : s_suf)[wave == 0 ? i : n - 1 - i] = run;
+                run = max(run, src[rev ? n - 1 - i : i]);
+                dst[rev ? n - 1 - i : i] = run;
             }
         }
         int incl = run;  // inclusive scan of the lanes' totals, then the exclusive one
@@ -505,28 +524,36 @@ __device__ inline void build_horizon_block(int job, int b, const float *__restri
         for (int e = 0; e < E; ++e) {
             const int i = i0 + e;
             if (i < n) {
-                int *p = &(wave == 0 ? s_pre : s_suf)[wave == 0 ? i : n - 1 - i];
+                int *p = &dst[rev ? n - 1 - i : i];
                 *p = max(*p, excl);
             }
         }
     }
     __syncthreads();
     // centred tables: entry kHorizonDim/2 + (j - N/2) belongs to column / row j of the N the image has; entries outside repeat
-    // the nearest one.  Component k of the entry's float4 is this band's value.
+    // the nearest one.  Component k of the entry's float4 is this band's value.  The wrap partners: every prefix entry includes
+    // the image's last column / row, every suffix entry its first (of THIS band's values).
     constexpr int S = kHorizonDim;
-    float *out = (float *)(zb + (size_t)b * zb_slot(H, W) + zb_stride(H, W)) + (size_t)(kind == 0 ? 0 : 2 * S) * 4 + k;
-    const int N = kind == 0 ? W : H;
-    // the wrap partners: every prefix entry includes the image's last column / row, every suffix entry its first (of THIS band's values)
-    const int j_first = kind == 0 ? 0 : 0 - b_lo, j_last = kind == 0 ? W - 1 : H - 1 - b_lo;  // their positions among this block's n entries
-    const int add_pre = (n > 0 && j_last >= 0 && j_last < n) ? s_val[j_last] : 0;
-    const int add_suf = (n > 0 && j_first >= 0 && j_first < n) ? s_val[j_first] : 0;
-    const int total = n > 0 ? s_pre[n - 1] : 0;
-    for (int i = tid; i < S; i += 256) {
-        const int j = min(max(i - S / 2 + N / 2, 0), N - 1) - (kind == 0 ? 0 : b_lo);  // position among this block's entries (rows: may lie outside the band)
-        const int pre = n <= 0 ? 0 : (j < 0 ? 0 : (j >= n ? total : s_pre[j]));
-        const int suf = n <= 0 ? 0 : (j < 0 ? total : (j >= n ? 0 : s_suf[j]));
-        out[(size_t)i * 4] = __builtin_bit_cast(float, max(pre, add_pre));
-        out[(size_t)(S + i) * 4] = __builtin_bit_cast(float, max(suf, add_suf));
+    float *out = (float *)(zb + (size_t)b * zb_slot(H, W) + zb_stride(H, W)) + k;
+    {   // columns: this band's column maxima over all W columns
+        const int add_pre = s_col[W - 1], add_suf = s_col[0];
+        for (int i = tid; i < S; i += 256) {
+            const int j = min(max(i - S / 2 + W / 2, 0), W - 1);
+            out[(size_t)i * 4] = __builtin_bit_cast(float, max(s_cpre[j], add_pre));
+            out[(size_t)(S + i) * 4] = __builtin_bit_cast(float, max(s_csuf[j], add_suf));
+        }
+    }
+    {   // rows: this band's own rows' maxima, zero elsewhere
+        const int total = nr > 0 ? s_rpre[nr - 1] : 0;
+        const int add_pre = (nr > 0 && b_hi == H) ? s_row[nr - 1] : 0;  // the band that holds the image's last row
+        const int add_suf = (nr > 0 && b_lo == 0) ? s_row[0] : 0;       // ... its first row
+        for (int i = tid; i < S; i += 256) {
+            const int j = min(max(i - S / 2 + H / 2, 0), H - 1) - b_lo;  // position among this band's rows (may lie outside)
+            const int pre = nr <= 0 ? 0 : (j < 0 ? 0 : (j >= nr ? total : s_rpre[j]));
+            const int suf = nr <= 0 ? 0 : (j < 0 ? total : (j >= nr ? 0 : s_rsuf[j]));
+            out[(size_t)(2 * S + i) * 4] = __builtin_bit_cast(float, max(pre, add_pre));
+            out[(size_t)(3 * S + i) * 4] = __builtin_bit_cast(float, max(suf, add_suf));
+        }
     }
 }
 
@@ -544,7 +571,7 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
 {
     const int Wp = W + 1, Hp = H + 1;
     const int b = blockIdx.y;
-    if ((int)blockIdx.x < hz_blocks) {  // (head of the grid: the longest job of the prepass; one block per image, kind and band)
+    if ((int)blockIdx.x < hz_blocks) {  // (head of the grid: the longest job of the prepass; one block per image and row band)
         build_horizon_block((int)blockIdx.x, b, depth, mask, mask_batch, H, W, zb);
         return;
     }
@@ -564,7 +591,10 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
         return;
     }
     const int qb = bx - zb_blocks - stat_blocks - bitmap_blocks;
-    const int i = qb * blockDim.x + threadIdx.x;
+#ifndef GCFR_QUAD_PER_THREAD
+#define GCFR_QUAD_PER_THREAD 4
+#endif
+    constexpr int QP = GCFR_QUAD_PER_THREAD;  // texels per thread of the repack job
     if (qb == 0 && b == 0 && threadIdx.x < 64) {
         // Is the sample table what the march's pruning / skipping reasons about -- increasing, inside [0, 1]
         // (every sample between the pixel and its end point) and uniform to 0.1 %?  One wave checks, once per launch.
@@ -598,17 +628,25 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
             light_prep_one(pl.light_raw, b * pl.L + l, pl.clamp_z, pl.clamp_min, pl.light_distance,
                            pl.unit_out, pl.light_pt_out);
     }
-    if (i >= Hp * Wp)
-        return;
-    const int rp = i / Wp, cp = i - rp * Wp;
-    const int r = rp - 1, c = cp - 1;
-    const int r0 = r < 0 ? H - 1 : r, c0 = c < 0 ? W - 1 : c;
-    const int r1 = (r + 1 >= H) ? 0 : r + 1, c1 = (c + 1 >= W) ? 0 : c + 1;
+    // QP texels per thread, 256 apart (coalesced), all their loads in flight before the first store: a block per 256 texels was
+    // 258 blocks per 256 x 256 image -- at B = 128 a third of a million workgroups, and the prepass ran at the dispatcher's pace
     const float *z = depth + (size_t)b * H * W;
-    const float zUL = z[(size_t)r0 * W + c0], zUR = z[(size_t)r0 * W + c1];
-    const float zLL = z[(size_t)r1 * W + c0], zLR = z[(size_t)r1 * W + c1];
-    const size_t o = (size_t)b * Hp * Wp + i;
-    quad[o] = make_float4(zUL, zUR, zLL, zLR);
+    float4 q[QP];
+#pragma unroll
+    for (int j = 0; j < QP; ++j) {
+        const int i = min((qb * QP + j) * 256 + (int)threadIdx.x, Hp * Wp - 1);
+        const int rp = i / Wp, cp = i - rp * Wp;
+        const int r = rp - 1, c = cp - 1;
+        const int r0 = r < 0 ? H - 1 : r, c0 = c < 0 ? W - 1 : c;
+        const int r1 = (r + 1 >= H) ? 0 : r + 1, c1 = (c + 1 >= W) ? 0 : c + 1;
+        q[j] = make_float4(z[(size_t)r0 * W + c0], z[(size_t)r0 * W + c1], z[(size_t)r1 * W + c0], z[(size_t)r1 * W + c1]);
+    }
+#pragma unroll
+    for (int j = 0; j < QP; ++j) {
+        const int i = (qb * QP + j) * 256 + (int)threadIdx.x;
+        if (i < Hp * Wp)
+            quad[(size_t)b * Hp * Wp + i] = q[j];
+    }
 }
 }  // namespace gcfr
 
@@ -831,14 +869,14 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
 #endif
         const bool lds_stage = !ksplit && lds_fits && (kn.lds_stage < 0 ? (GCFR_LDS_STAGE_AUTO != 0) : (kn.lds_stage == 1));
         const Schedule sch = ksplit ? kKSplit : (lds_stage ? kGridLds : kGrid);
-        const int quad_blocks = (texels + 255) / 256;
-        const int zb_blocks = use_zb ? (zb_max_tiles(H, W) + 3) / 4 : 0;  // sized for the finest stride
+        const int quad_blocks = (texels + 256 * GCFR_QUAD_PER_THREAD - 1) / (256 * GCFR_QUAD_PER_THREAD);
+        const int zb_blocks = use_zb ? (zb_max_tiles(H, W) + 4 * kZbTilesPerWave - 1) / (4 * kZbTilesPerWave) : 0;  // sized for the finest stride
         const int bitmap_blocks = lds_stage ? ((H * W) / 32 + 255) / 256 : 0;
         // horizon tables: for the trailing loop of the grid schedule's bounds-skipping march (not the k-split's quarter
         // ranges, not the LDS-staged variant), where the shape and the planes' alignment allow vector loads
         const bool horizon = (GCFR_HORIZON != 0) && use_zb && sch == kGrid && hz_shape_ok(H, W) && (((uintptr_t)depth & 15u) == 0) &&
                              (((uintptr_t)mask_u8 & 3u) == 0);
-        const int hz_blocks = horizon ? 2 * kHorizonBands : 0;
+        const int hz_blocks = horizon ? kHorizonBands : 0;
         const int vec_ok = ((W & 15) == 0) && (((uintptr_t)depth & 15u) == 0) && (((uintptr_t)mask_u8 & 15u) == 0);
         hipLaunchKernelGGL(build_quad_kernel, dim3(hz_blocks + zb_blocks + (int)n_stat + bitmap_blocks + quad_blocks, B), dim3(256), 0, st,
                            depth, (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox, zrange, mones, zb, zb_blocks,
