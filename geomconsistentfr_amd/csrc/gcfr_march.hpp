@@ -278,6 +278,7 @@ struct ShadowQuadArgs {
     const float *depth;     // (B,H,W)      own-pixel depth
     const float4 *quad;     // (B,H+1,W+1)  prepass output
     const int *bbox;        // (MB,n_stat,4) prepass output: partial mask bounding boxes {r_min, c_min, -r_max, -c_max}
+    const int *diag;        // (MB,n_stat,4) prepass output: partial diagonal extents {min(c+r), -max(c+r), min(c-r), -max(c-r)}
     const float4 *zb;       // (B,zb_slot) prepass output: depth bounds grid {a, b, c_lo, c_hi}, or null (skip off)
     const int *zrange;      // (B,n_stat,2) prepass output: partial depth ranges {z_min, -z_max} (sortable ints)
     const int *mones;       // (MB,n_stat)  prepass output: 1 iff every mask cell of the chunk is non-zero
@@ -336,6 +337,7 @@ enum { kCntTiles, kCntGroupsNominal, kCntGroupsVisited, kCntBoundTests, kCntBodi
 // Per-image statistics, wave-uniform: the reduction of the prepass' partial records (build_stats_block).
 struct ImageStats {
     int r_min, c_min, r_max, c_max;  // bounding box of the mask's non-zero cells (r_min == kBBoxInit: none)
+    int s_min, s_max, d_min, d_max;  // ... and their diagonal extents: c + r and c - r (the bounding octagon)
     int gz_lo_s, gz_nhi_s;           // depth range {z_min, -z_max} as sortable ints
     int mask_all_ones;               // 1 iff the image's mask has no zero cell at all
 };
@@ -350,6 +352,8 @@ __device__ inline ImageStats reduce_image_stats(ArgPtr a, int b, int lane, bool 
         const ConstI32Ptr sb = (ConstI32Ptr)(unsigned long long)a->bbox + 4 * (size_t)(a->mask_batch == 1 ? 0 : b) * n;
         const ConstI32Ptr sz = (ConstI32Ptr)(unsigned long long)a->zrange + 2 * (size_t)b * n;
         const ConstI32Ptr so = (ConstI32Ptr)(unsigned long long)a->mones + (size_t)(a->mask_batch == 1 ? 0 : b) * n;
+        const ConstI32Ptr sd = (ConstI32Ptr)(unsigned long long)a->diag + 4 * (size_t)(a->mask_batch == 1 ? 0 : b) * n;
+        int d0 = kBBoxInit, d1 = kBBoxInit, d2 = kBBoxInit, d3 = kBBoxInit;
         int m0 = kBBoxInit, m1 = kBBoxInit, m2 = kBBoxInit, m3 = kBBoxInit, z0 = 0x7fffffff, z1 = 0x7fffffff, ones = 1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -359,6 +363,10 @@ __device__ inline ImageStats reduce_image_stats(ArgPtr a, int b, int lane, bool 
                 m2 = min(m2, sb[4 * j + 2]);
                 m3 = min(m3, sb[4 * j + 3]);
                 ones = min(ones, so[j]);
+                d0 = min(d0, sd[4 * j + 0]);
+                d1 = min(d1, sd[4 * j + 1]);
+                d2 = min(d2, sd[4 * j + 2]);
+                d3 = min(d3, sd[4 * j + 3]);
                 if (want_z) {
                     z0 = min(z0, sz[2 * j + 0]);
                     z1 = min(z1, sz[2 * j + 1]);
@@ -373,12 +381,17 @@ __device__ inline ImageStats reduce_image_stats(ArgPtr a, int b, int lane, bool 
         st.gz_lo_s = z0;
         st.gz_nhi_s = z1;
         st.mask_all_ones = ones;
+        st.s_min = d0;
+        st.s_max = -d1;
+        st.d_min = d2;
+        st.d_max = -d3;
         return st;
     }
     const int4 *pb = (const int4 *)a->bbox + (size_t)(a->mask_batch == 1 ? 0 : b) * n;
     const int2 *pz = (const int2 *)a->zrange + (size_t)b * n;
     const int *po = a->mones + (size_t)(a->mask_batch == 1 ? 0 : b) * n;
-    int4 m = make_int4(kBBoxInit, kBBoxInit, kBBoxInit, kBBoxInit);
+    const int4 *pd = (const int4 *)a->diag + (size_t)(a->mask_batch == 1 ? 0 : b) * n;
+    int4 m = make_int4(kBBoxInit, kBBoxInit, kBBoxInit, kBBoxInit), dg = m;
     int2 mz = make_int2(0x7fffffff, 0x7fffffff);
     int ones = 1;
     for (int j = lane; j < n; j += 64) {
@@ -388,6 +401,11 @@ __device__ inline ImageStats reduce_image_stats(ArgPtr a, int b, int lane, bool 
         m.y = min(m.y, v.y);
         m.z = min(m.z, v.z);
         m.w = min(m.w, v.w);
+        const int4 w = pd[j];
+        dg.x = min(dg.x, w.x);
+        dg.y = min(dg.y, w.y);
+        dg.z = min(dg.z, w.z);
+        dg.w = min(dg.w, w.w);
         if (want_z) {
             const int2 vz = pz[j];
             mz.x = min(mz.x, vz.x);
@@ -402,6 +420,10 @@ __device__ inline ImageStats reduce_image_stats(ArgPtr a, int b, int lane, bool 
     st.gz_lo_s = want_z ? wave_min_i32(mz.x) : 0x7fffffff;
     st.gz_nhi_s = want_z ? wave_min_i32(mz.y) : 0x7fffffff;
     st.mask_all_ones = wave_min_i32(ones);
+    st.s_min = wave_min_i32(dg.x);
+    st.s_max = -wave_min_i32(dg.y);
+    st.d_min = wave_min_i32(dg.z);
+    st.d_max = -wave_min_i32(dg.w);
     return st;
 }
 
@@ -582,6 +604,31 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
                 tb = fminf(tb, fmaxf(t1, t2));
             } else {
                 empty = empty || (y < Y0) || (y > Y1);
+            }
+            // ... and inside the mask's bounding OCTAGON (round 3): the cell's column + row and column - row lie within the
+            // extents the prepass found, i.e. (s_x + W/2) +- (H/2 - s_y) does to within 1 (two roundings of 0.5) + 0.02.  For
+            // an elliptical mask the octagon cuts four fifths of the box's corners: -18 % visited groups (tools/sim_octagon.py).
+            if (st.mask_all_ones == 0) {  // (wave-uniform; an all-ones mask's octagon is its box)
+                const float hs = 0.5f * (float)(W + H), hd = 0.5f * (float)(W - H);
+                const float U0 = (float)st.s_min - hs - 1.02f, U1 = (float)st.s_max - hs + 1.02f;
+                const float V0 = (float)st.d_min - hd - 1.02f, V1 = (float)st.d_max - hd + 1.02f;
+                const float u = x - y, du = dxf - dyf, v = x + y, dv = dxf + dyf;
+                if (du != 0.0f) {
+                    const float inv = __builtin_amdgcn_rcpf(du);
+                    const float t1 = (U0 - u) * inv, t2 = (U1 - u) * inv;
+                    ta = fmaxf(ta, fminf(t1, t2));
+                    tb = fminf(tb, fmaxf(t1, t2));
+                } else {
+                    empty = empty || (u < U0) || (u > U1);
+                }
+                if (dv != 0.0f) {
+                    const float inv = __builtin_amdgcn_rcpf(dv);
+                    const float t1 = (V0 - v) * inv, t2 = (V1 - v) * inv;
+                    ta = fmaxf(ta, fminf(t1, t2));
+                    tb = fminf(tb, fmaxf(t1, t2));
+                } else {
+                    empty = empty || (v < V0) || (v > V1);
+                }
             }
             if (!empty && ta <= tb) {
                 const float t_first = __builtin_bit_cast(float, tfl[kTfTfirst]);  // (float)tt[0]

@@ -272,7 +272,10 @@ __device__ inline void build_zbounds_block(int block, int b, const float *__rest
         build_zbounds_tile((block * kZbTilesPerWave + t) * 4 + wave, ls, b, depth, zb, H, W);
 }
 
-__device__ inline void stat_mask_dword(uint32_t d, int r, int c, int &rmin, int &cmin, int &nrmax, int &ncmax, int &all_set)
+// diag[4]: {min (c + r), -max (c + r), min (c - r), -max (c - r)} over the non-zero cells: the mask's diagonal extents (the
+// bounding OCTAGON together with the box; round 3)
+__device__ inline void stat_mask_dword(uint32_t d, int r, int c, int &rmin, int &cmin, int &nrmax, int &ncmax, int &all_set,
+                                       int (&diag)[4])
 {
     const uint32_t nz = (d | ((d & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;  // bit 7 of every non-zero byte
     all_set &= (nz == 0x80808080u) ? 1 : 0;
@@ -282,19 +285,24 @@ __device__ inline void stat_mask_dword(uint32_t d, int r, int c, int &rmin, int 
         nrmax = min(nrmax, -r);
         cmin = min(cmin, c + first);
         ncmax = min(ncmax, -(c + last));
+        diag[0] = min(diag[0], c + first + r);
+        diag[1] = min(diag[1], -(c + last + r));
+        diag[2] = min(diag[2], c + first - r);
+        diag[3] = min(diag[3], -(c + last - r));
     }
 }
 
 __device__ inline void build_stats_block(int chunk, int b, const float *__restrict__ depth,
                                          const uint8_t *__restrict__ mask, int mask_batch, int H, int W,
                                          int *__restrict__ bbox, int *__restrict__ zrange, int *__restrict__ mones,
-                                         bool want_z, bool vec_ok)
+                                         int *__restrict__ diag_out, bool want_z, bool vec_ok)
 {
     const int P = H * W;
     const int p0 = chunk * kStatChunk;
     const bool want_box = b < mask_batch;
     int rmin = kBBoxInit, cmin = kBBoxInit, nrmax = kBBoxInit, ncmax = kBBoxInit;
     int all_set = 1;  // every mask cell this lane saw is non-zero
+    int diag[4] = {kBBoxInit, kBBoxInit, kBBoxInit, kBBoxInit};
     float zlo = __builtin_inff(), zhi = -__builtin_inff();  // fminf / fmaxf drop NaN cells (a NaN sample never wins)
     const float *z = depth + (size_t)b * P;
     const uint8_t *m = mask + (size_t)b * P;  // only dereferenced when want_box
@@ -315,10 +323,10 @@ __device__ inline void build_stats_block(int chunk, int b, const float *__restri
                 if (want_box) {
                     const uint4 mv = *(const uint4 *)(m + i);
                     const int r = i / W, c = i - r * W;
-                    stat_mask_dword(mv.x, r, c, rmin, cmin, nrmax, ncmax, all_set);
-                    stat_mask_dword(mv.y, r, c + 4, rmin, cmin, nrmax, ncmax, all_set);
-                    stat_mask_dword(mv.z, r, c + 8, rmin, cmin, nrmax, ncmax, all_set);
-                    stat_mask_dword(mv.w, r, c + 12, rmin, cmin, nrmax, ncmax, all_set);
+                    stat_mask_dword(mv.x, r, c, rmin, cmin, nrmax, ncmax, all_set, diag);
+                    stat_mask_dword(mv.y, r, c + 4, rmin, cmin, nrmax, ncmax, all_set, diag);
+                    stat_mask_dword(mv.z, r, c + 8, rmin, cmin, nrmax, ncmax, all_set, diag);
+                    stat_mask_dword(mv.w, r, c + 12, rmin, cmin, nrmax, ncmax, all_set, diag);
                 }
             }
         }
@@ -339,17 +347,22 @@ __device__ inline void build_stats_block(int chunk, int b, const float *__restri
                     cmin = min(cmin, c);
                     nrmax = min(nrmax, -r);
                     ncmax = min(ncmax, -c);
+                    diag[0] = min(diag[0], c + r);
+                    diag[1] = min(diag[1], -(c + r));
+                    diag[2] = min(diag[2], c - r);
+                    diag[3] = min(diag[3], -(c - r));
                 } else {
                     all_set = 0;
                 }
             }
         }
     }
-    __shared__ int part[4][7];
+    __shared__ int part[4][11];
     const int wv = threadIdx.x >> 6;
     const int v0 = wave_min_i32(rmin), v1 = wave_min_i32(cmin), v2 = wave_min_i32(nrmax), v3 = wave_min_i32(ncmax);
     const int v4 = wave_min_i32(f32_sortable(zlo)), v5 = wave_min_i32(f32_sortable(-zhi));
     const int v6 = __builtin_amdgcn_ballot_w64(all_set == 0) == 0ull ? 1 : 0;
+    const int v7 = wave_min_i32(diag[0]), v8 = wave_min_i32(diag[1]), v9 = wave_min_i32(diag[2]), v10 = wave_min_i32(diag[3]);
     if ((threadIdx.x & 63) == 0) {
         part[wv][0] = v0;
         part[wv][1] = v1;
@@ -358,9 +371,13 @@ __device__ inline void build_stats_block(int chunk, int b, const float *__restri
         part[wv][4] = v4;
         part[wv][5] = v5;
         part[wv][6] = v6;
+        part[wv][7] = v7;
+        part[wv][8] = v8;
+        part[wv][9] = v9;
+        part[wv][10] = v10;
     }
     __syncthreads();
-    if (threadIdx.x < 7) {
+    if (threadIdx.x < 11) {
         const int q = threadIdx.x;
         const int v = min(min(part[0][q], part[1][q]), min(part[2][q], part[3][q]));
         const size_t rec = (size_t)b * n_stat_chunks(H, W) + chunk;
@@ -370,8 +387,11 @@ __device__ inline void build_stats_block(int chunk, int b, const float *__restri
         } else if (q < 6) {
             if (want_z)
                 zrange[rec * 2 + (q - 4)] = v;
+        } else if (q == 6) {
+            if (want_box)
+                mones[rec] = v;  // 1 iff every mask cell of the chunk is non-zero
         } else if (want_box) {
-            mones[rec] = v;  // 1 iff every mask cell of the chunk is non-zero
+            diag_out[rec * 4 + (q - 7)] = v;
         }
     }
 }
@@ -567,7 +587,7 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
                                                          int want_z, int vec_ok, int N,
                                                          const double *__restrict__ t_table, int group,
                                                          int *__restrict__ tflag, uint32_t *__restrict__ bitmap,
-                                                         int bitmap_blocks, int hz_blocks)
+                                                         int bitmap_blocks, int hz_blocks, int *__restrict__ diag)
 {
     const int Wp = W + 1, Hp = H + 1;
     const int b = blockIdx.y;
@@ -581,7 +601,7 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
         return;
     }
     if (bx < zb_blocks + stat_blocks) {
-        build_stats_block(bx - zb_blocks, b, depth, mask, mask_batch, H, W, bbox, zrange, mones,
+        build_stats_block(bx - zb_blocks, b, depth, mask, mask_batch, H, W, bbox, zrange, mones, diag,
                           want_z != 0, vec_ok != 0);
         return;
     }
@@ -741,7 +761,7 @@ extern "C" void gcfr_options_default(gcfr_options *opt)
     opt->ksplit = opt->depth_bound_skip = opt->schedule = opt->tile_order = opt->lds_stage = -1;
 }
 
-// workspace layout: [quad texels | partial boxes | per image: depth-bounds records, horizon tables | partial depth ranges | tflag | all-ones flags | mask bitmaps]
+// workspace layout: [quad texels | partial boxes | per image: depth-bounds records, horizon tables | partial depth ranges | tflag | all-ones flags | mask bitmaps | partial diagonal extents]
 extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
 {
     if (B <= 0 || H <= 0 || W <= 0)
@@ -750,7 +770,8 @@ extern "C" size_t gcfr_shadow_workspace_bytes(int32_t B, int32_t H, int32_t W)
     return (size_t)B * (size_t)(H + 1) * (size_t)(W + 1) * sizeof(float4) + (size_t)B * n_stat * 4 * sizeof(int) +
            (size_t)B * (size_t)zb_slot(H, W) * sizeof(float4) + (size_t)B * n_stat * 2 * sizeof(int) +
            (kQueueSlot + 1) * sizeof(int) + 12 + (size_t)B * n_stat * sizeof(int) + 16 +
-           (((W & 31) == 0) ? (size_t)B * (size_t)bitmap_stride_bytes(H, W) : 0);  // mask bitmaps (LDS-staged march)
+           (((W & 31) == 0) ? (size_t)B * (size_t)bitmap_stride_bytes(H, W) : 0) +  // mask bitmaps (LDS-staged march)
+           16 + (size_t)B * n_stat * 4 * sizeof(int);                                  // partial diagonal extents of the masks
 }
 
 // The march's translation unit for a tile shape (gcfr_march_unit.hip, one compilation per shape)
@@ -855,6 +876,8 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         int *mones = tflag + kQueueSlot + 4;                          // (B, n_stat) all-ones flags of the mask chunks
         uint32_t *bitmap = (uint32_t *)(((uintptr_t)(mones + (size_t)B * n_stat) + 15u) & ~(uintptr_t)15u);  // (MB, stride) 16-B aligned
         const bool use_zb = kn.zbound && N >= 2;
+        int *diag = (int *)(((uintptr_t)((char *)bitmap + (((W & 31) == 0) ? (size_t)B * (size_t)bitmap_stride_bytes(H, W) : 0)) + 15u) &
+                            ~(uintptr_t)15u);  // (MB, n_stat, 4)
         // Schedule.  Tiny launches (<= 2048 tiles, B <= 2 at 256^2): split every tile's sample range over the 4
         // waves of its workgroup (finer, more uniform pieces; a quarter-range wave starts the depth-bound skip
         // without a running minimum, so it loses from B = 4 up).  Otherwise the grid: one wave per tile -- with the
@@ -880,7 +903,7 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         const int vec_ok = ((W & 15) == 0) && (((uintptr_t)depth & 15u) == 0) && (((uintptr_t)mask_u8 & 15u) == 0);
         hipLaunchKernelGGL(build_quad_kernel, dim3(hz_blocks + zb_blocks + (int)n_stat + bitmap_blocks + quad_blocks, B), dim3(256), 0, st,
                            depth, (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox, zrange, mones, zb, zb_blocks,
-                           (int)n_stat, use_zb ? 1 : 0, vec_ok, N, t_table, kn.group, tflag, bitmap, bitmap_blocks, hz_blocks);
+                           (int)n_stat, use_zb ? 1 : 0, vec_ok, N, t_table, kn.group, tflag, bitmap, bitmap_blocks, hz_blocks, diag);
         ShadowQuadArgs a = {};
         a.zb = use_zb ? zb : nullptr;
         a.zrange = zrange;
@@ -889,6 +912,7 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         a.depth = depth;
         a.quad = (const float4 *)workspace;
         a.bbox = bbox;
+        a.diag = diag;
         a.mask = mask_u8;
         a.bitmap = bitmap;
         a.hz_off = horizon ? zb_stride(H, W) * 16 : -1;

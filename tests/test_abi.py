@@ -43,7 +43,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     #  H*W/8 bytes per image follows, both for the LDS-staged march; behind each image's records 4 x 1024 float4 of horizon
     #  tables for the trailing loop's termination test)
     assert L.gcfr_shadow_workspace_bytes(8, 256, 256) == (8 * 257 * 257 * 16 + 8 * 4 * 16 + 8 * (1152 + 4096) * 16 + 8 * 4 * 8 + 65 * 4 + 12
-                                                          + 8 * 4 * 4 + 16 + 8 * 8192)
+                                                          + 8 * 4 * 4 + 16 + 8 * 8192 + 16 + 8 * 4 * 16)     # ... + the masks' partial diagonal extents
     assert L.gcfr_light_prep(None, 1, 1, 0.0, 4013.0, None, None, None) == -1
     assert L.gcfr_shade_fwd(None, None, None, None, None, None, 1, 1, 8, 8, 0.5, None, None, None, None, None) == -1
     # the inference image side: null planes, a diagnostic output without its input, mask batch neither 1 nor B, in-place border fix
