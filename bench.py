@@ -5,9 +5,12 @@ Metric (BASELINE.json): ray-steps/s (whole job) + relit faces/s on 256x256 faces
 ray_steps = B*L*H*W*N nominal, never "steps executed".
 
 --workload render (default; BASELINE configs[1]): a batch of 8 synthetic 256x256 faces per GPU, one light each,
-    forward-only shadow + shade.  One "step" = one pass of the hot path over one batch: one gcfr_render_fwd enqueue
-    (prepass: depth repack, statistics, depth bounds, light prep; then the ray march with the shading fused into its
-    epilogue), inputs resident in HBM.  Steps are independent batches: `--streams S` (default 4) keeps S of them in
+    forward-only normals + shadow + shade.  One "step" = one pass of the hot path over one batch: one
+    gcfr_render_from_depth_fwd enqueue -- what RelightNet.forward runs for T8:353-522 -- (prepass: depth repack, statistics,
+    depth bounds, light prep; then the ray march with the normals stencil and the shading fused into its epilogue), inputs
+    resident in HBM.  The same line carries, measured in the same run: `normals_in_*` (SURVEY 8d's accounting form, normals
+    as an input: rounds 1-3's headline step), `config5_*` (configs[4]'s per-GPU shape: 1 face x 18 lights x 512x512 x 320),
+    `train_*` (configs[2]: batch 32, the full training step) and `worst_case`.  Steps are independent batches: `--streams S` (default 4) keeps S of them in
     flight on S HIP streams, each a hipGraph replay of a preallocated RenderFwdPlan -- `value` is that throughput;
     `single_stream` in the same line is the one-batch-at-a-time rate (= the batch-8 latency).
 --workload train (BASELINE configs[2]; configs[3] under torchrun): batch of 32 faces per GPU, one full training step
@@ -22,13 +25,14 @@ The JSON line also carries
   roofline     -- for the dominant kernel, measured live with HIP events on the launch stream (un-captured plan calls
                   on one stream, library-recorded events around the kernel):
                   bound "valu": the SIMD issue time the kernel's instruction mix needs (rocprofv3 SQ_INSTS_VALU_* per
-                  launch from profiles/pmc_summary.json x the per-class issue cost measured by tools/ubench_valu on this
-                  chip) / launch duration, against 1024 SIMDs x 2.4 GHz -- a fraction <= 1 of a limit that binds;
+                  launch from profiles/pmc_summary.json x the guide's SPEC issue cycles per class; `frac_measured_costs`
+                  prices the same mix at the sustained costs tools/ubench_valu measured on this chip) / launch duration,
+                  against 1024 SIMDs x 2.4 GHz -- a fraction <= 1 of a limit that binds;
                   `hbm`: north_star's accounting kept beside it (17.4 algorithmic B per nominal ray-step vs 8 TB/s; the
                   gathers are cache-served and ~91 % of the nominal ray-steps are provably skipped, so it exceeds 1);
                   `traffic` = HBM bytes per launch from the PMC passes (separate --pmc runs, KiB units, read side x2);
   cpu_baseline -- oracle/materialised.py (op-for-op torch-CPU port of the reference, which cannot travel to the GPU
-                  box), T8 form B=3, forward and forward+backward, best of {8, 32, all} host threads (rank 0, N=1 only).
+                  box), T8 form B=3, forward and forward+backward, best of {8, 32} host threads (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -111,11 +115,12 @@ def cpu_baseline(seed0=0, runs=3, with_backward=True):
     """The CPU baseline of record: oracle/materialised.py -- the op-for-op torch-CPU port
     of T8:352-524, bit-equal to the imported reference (tests/test_oracle_vs_reference.py); the reference's own .py
     cannot travel to the GPU box -- in the reference's training form: a batch of B = 3 faces, normals from depth
-    inside the timed region (T8:353), 256 x 256 x 160.  Forward under no_grad at 8, 32 and 64 host threads, median
+    inside the timed region (T8:353), 256 x 256 x 160.  Forward under no_grad at 8 and 32 host threads (64 was never the best in
+    rounds 2-3 and is dropped so that the line's other legs fit the default run), median
     of `runs` after a warm-up each, the BEST thread count reported (all 256 hyper-threads of the GPU host are 14x
     slower than 32 for these memory-bound elementwise ops); then forward+backward (autograd through the port, as
     loss.backward() replays the reference's graph, T8:655) at that thread count, median of `runs`.
-    Checker code used strictly as the reported baseline; bounded: about 2-3 minutes of host time."""
+    Checker code used strictly as the reported baseline; bounded: about one minute of host time."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import materialised as M
     from normals_restatement import depth_to_normals
@@ -154,8 +159,8 @@ def cpu_baseline(seed0=0, runs=3, with_backward=True):
     steps = B * H * W * N_SAMPLES
     by_threads = {}
     # (all 256 hyper-threads of the GPU host: 60 s per batch, 14x slower than 32 -- measured once in round 2,
-    #  profiles/r02_bench_render.json; the sweep stops at 64 so that the default run stays within minutes)
-    for th in sorted({min(8, cores), min(32, cores), min(64, cores)}):
+    #  profiles/r02_bench_render.json; 64 threads: 4.8 M/s against 8.2 M/s at 8, BENCH_r03.json)
+    for th in sorted({min(8, cores), min(32, cores)}):
         torch.set_num_threads(th)
         forward()                                                            # warm-up (thread pool, allocator)
         med, ts = median_time(forward, runs)
@@ -365,6 +370,7 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
+T_START = time.perf_counter()   # main() resets it: the aux legs of the headline line stop adding work after ~170 s
 FORCED_REGIONS = 0       # --regions N: exactly N timed regions (profiling runs want 1); 0 = the rule below
 
 
@@ -590,8 +596,7 @@ SPEC_CYCLES = {"ADD_F32": 2, "MUL_F32": 2, "FMA_F32": 2, "INT32": 2, "OTHER": 2,
 def library_srchash():
     try:
         from geomconsistentfr_amd import build as hb
-        with open(hb.HASH_PATH) as f:
-            return f.read().strip()
+        return hb.recorded_hashes()[0]
     except Exception:
         return None
 
@@ -600,10 +605,15 @@ def run_render(a, rk):
     knobs = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)}
     B = a.faces
     mode = "direct" if a.direct else ("unfused" if a.unfused else ("eager" if a.eager else "plan"))
+    # The step is what the drop-in executes for T8:353-522 (relightnet.py -> block.render_from_depth ->
+    # gcfr_render_from_depth_fwd): normals from depth (a3) INSIDE the step, as in the CPU baseline printed beside it.
+    # --normals-in selects SURVEY 8d's accounting form (normals handed in as a 12 B/pixel input, gcfr_render_fwd); the
+    # headline line carries that figure as `normals_in_*`, measured in the same run.
+    from_depth = (not a.normals_in) and mode in ("plan", "eager")      # (the direct / unfused A/B forms take normals as input)
     headline = (a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse" and a.depth_noise == 0.0
-                and a.data == "synthetic" and B == FACES_PER_GPU and not knobs and mode == "plan" and not a.from_depth
+                and a.data == "synthetic" and B == FACES_PER_GPU and not knobs and mode == "plan" and from_depth
                 and not a.argmin)
-    rig = RenderRig(rk, B, a.size, a.lights, a.samples, a.mask, a.depth_noise, a.data, a.streams, a.from_depth,
+    rig = RenderRig(rk, B, a.size, a.lights, a.samples, a.mask, a.depth_noise, a.data, a.streams, from_depth,
                     a.argmin, knobs, graph=not a.no_graph, mode=mode)
     n_streams, world, rank = rig.n_streams, rk.world, rk.rank
     ev = HipEvents()
@@ -633,6 +643,7 @@ def run_render(a, rk):
                         ("train_depth_b32", dict(data="train_depth", B=32, from_depth=True, want_argmin=True, streams=1))):
             try:
                 kw = dict(kw)
+                kw.setdefault("from_depth", True)                              # the headline's form of the step
                 r2 = RenderRig(rk, kw.pop("B", B), streams=kw.pop("streams", a.streams), **kw)
                 for i in range(20):
                     r2.issue(i, r2.n_streams)
@@ -657,13 +668,54 @@ def run_render(a, rk):
     saturated_ms = None
     if headline and world == 1 and not a.no_worst_case:
         try:
-            r3 = RenderRig(rk, 128, streams=1)
+            r3 = RenderRig(rk, 128, streams=1, from_depth=True)
             for i in range(5):
                 r3.issue(i, 1)
             saturated_ms = r3.kernel_launch_ms(ev, 20)
             del r3
         except Exception:
             saturated_ms = None
+    # the other single-GPU configurations of BASELINE.json, measured in the same run: the accounting form
+    # with normals handed in, configs[4]'s per-GPU shape, and configs[2]'s training step -- short, and never at the headline's
+    # expense (each leg is skipped once the run has used its time budget, and a failure is recorded, not raised)
+    aux = {}
+    if headline and world == 1 and not a.no_worst_case:
+        try:
+            r4 = RenderRig(rk, B, streams=a.streams, from_depth=False)
+            for i in range(20):
+                r4.issue(i, r4.n_streams)
+            sec, reg, _, _ = r4.timed_regions(a.steps)
+            aux["normals_in"] = {"ray_steps_per_sec": r4.ray_steps_per_step * a.steps / sec, "ms_per_step": 1e3 * sec / a.steps,
+                                 "march_kernel_ms": r4.kernel_launch_ms(ev, 50)[0], "regions": reg["n"],
+                                 "note": "SURVEY 8d's accounting form: gcfr_render_fwd with the normals as a 12 B/pixel input "
+                                         "(rounds 1-3's headline step); same faces, same streams, same number of steps"}
+            del r4
+        except Exception as e:
+            aux["normals_in"] = {"error": repr(e)}
+        try:
+            r5 = RenderRig(rk, 1, size=512, lights=18, samples=320, streams=a.streams, from_depth=True)
+            for i in range(20):
+                r5.issue(i, r5.n_streams)
+            steps5 = 100
+            sec, reg, _, _ = r5.timed_regions(steps5)
+            aux["config5"] = {"ray_steps_per_sec": r5.ray_steps_per_step * steps5 / sec, "ms_per_step": 1e3 * sec / steps5,
+                              "faces_lights_per_sec": 18 * steps5 / sec, "march_kernel_ms": r5.kernel_launch_ms(ev, 30)[0],
+                              "steps": steps5, "regions": reg["n"], "batches_in_flight": r5.n_streams,
+                              "workload": "BASELINE configs[4], per-GPU shape: 1 face x 18 lights x 512x512 x 320 march steps, "
+                                          "normals from depth, forward-only shadow+shade"}
+            del r5
+        except Exception as e:
+            aux["config5"] = {"error": repr(e)}
+        if a.no_train_leg:
+            aux["train"] = {"skipped": "--no-train-leg"}
+        elif time.perf_counter() - T_START > 170.0:
+            aux["train"] = {"skipped": "time budget: %.0f s used before the training leg" % (time.perf_counter() - T_START)}
+        else:
+            try:
+                torch.cuda.empty_cache()
+                aux["train"] = measure_train(rk, 32, steps=12, warmup=6)
+            except Exception as e:
+                aux["train"] = {"error": repr(e)}
     if rank != 0:
         return None
     algo_bytes = rsps * ALGO_BYTES_PER_RAY_STEP                              # per launch (one rank)
@@ -676,35 +728,57 @@ def run_render(a, rk):
                         "fraction of a limit (it exceeds 1) -- the binding roofline is the VALU one"}
     fwd = pm.get("kernels", {}).get("fwd")
     if headline and fwd:
-        roof = valu_roofline(fwd, shadow_ms)
-        roof["avg_launch_ms_min_max"] = [shadow_ms_min, shadow_ms_max]
-        # the same instruction mix priced at the guide's SPEC issue rates (MI355X_MICROARCH.md: SIMD-32, 2 cycles per wave64
-        # f32 / int op, 4 per f64 / cvt; transcendentals quarter rate) instead of the measured sustained costs
+        cap = N_SIMD * NOMINAL_HZ                                             # SIMD issue cycles per second of the chip
+        # `frac`: the kernel's instruction mix priced at the guide's SPEC issue rates (MI355X_MICROARCH.md: SIMD-32, 2 cycles per
+        # wave64 f32 / int op, 4 per f64 / cvt, transcendentals quarter rate) / live launch duration / capacity -- the number a
+        # reader takes from the line is the conservative one.  `frac_measured_costs`: the same mix priced
+        # at the sustained per-class costs tools/ubench_valu measured on this chip (rounds 1-3's `frac`).
         spec_cycles = sum(fwd["valu"]["by_class"].get(k, 0.0) * c for k, c in SPEC_CYCLES.items())
-        roof["frac_spec"] = spec_cycles / (N_SIMD * NOMINAL_HZ * shadow_ms * 1e-3)
-        roof["spec_issue_cycles_per_launch"] = spec_cycles
+        meas_cycles = fwd["valu"]["issue_cycles_per_launch"]
+        step_s = elapsed / a.steps
+        roof = {"bound": "valu", "kernel": fwd["kernel"], "achieved": spec_cycles / (shadow_ms * 1e-3) / 1e9, "peak": cap / 1e9,
+                "unit": "G SIMD-issue-cycles/s", "frac": spec_cycles / (cap * shadow_ms * 1e-3),
+                "frac_measured_costs": meas_cycles / (cap * shadow_ms * 1e-3),
+                "avg_launch_ms": shadow_ms, "avg_launch_ms_min": shadow_ms_min, "avg_launch_ms_max": shadow_ms_max,
+                "traffic": fwd["hbm"]["bytes_per_launch"],
+                "valu_insts_per_launch": fwd["valu"]["insts_per_launch"], "spec_issue_cycles_per_launch": spec_cycles,
+                "measured_cost_issue_cycles_per_launch": meas_cycles,
+                "kernel_ray_steps_per_sec": rsps / (shadow_ms * 1e-3),
+                # the same mix against the overlapped rate: what the chip's VALU does when `streams` launches share it
+                "frac_at_throughput": spec_cycles / (cap * step_s),
+                "frac_measured_costs_at_throughput": meas_cycles / (cap * step_s),
+                # north_star's HBM accounting, flattened (the driver's record keeps scalars only): 17.4 algorithmic B per
+                # NOMINAL ray-step / launch duration against 8 TB/s -- exceeds 1, not a fraction of a limit (see `hbm`)
+                "hbm_achieved_GBs_nominal": achieved_gbs, "hbm_frac_nominal": achieved_gbs / HBM_PEAK_GBS,
+                "hbm_traffic_frac_of_peak": fwd["hbm"]["bytes_per_launch"] / (shadow_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "hbm_measured_copy_GBs": hbm_line["measured_copy_GBs"],
+                "note": "achieved = sum over VALU instruction classes of (wave-instructions per launch, rocprofv3 SQ_INSTS_VALU_* of "
+                        "this workload, profiles/pmc_summary.json) x (SPEC issue cycles of the class, MI355X_MICROARCH.md), divided "
+                        "by the kernel's un-overlapped launch duration measured live (HIP events recorded by the library around "
+                        "the kernel, 100 plan calls on one stream); peak = 1024 SIMDs x 2.4 GHz"}
         roof["hbm"] = hbm_line
-        roof["kernel_ray_steps_per_sec"] = rsps / (shadow_ms * 1e-3)
         if "work" in fwd:
             roof["executed_fraction_of_nominal_ray_steps"] = fwd["work"]["executed_fraction_of_nominal"]
             roof["valu_wave_insts_per_executed_wave_step"] = fwd["work"]["valu_wave_insts_per_executed_wave_step"]
         if "l1" in fwd:
             roof["l1_frac_of_peak_under_rocprofv3"] = fwd["l1"]["frac"]
-        # the same mix against the overlapped rate: what the chip's VALU does when `streams` launches share it
-        roof["frac_at_throughput"] = fwd["valu"]["issue_cycles_per_launch"] / (N_SIMD * NOMINAL_HZ * elapsed / a.steps)
-        roof["frac_spec_at_throughput"] = spec_cycles / (N_SIMD * NOMINAL_HZ * elapsed / a.steps)
+        if fwd.get("wave_cycles_quad") and fwd.get("wait_any_quad"):
+            roof["wait_any_frac_of_wave_time"] = fwd["wait_any_quad"] / fwd["wave_cycles_quad"]
         f128 = pm.get("kernels", {}).get("fwd_b128")
         if saturated_ms and f128:
             spec128 = sum(f128["valu"]["by_class"].get(k, 0.0) * c for k, c in SPEC_CYCLES.items())
+            roof["frac_spec_saturated"] = spec128 / (cap * saturated_ms[0] * 1e-3)
+            roof["frac_measured_costs_saturated"] = f128["valu"]["issue_cycles_per_launch"] / (cap * saturated_ms[0] * 1e-3)
+            roof["saturated_launch_ms"] = saturated_ms[0]
+            roof["saturated_kernel_ray_steps_per_sec"] = 128 * 256 * 256 * 160 / (saturated_ms[0] * 1e-3)
             roof["saturated"] = {
                 "faces_per_launch": 128, "avg_launch_ms": saturated_ms[0], "avg_launch_ms_min_max": list(saturated_ms[1:]),
                 "valu_insts_per_launch": f128["valu"]["insts_per_launch"],
-                "frac": f128["valu"]["issue_cycles_per_launch"] / (N_SIMD * NOMINAL_HZ * saturated_ms[0] * 1e-3),
-                "frac_spec": spec128 / (N_SIMD * NOMINAL_HZ * saturated_ms[0] * 1e-3),
-                "kernel_ray_steps_per_sec": 128 * 256 * 256 * 160 / (saturated_ms[0] * 1e-3),
+                "frac": roof["frac_spec_saturated"], "frac_measured_costs": roof["frac_measured_costs_saturated"],
+                "kernel_ray_steps_per_sec": roof["saturated_kernel_ray_steps_per_sec"],
                 "note": "the same kernel on ONE launch of 128 faces, un-overlapped (library events, 20 calls): long enough that "
-                        "the launch's tail -- a launch ends with its heaviest tiles, §4.1 -- does not matter; instruction mix from "
-                        "a PMC pass of exactly that launch (profiles/pmc_summary.json kernels.fwd_b128)"}
+                        "the launch's tail -- a launch ends with its heaviest tiles, DESIGN 4.1 -- does not matter; instruction mix "
+                        "from a PMC pass of exactly that launch (profiles/pmc_summary.json kernels.fwd_b128)"}
         # instruction counts / traffic come from the committed PMC passes (rocprofv3 cannot run inside the timed run):
         # they are only valid for the library they were collected on
         lib_hash, pmc_hash = library_srchash(), pm.get("library_srchash")
@@ -713,7 +787,8 @@ def run_render(a, rk):
     else:       # no PMC mix for this workload / kernel selection: HBM accounting only
         roof = dict(hbm_line, kernel="shadow_fwd_quad_kernel" if mode != "direct" else "shadow_fwd_kernel",
                     avg_launch_ms=shadow_ms, traffic=None, kernel_ray_steps_per_sec=rsps / (shadow_ms * 1e-3))
-    desc = ("batch=%d %s 256x256 faces per GPU, 1 light each, 160 march steps, forward-only shadow+shade; %d batch(es) in flight"
+    desc = ("batch=%d %s 256x256 faces per GPU, 1 light each, 160 march steps, forward-only normals+shadow+shade "
+            "(gcfr_render_from_depth_fwd: what RelightNet.forward runs for T8:353-522); %d batch(es) in flight"
             % (B, "synthetic" if a.data == "synthetic" else "FFHQ-fixture", n_streams))
     out = {
         "metric": "ray_steps_per_sec", "value": value, "unit": "ray-steps/s", **{k: layout[k] for k in ("n_gpus", "rccl_ranks")},
@@ -724,7 +799,8 @@ def run_render(a, rk):
                                ("non-headline: batch=%d %s %dx%d faces per GPU, %d light(s) each, %d march steps, mask=%s, "
                                 "depth noise %g, knobs %s, %s%sforward-only shadow+shade; %d batch(es) in flight"
                                 % (B, a.data, a.size, a.size, a.lights, a.samples, a.mask, a.depth_noise, knobs or "default",
-                                   "argmin variant, " if a.argmin else "", "normals fused, " if a.from_depth else "", n_streams)),
+                                   "argmin variant, " if a.argmin else "", "normals from depth, " if from_depth else "normals as input, ",
+                                   n_streams)),
                    "faces_per_gpu": B, "H": a.size, "W": a.size, "lights_per_face": a.lights, "n_samples": a.samples,
                    "parallelism": "dp%d" % world, "hip_streams": n_streams, "batches_in_flight": n_streams,
                    "distinct_face_batches": n_streams,
@@ -746,6 +822,32 @@ def run_render(a, rk):
     }
     if worst is not None:
         out["worst_case"] = worst
+        for k in ("ones_mask", "depth_noise_400", "ffhq", "train_depth_b32"):    # scalars at the top level too
+            if "ray_steps_per_sec" in worst.get(k, {}):
+                out["worst_case_%s_ray_steps_per_sec" % k] = worst[k]["ray_steps_per_sec"]
+    if aux:
+        out["aux"] = aux
+        flat = {}
+        ni, c5, tr = aux.get("normals_in", {}), aux.get("config5", {}), aux.get("train", {})
+        if "ray_steps_per_sec" in ni:
+            flat.update(normals_in_ray_steps_per_sec=ni["ray_steps_per_sec"], normals_in_ms_per_step=ni["ms_per_step"],
+                        normals_in_march_kernel_ms=ni["march_kernel_ms"])
+        if "ray_steps_per_sec" in c5:
+            flat.update(config5_ray_steps_per_sec=c5["ray_steps_per_sec"], config5_ms_per_step=c5["ms_per_step"],
+                        config5_march_kernel_ms=c5["march_kernel_ms"])
+        if "step_ms" in tr:
+            flat.update(train_step_ms=tr["step_ms"], train_faces_per_sec=tr["faces_per_sec"],
+                        train_march_kernel_ms=tr["march_kernel_ms"], train_bwd_kernel_ms=tr["bwd_kernel_ms"],
+                        train_ray_steps_per_sec=tr["ray_steps_per_sec"])
+        out.update(flat)
+        # ... and once more inside `roofline`, whose scalar keys the driver's parsed record is known to keep (BENCH_r03.json kept
+        # every scalar of `roofline` and `config` but only the NAMES of extra top-level keys)
+        if isinstance(out.get("roofline"), dict):
+            out["roofline"].update({"aux_" + k: v for k, v in flat.items()})
+            if worst is not None:
+                out["roofline"].update({"aux_worst_case_%s_ray_steps_per_sec" % k: worst[k]["ray_steps_per_sec"]
+                                        for k in ("ones_mask", "depth_noise_400", "ffhq", "train_depth_b32")
+                                        if "ray_steps_per_sec" in worst.get(k, {})})
     if rig.graph_error:
         out["config"]["graph_capture_failed"] = rig.graph_error
     if world == 1 and not a.no_cpu_baseline and headline:
@@ -757,31 +859,31 @@ def run_render(a, rk):
 # ------------------------------------------------------------------------------------------------
 # workload "train": BASELINE configs[2] (1 GPU) / configs[3] (8 GPUs, DDP over RCCL)
 # ------------------------------------------------------------------------------------------------
-def run_train(a, rk):
-    rank, world, dev, dist = rk.rank, rk.world, rk.dev, rk.dist
+def measure_train(rk, B, steps, warmup, epoch=200):
+    """One rank's measurement of the full training step (BASELINE configs[2]; configs[3] when rk has > 1 rank): `warmup`
+    untimed steps (MIOpen's find mode tunes on first use), `steps` timed ones fenced on both sides, then the render block's own
+    kernels on this batch measured live: forward (prepass + march with fused normals + shading, argmin variant; library events
+    around the march kernel) and the fused backward (events on the current stream), from the tensors of a real step's forward.
+    Returns a dict of scalars (a collective when rk.dist is set: every rank calls it)."""
+    dev, dist = rk.dev, rk.dist
     from geomconsistentfr_amd import _lib
     from geomconsistentfr_amd import block as R
     from geomconsistentfr_amd.train import TrainConfig, Trainer, synthetic_batch
 
-    B = a.faces if a.faces != FACES_PER_GPU else 32                          # configs[2]: batch=32 per GPU
-    torch.manual_seed(1234 + rank)
+    torch.manual_seed(1234 + rk.rank)
     tr = Trainer(TrainConfig(), device=dev, distributed=dist is not None)
-    batch = synthetic_batch(B, rank * 1_000_000, device=dev)
-    epoch = 200                                                               # every epoch-gated skip on (T8:245-283)
-    for j in range(max(a.warmup, 6)):                                        # MIOpen find mode tunes on first use
+    batch = synthetic_batch(B, rk.rank * 1_000_000, device=dev)
+    for j in range(max(warmup, 6)):                                          # MIOpen find mode tunes on first use
         tr.step(batch, epoch, j, log=False)
     rk.fence()
     t0 = time.perf_counter()
-    for j in range(a.steps):
+    for j in range(steps):
         tr.step(batch, epoch, j, log=False)                                  # D step every 5th (T8:624), G step always
     rk.fence()
     own_elapsed = time.perf_counter() - t0
     elapsed = rk.max_over_ranks(own_elapsed)
     per_rank_s = rk.gather(own_elapsed)
-    layout = rk.describe()
 
-    # the render block's own kernels on this batch, measured live on the current stream: forward (prepass + march with
-    # fused normals + shading, argmin variant) and the fused backward, from the tensors of a real step's forward
     with torch.no_grad():
         albedo, depth, SL = tr.model.features(batch["images"], epoch)
     prm = tr.model.render_params
@@ -799,6 +901,10 @@ def run_train(a, rk):
         o = plan(*ins)
     torch.cuda.synchronize()
     march_ms = float(np.mean([ev.elapsed_ms(e0, e1) for e0, e1, _ in pairs[5:]]))
+    for e0, e1, _ in pairs:
+        ev.destroy(e0)
+        ev.destroy(e1)
+    plan.options = None
     L_ = _lib.load()
     g_ren = torch.rand((B, 1, 3, 256, 256), device=dev) * masks[:, None, None].float()  # the losses mask the rendered image
     g_alb, g_depth = torch.empty((B, 3, 256, 256), device=dev), torch.zeros((B, 256, 256), device=dev)
@@ -822,39 +928,53 @@ def run_train(a, rk):
     t_ev[1].record()
     torch.cuda.synchronize()
     bwd_ms = t_ev[0].elapsed_time(t_ev[1]) / 30
+    del tr, plan
+    step_ms = 1e3 * elapsed / steps
+    return {"step_ms": step_ms, "faces_per_sec": rk.world * B * steps / elapsed,
+            "ray_steps_per_sec": rk.world * B * 256 * 256 * N_SAMPLES * steps / elapsed,
+            "march_kernel_ms": march_ms, "bwd_kernel_ms": bwd_ms, "render_block_share_of_step": (march_ms + bwd_ms) / step_ms,
+            "faces_per_gpu": B, "steps": steps, "warmup": max(warmup, 6), "epoch": epoch, "elapsed_s": elapsed,
+            "per_rank_s": per_rank_s,
+            "workload": "BASELINE configs[%d]: batch=%d per GPU, full training step (RelightNet forward with the fused HIP render "
+                        "block, PatchGAN step every 5th iteration, seven losses, backward through the fused HIP backward, two "
+                        "Adam steps)%s" % (2 if rk.world == 1 else 3, B,
+                                           "" if rk.world == 1 else ", DistributedDataParallel over RCCL")}
+
+
+def run_train(a, rk):
+    rank, world = rk.rank, rk.world
+    B = a.faces if a.faces != FACES_PER_GPU else 32                          # configs[2]: batch=32 per GPU
+    m = measure_train(rk, B, a.steps, a.warmup)
+    layout = rk.describe()
     if rank != 0:
         return None
-    ray_steps = B * 256 * 256 * N_SAMPLES
-    value = world * ray_steps * a.steps / elapsed
+    bwd_ms, march_ms = m["bwd_kernel_ms"], m["march_kernel_ms"]
     pm = pmc_summary().get("kernels", {})
     px_bytes = 72.0     # per pixel: reads depth 4 + albedo 12 + g_rendered 12 + min_dist 4 + argmin 4 + normals 12 (+ stencil
     #                     neighbours from cache), writes grad_albedo 12 + grad_depth read-modify-write 8 + light partials ~0
+    traffic = pm.get("bwd", {}).get("hbm", {}).get("bytes_per_launch")
     bwd_roof = {"bound": "hbm", "kernel": "gcfr::render_bwd_single_light_kernel", "avg_launch_ms": bwd_ms,
                 "achieved": B * 65536 * px_bytes / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": B * 65536 * px_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": B * 65536 * px_bytes,
-                "traffic": pm.get("bwd", {}).get("hbm", {}).get("bytes_per_launch"),
-                "note": "one backward sample per pixel: compulsory I/O 72 B per pixel; what holds the kernel back is the L2's "
-                        "f32 atomic rate (4 bilinear-corner atomics per pixel: 78 of 167 us before same-texel merging, "
-                        "profiles/r02_bwd_stage_trace.txt, DESIGN.md 4.5), then f64 VALU issue"}
-    # (no VALU line here: the committed instruction mixes are those of tools/bwd_bench.py -- dense upstream gradient,
-    #  depth noise 2 -- not of this step's masked gradient and untrained-network depth; profiles/pmc_summary.json has
-    #  them with their own launch times: backward 0.40, training march 0.66 of the VALU issue capacity)
+                "traffic": traffic,
+                "note": "one backward sample per pixel: compulsory I/O 72 B per pixel; `traffic` is that of tools/bwd_bench.py's "
+                        "DENSE upstream gradient at batch 32 (profiles/pmc_summary.json kernels.bwd), this step's gradient is "
+                        "masked (about half the pixels carry one)"}
     return {
-        "metric": "ray_steps_per_sec", "value": value, "unit": "ray-steps/s", "n_gpus": world,
+        "metric": "ray_steps_per_sec", "value": m["ray_steps_per_sec"], "unit": "ray-steps/s", "n_gpus": world,
         "rccl_ranks": layout["rccl_ranks"], "process_layout": layout,
-        "per_rank": [{"rank": r, "seconds": s_, "faces_per_sec": B * a.steps / s_} for r, s_ in enumerate(per_rank_s)],
-        "steps": a.steps, "warmup": max(a.warmup, 6), "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+        "per_rank": [{"rank": r, "seconds": s_, "faces_per_sec": B * a.steps / s_} for r, s_ in enumerate(m["per_rank_s"])],
+        "steps": a.steps, "warmup": m["warmup"], "ms_per_step": m["step_ms"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 network (MIOpen) + f64/f32 render block", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[%d]: batch=%d per GPU, full training step (RelightNet forward with the fused HIP "
-                               "render block, PatchGAN step every 5th iteration, seven losses, backward through the fused HIP "
-                               "backward, two Adam steps)%s" % (2 if world == 1 else 3, B,
-                                                               "" if world == 1 else ", DistributedDataParallel over RCCL"),
+        "config": {"workload": m["workload"],
                    "faces_per_gpu": B, "global_batch": B * world, "H": 256, "W": 256, "n_samples": N_SAMPLES,
-                   "parallelism": "dp%d" % world, "epoch": epoch},
-        "faces_per_sec": world * B * a.steps / elapsed,
+                   "parallelism": "dp%d" % world, "epoch": m["epoch"]},
+        "faces_per_sec": m["faces_per_sec"],
+        "train_step_ms": m["step_ms"], "train_faces_per_sec": m["faces_per_sec"], "train_march_kernel_ms": march_ms,
+        "train_bwd_kernel_ms": bwd_ms,
         "render_block_ms": {"forward_march_kernel": march_ms, "fused_backward_kernel": bwd_ms,
-                            "share_of_step": (march_ms + bwd_ms) / (1e3 * elapsed / a.steps),
+                            "share_of_step": m["render_block_share_of_step"],
                             "note": "the step is MIOpen-bound (fp32 convolutions of the hourglass and PatchGAN); the render "
                                     "block's two big kernels are this share of it"},
         "roofline": bwd_roof,
@@ -895,8 +1015,12 @@ def main():
     ap.add_argument("--direct", action="store_true", help="A/B: direct-gather kernel (no workspace prepass)")
     ap.add_argument("--unfused", action="store_true", help="A/B: three separate entry points instead of gcfr_render_fwd")
     ap.add_argument("--from-depth", action="store_true",
-                    help="also compute the normals (T8:353-354) inside the march epilogue instead of reading them "
-                         "(SURVEY 8d's 17.4 B/ray-step accounting counts normals as a 12 B/pixel input, the default)")
+                    help="(the default since round 4, accepted for old scripts) normals from depth (T8:353-354) inside the march "
+                         "epilogue: gcfr_render_from_depth_fwd, what RelightNet.forward runs")
+    ap.add_argument("--normals-in", action="store_true",
+                    help="SURVEY 8d's accounting form instead: normals handed in as a 12 B/pixel input (gcfr_render_fwd; rounds "
+                         "1-3's headline step -- the default line carries it as normals_in_*)")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the configs[2] training-step leg of the headline line")
     ap.add_argument("--argmin", action="store_true", help="the training-time march (argmin tracked, 5 waves/SIMD)")
     ap.add_argument("--streams", type=int, default=4,
                     help="batches in flight: successive steps go round-robin to this many HIP streams, one RenderFwdPlan (own "
@@ -921,6 +1045,8 @@ def main():
                     help="A/B: comma list of gcfr_options knobs, e.g. tile_w=32,ksplit=1,depth_bound_skip=0,group=2 "
                          "(never changes a result bit)")
     a = ap.parse_args()
+    global T_START
+    T_START = time.perf_counter()
     if a.steps is None:
         a.steps = 3000 if a.workload == "render" else 20
     if a.warmup is None:

@@ -46,7 +46,16 @@ def _code_only(text: str) -> str:
     out, i, n = [], 0, len(text)
     while i < n:
         c = text[i]
-        if c == '"' or c == "'":                      # string / character literal: copied verbatim
+        if c == "'" and i > 0 and i + 1 < n and text[i - 1].isalnum() and text[i + 1].isalnum() and _in_number(text, i):
+            out.append(c)                             # C++14 digit separator (1'000'000), not a character literal
+            i += 1
+        elif c == '"' and _prefix_token(text, i) in ("R", "u8R", "uR", "UR", "LR"):
+            k = text.find("(", i)                     # raw string R"delim( ... )delim": copied verbatim, nothing inside is a comment
+            end = -1 if k < 0 else text.find(")" + text[i + 1:k] + '"', k)
+            j = n if end < 0 else end + (k - i) + 1
+            out.append(text[i:j])
+            i = j
+        elif c == '"' or c == "'":                    # string / character literal: copied verbatim
             j = i + 1
             while j < n and text[j] != c:
                 j += 2 if text[j] == "\\" else 1
@@ -66,6 +75,23 @@ def _code_only(text: str) -> str:
     return "\n".join(ln for ln in lines if ln.strip())
 
 
+def _prefix_token(text: str, i: int) -> str:
+    """the identifier characters immediately in front of text[i] (a string literal's encoding / raw prefix, if any)"""
+    j = i
+    while j > 0 and (text[j - 1].isalnum() or text[j - 1] == "_"):
+        j -= 1
+    return text[j:i]
+
+
+def _in_number(text: str, i: int) -> bool:
+    """Is the apostrophe at text[i] inside a numeric literal?  Walk back over [0-9a-zA-Z'.]: a pp-number starts with a digit
+    (or a dot followed by one)."""
+    j = i
+    while j > 0 and (text[j - 1].isalnum() or text[j - 1] in "'._"):
+        j -= 1
+    return j < i and (text[j].isdigit() or (text[j] == "." and j + 1 < i and text[j + 1].isdigit()))
+
+
 def source_hash() -> str:
     """sha256 over the flags, the list of march units and the CODE (comments stripped) of every file the library is compiled
     from (csrc/*, include/gcfr.h)."""
@@ -79,13 +105,38 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
+def full_bytes_hash() -> str:
+    """sha256 over the raw bytes of the same files: the fallback beside the code-only hash (second line of the .srchash
+    file).  `GCFR_STRICT_HASH=1` makes needs_build() compare it too, so that a change the comment stripper mis-reads as
+    "comment only" cannot leave a stale library behind where that matters (CI; build(force=True) always rebuilds anyway)."""
+    import hashlib
+    h = hashlib.sha256((" ".join(FLAGS) + " " + repr(MARCH_UNITS)).encode())
+    for d in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(PKG, "..", "include", "gcfr.h")]:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def recorded_hashes():
+    """(code-only hash, full-bytes hash | None) recorded beside the library, or (None, None)."""
+    try:
+        with open(HASH_PATH) as f:
+            lines = f.read().split()
+    except OSError:
+        return None, None
+    return (lines[0] if lines else None), (lines[1] if len(lines) > 1 else None)
+
+
 def needs_build() -> bool:
     """True when the library is missing or was built from other sources (content hash recorded beside the .so --
     not mtimes, which a snapshot copy to the GPU box does not preserve)."""
     if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
         return True
-    with open(HASH_PATH) as f:
-        return f.read().strip() != source_hash()
+    code, full = recorded_hashes()
+    if code != source_hash():
+        return True
+    return os.environ.get("GCFR_STRICT_HASH") == "1" and full is not None and full != full_bytes_hash()
 
 
 def compile_and_link(out: str, defines=(), verbose: bool = False, jobs=None) -> str:
@@ -122,7 +173,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     compile_and_link(LIB_PATH, verbose=verbose)
     with open(HASH_PATH, "w") as f:
-        f.write(source_hash() + "\n")
+        f.write(source_hash() + "\n" + full_bytes_hash() + "\n")
     return LIB_PATH
 
 

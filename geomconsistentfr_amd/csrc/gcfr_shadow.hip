@@ -473,7 +473,15 @@ __device__ inline void build_horizon_block(int k, int b, const float *__restrict
         const bool in_w = c < W;
         const int cc = in_w ? c : 0;  // (loads stay inside the plane; their values are dropped)
         // dilation across the segment's edges is not looked up: with more than one segment the edge lanes are always live
-        const unsigned long long edge = segs > 1 ? 0x8000000000000001ull : 0ull;
+        // -- and so is the image's last dword of columns, the wrap partner of column 0 (below)
+        const int last_lane = min(63, ((W - (sg << 8)) >> 2) - 1);  // this segment's last lane inside the image
+        const unsigned long long edge = segs > 1 ? (0x8000000000000001ull | (1ull << last_lane)) : 0ull;
+        // The dilation WRAPS where the reference's gathers do (index -1 == last, T8:488-491): a sample whose rounded cell lies in
+        // column 0 (row 0) reads column W-1 (row H-1) as its left (upper) bilinear corner, with weight 1e-4 when it sits on the
+        // image's edge.  So a non-zero mask cell in column 0 makes the last column live in its three rows, and one in row 0 makes
+        // row H-1 live in its columns (round 4, advisor r03: a mask touching only the left / top edge left the wrap partner out
+        // of the tables, and a large masked-out depth there was not covered by the trailing loop's cap).
+        const unsigned long long wrap_bit = segs > 1 ? 0ull : (1ull << last_lane);
         float4 cm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // running maxima of this lane's four columns
         for (int r0 = r_lo; r0 < r_hi; r0 += RB) {
             uint32_t md[RB + 2];
@@ -481,7 +489,7 @@ __device__ inline void build_horizon_block(int k, int b, const float *__restrict
 #pragma unroll
             for (int j = 0; j < RB + 2; ++j) {
                 const int r = r0 - 1 + j;
-                md[j] = *(const uint32_t *)(m + (size_t)min(max(r, 0), H - 1) * W + cc);
+                md[j] = *(const uint32_t *)(m + (size_t)(r == H ? 0 : min(max(r, 0), H - 1)) * W + cc);  // (row H: row 0, the wrap)
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j)
@@ -490,13 +498,13 @@ __device__ inline void build_horizon_block(int k, int b, const float *__restrict
 #pragma unroll
             for (int j = 0; j < RB + 2; ++j) {
                 const int r = r0 - 1 + j;
-                bits[j] = __builtin_amdgcn_ballot_w64(in_w && r >= 0 && r < H && md[j] != 0);
+                bits[j] = __builtin_amdgcn_ballot_w64(in_w && r >= 0 && r <= H && md[j] != 0);
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
                 const int r = r0 + j;
                 const unsigned long long v3 = bits[j] | bits[j + 1] | bits[j + 2];
-                const unsigned long long live = v3 | (v3 << 1) | (v3 >> 1) | edge;
+                const unsigned long long live = v3 | (v3 << 1) | (v3 >> 1) | edge | ((v3 & 1ull) ? wrap_bit : 0ull);
                 float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (in_w && r < r_hi && ((live >> lane) & 1ull))  // (fmaxf drops NaN)
                     v = make_float4(fmaxf(dv[j].x, 0.0f), fmaxf(dv[j].y, 0.0f), fmaxf(dv[j].z, 0.0f), fmaxf(dv[j].w, 0.0f));

@@ -43,8 +43,8 @@ class RelightDataset:
         d = {k: os.path.join(root, v) for k, v in DIRS.items()}
         depths = sorted(os.listdir(d["depths"]))                                           # T8:539
         masks = sorted(os.listdir(d["masks"]))                                             # T8:540
-        if len(masks) != len(depths):
-            raise ValueError("load_data pairs depth maps and depth masks by position: %d maps, %d masks" % (len(depths), len(masks)))
+        if len(masks) < len(depths):       # the script iterates range(len(depths)) and indexes masks[i]: surplus masks are tolerated
+            raise ValueError("load_data pairs depth maps and depth masks by position: %d maps, only %d masks" % (len(depths), len(masks)))
         n = len(depths) if limit is None else min(limit, len(depths))
         self.H, self.W, self.ids = H, W, []
         self.images = np.zeros((n, H, W, 3), np.uint8)

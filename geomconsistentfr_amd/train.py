@@ -207,8 +207,15 @@ class Trainer:
         kw = ddp_kwargs(self.cfg, self.device, generator=True, epoch=epoch)
         if self._net_find_unused == kw["find_unused_parameters"]:
             return
+        # BatchNorm running statistics stay per GPU (module docstring).  DDP's constructor synchronises module state from
+        # rank 0 (_sync_module_states); whether that includes BUFFERS under broadcast_buffers=False has differed between torch
+        # releases, so the buffers are snapshotted and put back around the (re-)wrap instead of trusting the installed one.
+        keep = [(b_, b_.detach().clone()) for b_ in self.model.buffers()]
         self.net = None                                                       # release the previous reducer's hooks
-        self.net = DDP(self.model, **kw)
+        self.net = DDP(self.model, **kw)                                      # (callers must not cache `trainer.net`: a
+        with torch.no_grad():                                                 #  still-referenced old wrapper keeps its hooks)
+            for b_, saved in keep:
+                b_.copy_(saved)
         self._net_find_unused = kw["find_unused_parameters"]
 
     def step(self, batch: Dict[str, torch.Tensor], epoch: int, j: int, log: bool = True) -> Dict[str, float]:

@@ -4,7 +4,7 @@ loop of the march terminates against -- read back from the workspace and compare
 The tables must BOUND, from above, every depth value an unmasked sample can read (cells within one cell of a non-zero mask
 cell, T8:472-494) and 0; the kernel dilates the mask by whole dwords of columns (a superset).  Checked here: equality with
 the numpy statement of exactly that construction (the kernel stores, per entry, the values of four row bands whose maximum
-is the table), and >= the tight 3 x 3 dilation it is a superset of.  That the march's
+is the table), and >= the tight 3 x 3 dilation (wrapping at index -1 as the reference's gathers do) it is a superset of.  That the march's
 results do not change is tests/test_gpu_parity.py's business (bit-equality to the C oracle)."""
 import numpy as np
 import pytest
@@ -25,7 +25,8 @@ def _tables(depth, mask):
     v3 = dw.copy()
     v3[1:] |= dw[:-1]
     v3[:-1] |= dw[1:]
-    live = v3.copy()
+    v3[H - 1] |= dw[0]                                # the dilation wraps where the gathers do (index -1 == last, T8:488-491):
+    live = v3.copy()                                  # row 0 unmasked -> row H-1 is readable
     nseg = (W + 255) // 256
     for s in range(nseg):
         seg = v3[:, s * 64:(s + 1) * 64]
@@ -37,12 +38,21 @@ def _tables(depth, mask):
             if out.shape[1] == 64:
                 out[:, 63] = True
         live[:, s * 64:(s + 1) * 64] = out
+    if nseg > 1:
+        live[:, -1] = True                            # ... the image's last dword of columns: always live with several segments,
+    else:
+        live[:, -1] |= v3[:, 0]                       # the wrap partner of column 0 otherwise
     live = np.repeat(live, 4, axis=1)
-    tight = nz.copy()
+    # the cells an unmasked sample can read: its rounded cell's 3 x 3 neighbourhood, where index -1 is the LAST column / row
+    # (floor(u) = -1 wraps, T8:488-491) and index W / H does not occur (the end point is clamped to the box, T8:462-465)
+    tight = np.zeros_like(nz)
     for dr in (-1, 0, 1):
         for dc in (-1, 0, 1):
-            sh = np.zeros_like(nz)
-            sh[max(dr, 0):H + min(dr, 0), max(dc, 0):W + min(dc, 0)] = nz[max(-dr, 0):H + min(-dr, 0), max(-dc, 0):W + min(-dc, 0)]
+            sh = np.roll(np.roll(nz, dr, axis=0), dc, axis=1)
+            if dr == 1:
+                sh[0] = False
+            if dc == 1:
+                sh[:, 0] = False
             tight |= sh
     assert (live | ~tight).all()                      # the kernel's live set contains the tight one
 
@@ -133,3 +143,128 @@ def test_tiny_and_odd_shapes_march_bit_identically_with_the_tables(H, W):
     assert np.array_equal(md, md_o)
     lit = md_o < 1e5
     assert np.array_equal(am[lit], am_o[lit])
+
+
+def test_rays_running_along_column_zero_read_the_wrap_column_at_every_sample():
+    """The case in which the wrap partner decides results (advisor r03): a light whose image-plane x is the image's left
+    edge (C_x = -W/2 to within 1e-3), so that the rays of the pixels in column 0 climb straight up that column with
+    u_x = -1e-4 ... 0 at every sample: each reads column W-1 as its left bilinear corner with weight ~1e-4.  The mask covers
+    the left quarter only; column W-1 holds a masked-out wall of 1e5 ... 2e6 (z_A = z + 10 ... 200: it ramps with the height the
+    climbing rays have gained, so their minima sit at LATE samples).  The trailing loop's cap must know that wall.  Grid schedule forced; against the C oracle, bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import c_oracle
+    from geomconsistentfr_amd import _lib, RenderParams, light_prep, shadow_min_distance
+    dev = torch.device("cuda:0")
+    H = W = 256
+    prm = RenderParams()
+    lights = []
+    for ly, lz in ((0.8, 0.6), (0.9, 0.43), (0.6, 0.8), (0.95, 0.3)):
+        a = -128.0 / 4013.0
+        for _ in range(8):                                   # raw light whose prepared point has x = -128 (f32 arithmetic of T8:357-363)
+            raw = np.array([[a, ly, lz]], np.float32)
+            _, pt = c_oracle.light_prep(raw, clamp_z_min=0.0)
+            a *= -128.0 / float(pt[0, 0])
+        assert abs(float(pt[0, 0]) + 128.0) < 2e-3, pt
+        lights.append(raw[0])
+    lights = np.stack(lights)
+    B = len(lights)
+    rng = np.random.default_rng(5)
+    r, c = np.mgrid[0:H, 0:W]
+    depth = (8.0 + 3.0 * np.sin(r / 17.0) * np.cos(c / 13.0))[None].repeat(B, 0) + 0.2 * rng.random((B, H, W))
+    depth = depth.astype(np.float32)
+    mask = np.zeros((B, H, W), np.uint8)
+    mask[:, :, :64] = 1                                      # touches column 0, nowhere near column W-1
+    rows = np.arange(H)
+    for b in range(B):                                       # the wall in the wrap partner column (masked out): 1e-4 x wall = 10 +
+        slope = float(lights[b, 2] / lights[b, 1])           # half the height a ray from the bottom row has gained at that row, so
+        depth[b, 2:200, W - 1] = (1e4 * (10.0 + 0.5 * slope * rows[::-1]))[2:200].astype(np.float32)   # that LATE samples win
+    _, pt = light_prep(torch.from_numpy(lights).to(dev), prm)
+    _, pt_o = c_oracle.light_prep(lights, clamp_z_min=0.0)
+    md_o, am_o = c_oracle.shadow_min_distance(depth, mask, pt_o[:, None, :], c_oracle.sample_table(prm.t0, prm.dt, prm.n_samples))
+    assert (am_o[:, 0, :, 0] > 10).mean() > 0.8              # the wall decides: column 0's minima sit late on the rays
+    lit = md_o < 1e5
+    for want_argmin in (False, True):
+        md, am = shadow_min_distance(torch.from_numpy(depth).to(dev), torch.from_numpy(mask).to(dev), pt.reshape(B, 1, 3), prm,
+                                     want_argmin=want_argmin, options=_lib.options(ksplit=0))
+        bad = np.argwhere(md.cpu().numpy() != md_o)
+        assert bad.size == 0, (want_argmin, len(bad), bad[:6])
+        if want_argmin:
+            assert np.array_equal(am.cpu().numpy()[lit], am_o[lit])
+
+
+@pytest.mark.parametrize("edge", ["left", "top", "corner"])
+def test_wrap_partner_of_an_edge_touching_mask_is_covered_by_the_tables(edge):
+    """Advisor r03: a mask that touches column 0 (row 0) but not column W-1 (row H-1), and an extreme masked-out depth in that
+    opposite column (row).  Samples whose rounded cell is in column 0 read column W-1 as their left bilinear corner (index -1
+    wraps, T8:488-491; weight 1e-4 on the image's edge, up to 0.5 beside it): the horizon tables must contain those cells or the
+    trailing loop's cap misses them.  Grid schedule forced, inference and argmin march, against the C oracle, bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import c_oracle
+    from geomconsistentfr_amd import _lib, RenderParams, light_prep, shadow_min_distance
+    dev = torch.device("cuda:0")
+    H = W = 256
+    rng = np.random.default_rng(17)
+    r, c = np.mgrid[0:H, 0:W]
+    lights = np.array([[-0.9, 0.05, 0.3], [-0.6, 0.6, 0.5], [-0.3, -0.8, 0.4], [0.05, 0.9, 0.3], [0.4, 0.8, 0.4], [-0.7, 0.7, 0.1],
+                       [-0.2, 0.3, 0.9], [0.0, 0.95, 0.2], [-0.95, 0.0, 0.2], [-0.5, 0.5, 0.7], [0.3, -0.2, 0.9], [-0.8, 0.5, 0.05]],
+                      np.float32)
+    B = len(lights)
+    # a smooth surface that rises towards the touched edge (rays over it climb slowly: long trailing walks) + ripple
+    base = 60.0 * np.exp(-((c / 90.0) ** 2 if edge != "top" else (r / 90.0) ** 2)) + 2.0 * np.sin(c / 9.0) * np.cos(r / 7.0)
+    depth = (base[None] + 0.3 * rng.random((B, H, W))).astype(np.float32)
+    mask = np.zeros((B, H, W), np.uint8)
+    for b in range(B):
+        if edge in ("left", "corner"):
+            lo = 0 if edge == "corner" else 40 + 5 * b
+            mask[b, lo:lo + 120, 0:60 + 3 * b] = 1            # touches column 0, far from column W-1
+            depth[b, max(lo - 2, 0):lo + 122, W - 1] = (1e6, 3e4, 5e3)[b % 3]   # masked-out spike in the wrap partner column
+        if edge in ("top", "corner"):
+            lo = 0 if edge == "corner" else 30 + 6 * b
+            mask[b, 0:50 + 2 * b, lo:lo + 130] = 1            # touches row 0, far from row H-1
+            depth[b, H - 1, max(lo - 2, 0):lo + 132] = (1e6, 3e4, 5e3)[b % 3]
+        if edge == "corner":
+            depth[b, H - 1, W - 1] = 1e6
+    prm = RenderParams()
+    _, pt = light_prep(torch.from_numpy(lights).to(dev), prm)
+    _, pt_o = c_oracle.light_prep(lights, clamp_z_min=0.0)
+    md_o, am_o = c_oracle.shadow_min_distance(depth, mask, pt_o[:, None, :], c_oracle.sample_table(prm.t0, prm.dt, prm.n_samples))
+    lit = md_o < 1e5
+    assert lit.any()
+    for want_argmin in (False, True):
+        md, am = shadow_min_distance(torch.from_numpy(depth).to(dev), torch.from_numpy(mask).to(dev), pt.reshape(B, 1, 3), prm,
+                                     want_argmin=want_argmin, options=_lib.options(ksplit=0))
+        bad = np.argwhere(md.cpu().numpy() != md_o)
+        assert bad.size == 0, (want_argmin, len(bad), bad[:6])
+        if want_argmin:
+            assert np.array_equal(am.cpu().numpy()[lit], am_o[lit])
+
+
+def test_config5_shape_with_forced_grid_schedule_against_the_c_oracle():
+    """BASELINE configs[4]'s per-GPU shape -- one 512 x 512 face, elliptical mask, 18 lights, 320 samples -- through the grid
+    schedule with trailing loop, horizon tables and octagon pruning (the shape where they gained most, +39 %), against the C
+    oracle: minimum distance and argmin bit for bit."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "oracle"))
+    sys.path.insert(0, root)
+    import c_oracle
+    import bench
+    from geomconsistentfr_amd import _lib, RenderParams, light_prep, shadow_min_distance
+    dev = torch.device("cuda:0")
+    depth, mask, _, _, light, _ = bench.synth_faces_sized(1, 3, 512, 18, "ellipse")
+    prm = RenderParams(n_samples=320, dt=0.8 / 320)
+    _, pt = light_prep(torch.from_numpy(light.reshape(18, 3)).to(dev), prm)
+    _, pt_o = c_oracle.light_prep(light.reshape(18, 3), clamp_z_min=0.0)
+    md_o, am_o = c_oracle.shadow_min_distance(depth, mask, pt_o.reshape(1, 18, 3), c_oracle.sample_table(prm.t0, prm.dt, 320))
+    lit = md_o < 1e5
+    for want_argmin in (False, True):
+        md, am = shadow_min_distance(torch.from_numpy(depth).to(dev), torch.from_numpy(mask).to(dev), pt.reshape(1, 18, 3), prm,
+                                     want_argmin=want_argmin, options=_lib.options(ksplit=0))
+        assert np.array_equal(md.cpu().numpy(), md_o)
+        if want_argmin:
+            assert np.array_equal(am.cpu().numpy()[lit], am_o[lit])

@@ -109,7 +109,7 @@ def main(tag):
     # the instruction counts / traffic below belong to ONE build of the library: bench.py compares this hash with the loaded
     # library's and marks its roofline `stale` when they differ
     try:
-        lib_hash = open(os.path.join(ROOT, "geomconsistentfr_amd", "lib", "libgcfr_hip.srchash")).read().strip()
+        lib_hash = open(os.path.join(ROOT, "geomconsistentfr_amd", "lib", "libgcfr_hip.srchash")).read().split()[0]
     except OSError:
         lib_hash = None
     summary = {"tag": tag, "library_srchash": lib_hash, "n_simd": N_SIMD, "nominal_hz": NOMINAL_HZ, "kernels": {}}
