@@ -40,8 +40,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+T_START = time.perf_counter()   # process start (before torch pages in): the aux legs of the headline line stop adding work after ~170 s
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -370,7 +372,6 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-T_START = time.perf_counter()   # main() resets it: the aux legs of the headline line stop adding work after ~170 s
 FORCED_REGIONS = 0       # --regions N: exactly N timed regions (profiling runs want 1); 0 = the rule below
 
 
@@ -424,7 +425,7 @@ class RenderRig:
     returns the fenced wall time (max over ranks)."""
 
     def __init__(self, rk, B, size=256, lights=1, samples=160, mask="ellipse", depth_noise=0.0, data="synthetic",
-                 streams=4, from_depth=False, want_argmin=False, knobs=None, graph=True, mode="plan"):
+                 streams=4, from_depth=False, want_argmin=False, knobs=None, graph=True, mode="plan", pixels="all"):
         from geomconsistentfr_amd import RenderParams, _lib
         from geomconsistentfr_amd import block as R
         self.rk, self.R, self._lib = rk, R, _lib
@@ -436,7 +437,7 @@ class RenderRig:
         self.n_streams = max(1, streams)
         dev = self.dev = rk.dev
         self.default_shape = size == 256 and lights == 1 and samples == 160
-        self.prm = RenderParams() if self.default_shape else RenderParams(n_samples=samples, dt=0.8 / samples)
+        self.prm = RenderParams(pixels=pixels) if self.default_shape else RenderParams(n_samples=samples, dt=0.8 / samples, pixels=pixels)
         self.cam = (1570.0 * size / 256.0, 1570.0 * size / 256.0, size / 2.0, size / 2.0, 1610.0)
         self.batches = [self._device_batch(j) for j in range(self.n_streams)]
         self.inputs = [self._inputs_of(bt) for bt in self.batches]
@@ -569,12 +570,13 @@ class RenderRig:
         with torch.cuda.stream(self.streams[0]):
             for _ in range(n):
                 e0, e1 = ev.new(), ev.new()
-                opt = self._lib.options(**self.knobs, event_start=e0, event_stop=e1)
+                opt = self._lib.options(**self.knobs, event_start=e0, event_stop=e1, pixels=int(self.prm.pixels == "mask"))
                 pairs.append((e0, e1, opt))
                 if self.use_plans:
+                    keep = self.plans[0].options          # (the plan's own: base knobs + what RenderParams.pixels asked for)
                     self.plans[0].options = opt
                     self.plans[0](*self.inputs[0])
-                    self.plans[0].options = self.base_opt
+                    self.plans[0].options = keep
                 else:
                     self.eager_step(opt)
         torch.cuda.synchronize()
@@ -612,11 +614,19 @@ def run_render(a, rk):
     from_depth = (not a.normals_in) and mode in ("plan", "eager")      # (the direct / unfused A/B forms take normals as input)
     headline = (a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse" and a.depth_noise == 0.0
                 and a.data == "synthetic" and B == FACES_PER_GPU and not knobs and mode == "plan" and from_depth
-                and not a.argmin)
+                and not a.argmin and a.pixels == "all")
     rig = RenderRig(rk, B, a.size, a.lights, a.samples, a.mask, a.depth_noise, a.data, a.streams, from_depth,
-                    a.argmin, knobs, graph=not a.no_graph, mode=mode)
+                    a.argmin, knobs, graph=not a.no_graph, mode=mode, pixels=a.pixels)
     n_streams, world, rank = rig.n_streams, rk.world, rk.rank
     ev = HipEvents()
+    legs = {"setup_s": time.perf_counter() - T_START}           # wall seconds per leg of this run (how the default run spends its minutes)
+    t_leg = time.perf_counter()
+
+    def leg(name):
+        nonlocal t_leg
+        now = time.perf_counter()
+        legs[name] = now - t_leg
+        t_leg = now
     for i in range(a.warmup):
         rig.issue(i, n_streams)
     elapsed, regions, own_elapsed, host_issue = rig.timed_regions(a.steps)
@@ -633,6 +643,7 @@ def run_render(a, rk):
               "ray_steps_per_sec": world * rsps * single_steps / single_elapsed, "regions": single_regions,
               "note": "the same steps one at a time on ONE stream (hipGraph replay): the latency of one batch"}
     layout = rk.describe()                                                    # (a collective: every rank calls it)
+    leg("headline_s")
 
     # secondary workloads, measured in the same run (1 rank only, headline only; short): the data the headline is NOT
     worst = None
@@ -663,6 +674,7 @@ def run_render(a, rk):
                          "(what an untrained network emits: the depth bounds never separate ray and surface), the three "
                          "checkpoint-derived FFHQ fixture faces tiled to the batch (--data ffhq), and the training step's "
                          "march -- batch 32, argmin variant, normals fused, depth of a freshly initialised RelightNet")
+    leg("worst_case_s")
     # the dominant kernel on a launch long enough that its tail does not matter (128 faces, one launch at a time): how busy
     # the VALU issue ports are when the chip is full -- one launch of 8 faces ends with its heaviest tiles, most SIMDs idle
     saturated_ms = None
@@ -678,6 +690,7 @@ def run_render(a, rk):
     # the other single-GPU configurations of BASELINE.json, measured in the same run: the accounting form
     # with normals handed in, configs[4]'s per-GPU shape, and configs[2]'s training step -- short, and never at the headline's
     # expense (each leg is skipped once the run has used its time budget, and a failure is recorded, not raised)
+    leg("saturated_s")
     aux = {}
     if headline and world == 1 and not a.no_worst_case:
         try:
@@ -706,6 +719,7 @@ def run_render(a, rk):
             del r5
         except Exception as e:
             aux["config5"] = {"error": repr(e)}
+        leg("normals_in_config5_s")
         if a.no_train_leg:
             aux["train"] = {"skipped": "--no-train-leg"}
         elif time.perf_counter() - T_START > 170.0:
@@ -716,6 +730,7 @@ def run_render(a, rk):
                 aux["train"] = measure_train(rk, 32, steps=12, warmup=6)
             except Exception as e:
                 aux["train"] = {"error": repr(e)}
+        leg("train_s")
     if rank != 0:
         return None
     algo_bytes = rsps * ALGO_BYTES_PER_RAY_STEP                              # per launch (one rank)
@@ -853,13 +868,16 @@ def run_render(a, rk):
     if world == 1 and not a.no_cpu_baseline and headline:
         out["cpu_baseline"] = cpu_baseline()
         out["cpu_baseline_c_openmp"] = cpu_baseline_c()
+        leg("cpu_baseline_s")
+    legs["total_s"] = time.perf_counter() - T_START
+    out["run_seconds"] = legs
     return out
 
 
 # ------------------------------------------------------------------------------------------------
 # workload "train": BASELINE configs[2] (1 GPU) / configs[3] (8 GPUs, DDP over RCCL)
 # ------------------------------------------------------------------------------------------------
-def measure_train(rk, B, steps, warmup, epoch=200):
+def measure_train(rk, B, steps, warmup, epoch=200, pixels="all"):
     """One rank's measurement of the full training step (BASELINE configs[2]; configs[3] when rk has > 1 rank): `warmup`
     untimed steps (MIOpen's find mode tunes on first use), `steps` timed ones fenced on both sides, then the render block's own
     kernels on this batch measured live: forward (prepass + march with fused normals + shading, argmin variant; library events
@@ -871,7 +889,7 @@ def measure_train(rk, B, steps, warmup, epoch=200):
     from geomconsistentfr_amd.train import TrainConfig, Trainer, synthetic_batch
 
     torch.manual_seed(1234 + rk.rank)
-    tr = Trainer(TrainConfig(), device=dev, distributed=dist is not None)
+    tr = Trainer(TrainConfig(render_pixels=pixels), device=dev, distributed=dist is not None)
     batch = synthetic_batch(B, rk.rank * 1_000_000, device=dev)
     for j in range(max(warmup, 6)):                                          # MIOpen find mode tunes on first use
         tr.step(batch, epoch, j, log=False)
@@ -896,7 +914,7 @@ def measure_train(rk, B, steps, warmup, epoch=200):
     pairs = []
     for _ in range(30):
         e0, e1 = ev.new(), ev.new()
-        plan.options = _lib.options(event_start=e0, event_stop=e1)
+        plan.options = _lib.options(event_start=e0, event_stop=e1, pixels=int(prm.pixels == "mask"))
         pairs.append((e0, e1, plan.options))
         o = plan(*ins)
     torch.cuda.synchronize()
@@ -904,7 +922,7 @@ def measure_train(rk, B, steps, warmup, epoch=200):
     for e0, e1, _ in pairs:
         ev.destroy(e0)
         ev.destroy(e1)
-    plan.options = None
+    plan.options = _lib.options(pixels=1) if prm.pixels == "mask" else None
     L_ = _lib.load()
     g_ren = torch.rand((B, 1, 3, 256, 256), device=dev) * masks[:, None, None].float()  # the losses mask the rendered image
     g_alb, g_depth = torch.empty((B, 3, 256, 256), device=dev), torch.zeros((B, 256, 256), device=dev)
@@ -933,7 +951,7 @@ def measure_train(rk, B, steps, warmup, epoch=200):
     return {"step_ms": step_ms, "faces_per_sec": rk.world * B * steps / elapsed,
             "ray_steps_per_sec": rk.world * B * 256 * 256 * N_SAMPLES * steps / elapsed,
             "march_kernel_ms": march_ms, "bwd_kernel_ms": bwd_ms, "render_block_share_of_step": (march_ms + bwd_ms) / step_ms,
-            "faces_per_gpu": B, "steps": steps, "warmup": max(warmup, 6), "epoch": epoch, "elapsed_s": elapsed,
+            "faces_per_gpu": B, "steps": steps, "warmup": max(warmup, 6), "epoch": epoch, "elapsed_s": elapsed, "render_pixels": pixels,
             "per_rank_s": per_rank_s,
             "workload": "BASELINE configs[%d]: batch=%d per GPU, full training step (RelightNet forward with the fused HIP render "
                         "block, PatchGAN step every 5th iteration, seven losses, backward through the fused HIP backward, two "
@@ -944,7 +962,7 @@ def measure_train(rk, B, steps, warmup, epoch=200):
 def run_train(a, rk):
     rank, world = rk.rank, rk.world
     B = a.faces if a.faces != FACES_PER_GPU else 32                          # configs[2]: batch=32 per GPU
-    m = measure_train(rk, B, a.steps, a.warmup)
+    m = measure_train(rk, B, a.steps, a.warmup, pixels=a.pixels)
     layout = rk.describe()
     if rank != 0:
         return None
@@ -1021,6 +1039,9 @@ def main():
                     help="SURVEY 8d's accounting form instead: normals handed in as a 12 B/pixel input (gcfr_render_fwd; rounds "
                          "1-3's headline step -- the default line carries it as normals_in_*)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the configs[2] training-step leg of the headline line")
+    ap.add_argument("--pixels", choices=["all", "mask"], default="all",
+                    help="mask = RenderParams(pixels='mask') / gcfr_options.pixels = 1: pixels outside the mask are not marched (opt-in "
+                         "deviation, include/gcfr.h; every loss of the training script multiplies them by the mask).  Non-headline.")
     ap.add_argument("--argmin", action="store_true", help="the training-time march (argmin tracked, 5 waves/SIMD)")
     ap.add_argument("--streams", type=int, default=4,
                     help="batches in flight: successive steps go round-robin to this many HIP streams, one RenderFwdPlan (own "
@@ -1045,8 +1066,6 @@ def main():
                     help="A/B: comma list of gcfr_options knobs, e.g. tile_w=32,ksplit=1,depth_bound_skip=0,group=2 "
                          "(never changes a result bit)")
     a = ap.parse_args()
-    global T_START
-    T_START = time.perf_counter()
     if a.steps is None:
         a.steps = 3000 if a.workload == "render" else 20
     if a.warmup is None:

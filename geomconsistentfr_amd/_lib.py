@@ -15,7 +15,7 @@ from . import build as _build
 _LIB = None
 
 GCFR_OK = 0
-ABI_VERSION = 3      # include/gcfr.h GCFR_ABI_VERSION this binding was written against
+ABI_VERSION = 4      # include/gcfr.h GCFR_ABI_VERSION this binding was written against
 _ERRORS = {-1: "GCFR_ERR_INVALID_ARGUMENT", -2: "GCFR_ERR_LAUNCH"}
 
 _p, _i, _f, _d = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_double
@@ -23,25 +23,38 @@ _p, _i, _f, _d = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_doubl
 N_COUNTERS = 16      # GCFR_N_COUNTERS
 COUNTER_NAMES = ("tiles", "groups_nominal", "groups_visited", "bound_tests", "bodies", "lane_samples", "early_exits",
                  "tie_remarches", "samples_in_range", "bounds_given_up", "visits_after_last_body", "visits_before_first_body",
-                 "trail_enter", "trail_skips", "trail_leave")
+                 "trail_enter", "trail_skips", "trail_leave", "rough_samples")
 
 
 class Options(ctypes.Structure):
-    """include/gcfr.h `gcfr_options`: per-call knobs and hooks of the forward entry points (never change a result
-    bit).  Build one with `options(...)`; pass it as `options=` to the block functions / RenderFwdPlan."""
+    """include/gcfr.h `gcfr_options`: per-call knobs and hooks of the forward entry points (none changes a result bit
+    except `pixels`, see the header).  Build one with `options(...)`; pass it as `options=` to the block functions /
+    RenderFwdPlan."""
     _fields_ = [("struct_size", ctypes.c_uint32), ("tile_w", _i), ("group", _i), ("ksplit", _i),
                 ("depth_bound_skip", _i), ("schedule", _i), ("tile_order", _i), ("lds_stage", _i),
-                ("event_start", _p), ("event_stop", _p), ("counters", _p)]
+                ("event_start", _p), ("event_stop", _p), ("counters", _p), ("pixels", _i)]
 
 
 def options(tile_w=0, group=0, ksplit=-1, depth_bound_skip=-1, schedule=-1, tile_order=-1, event_start=None,
-            event_stop=None, counters=None, lds_stage=-1) -> Options:
+            event_stop=None, counters=None, lds_stage=-1, pixels=0) -> Options:
     o = Options()
     load().gcfr_options_default(ctypes.byref(o))
     o.tile_w, o.group, o.ksplit, o.depth_bound_skip = tile_w, group, ksplit, depth_bound_skip
     o.schedule, o.tile_order, o.lds_stage = schedule, tile_order, lds_stage
     o.event_start, o.event_stop, o.counters = event_start, event_stop, counters
+    o.pixels = pixels
     return o
+
+
+def with_pixels(o, pixels: int) -> Options:
+    """a copy of `o` (or the defaults) with `pixels` set -- RenderParams(pixels="mask") reaches the library this way"""
+    n = Options()
+    if o is None:
+        load().gcfr_options_default(ctypes.byref(n))
+    else:
+        ctypes.memmove(ctypes.byref(n), ctypes.byref(o), ctypes.sizeof(Options))
+    n.pixels = pixels
+    return n
 
 
 def opt_ref(o):

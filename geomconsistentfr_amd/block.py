@@ -25,6 +25,11 @@ class RenderParams:
     clamp_light_z_min: Optional[float] = 0.0   # T8:358; None = target light given, no clamp (S1:332)
     inside_bonus: float = 0.0             # S1:495-496 / SLT:503-504 -> 5.0
     bonus_box: Optional[Tuple[float, float, float, float]] = None   # (x_lo, x_hi, y_lo, y_hi)
+    # Which pixels are marched.  "all": every pixel, as the reference (T8:371-515).  "mask" (opt-in, DEVIATES from the
+    # reference's returned tensors): pixels whose own mask cell is zero are not marched and carry the masked value
+    # (minimum distance 1e6 -> shadow weight 1, final = full shading); every consumer of the training script multiplies
+    # them by the mask (T8:619, 633, 641, 643), so the losses are bit-equal -- see gcfr_options.pixels in include/gcfr.h.
+    pixels: str = "all"
 
     @staticmethod
     def training() -> "RenderParams":
@@ -102,6 +107,8 @@ def shadow_min_distance(depth: torch.Tensor, mask: torch.Tensor, light_pt: torch
     Replaces T8:371-515.  use_workspace=False selects the direct-gather kernel (same bits, slower).
     `options`: a `_lib.Options` (kernel / schedule selection and hooks; never changes a result bit)."""
     _require_device(depth, mask, light_pt)
+    if params.pixels != "all" and use_workspace:
+        want_argmin, options = _pixels_options(params, want_argmin, options)
     L_ = _lib.load()
     depth = _f32c(depth)
     B, H, W = depth.shape
@@ -164,6 +171,7 @@ def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParam
     _require_device(depth, mask, light, ambient, albedo)
     if normals is None and camera is None:
         raise _lib.GcfrError("render_fwd needs either normals or camera=(fx, fy, cx, cy, z_offset)")
+    want_argmin, options = _pixels_options(params, want_argmin, options)
     L_ = _lib.load()
     depth = _f32c(depth)
     B, H, W = depth.shape
@@ -213,6 +221,16 @@ def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParam
                 ws_bytes, _stream_ptr(dev), _lib.opt_ref(options)), "gcfr_render_from_depth_fwd")
             out["surface_normals"] = nout
     return out
+
+
+def _pixels_options(params: RenderParams, want_argmin: bool, options):
+    """RenderParams.pixels -> gcfr_options.pixels.  "mask" lives in the library's training (argmin) march, so the argmin
+    plane is requested whether or not the caller wants it."""
+    if params.pixels == "all":
+        return want_argmin, options
+    if params.pixels != "mask":
+        raise _lib.GcfrError("RenderParams.pixels must be 'all' or 'mask', got %r" % (params.pixels,))
+    return True, _lib.with_pixels(options, 1)
 
 
 def _zeros(shape, dtype, device):
@@ -328,6 +346,7 @@ class RenderFwdPlan:
     def __init__(self, B, L, H, W, params: RenderParams = RenderParams(), device="cuda", want_argmin=False,
                  mask_batch=None, camera=None, options=None):
         self.L_ = _lib.load()
+        want_argmin, options = _pixels_options(params, want_argmin, options)
         self.options = options          # _lib.Options or None; kept alive here, read by the library at every call
         dev = torch.device(device)
         if dev.type != "cuda":

@@ -76,6 +76,24 @@ __device__ inline double wave_sum_dpp(double v)
     return v;
 }
 
+// Wave-wide integer minimum (DPP row shifts + row broadcasts, as the march's wave_min_i32), result in every lane via readlane.
+template <int CTRL, int ROW_MASK>
+__device__ inline int bwd_dpp_min_step(int v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, ROW_MASK, 0xf, false);
+    return min(v, moved);
+}
+__device__ inline int bwd_wave_min_i32(int v)
+{
+    v = bwd_dpp_min_step<0x111, 0xf>(v);
+    v = bwd_dpp_min_step<0x112, 0xf>(v);
+    v = bwd_dpp_min_step<0x114, 0xf>(v);
+    v = bwd_dpp_min_step<0x118, 0xf>(v);
+    v = bwd_dpp_min_step<0x142, 0xa>(v);
+    v = bwd_dpp_min_step<0x143, 0xc>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // Block-wide sum of the four per-(image, light) partials {dC.x, dC.y, dC.z, d ambient} -> one f64 atomicAdd each.
 __device__ inline void block_reduce_atomic4(double (&v)[4], double *dst_light3, double *dst_ambient)
 {
@@ -116,6 +134,7 @@ struct ShadowBwdArgs {
 struct CornerScatter {  // the four bilinear-corner depth gradients of one argmin sample, to be added atomically later
     int idx[4];
     float val[4];
+    int fy, fx, gy, gx;  // rows / columns of the corners (fy, fx after the -1 wrap): idx = {fy W + fx, fy W + gx, gy W + fx, gy W + gx}
 };
 __device__ GCFR_BWD_INLINE void shadow_bwd_pixel(const float *zimg, float *gz, const double *t_table, int H, int W,
                                         int r, int c, float Cx, float Cy, float Cz, int k, float g32,
@@ -243,6 +262,10 @@ __device__ GCFR_BWD_INLINE void shadow_bwd_pixel(const float *zimg, float *gz, c
 
     // depth: four bilinear corners + the pixel's own depth
     if (defer) {  // the caller issues them after its last barrier (a barrier waits for every outstanding atomic)
+        defer->fy = fy;
+        defer->fx = fx;
+        defer->gy = gy;
+        defer->gx = gx;
         defer->idx[0] = (int)iUL;
         defer->idx[1] = (int)iUR;
         defer->idx[2] = (int)iLL;
@@ -427,6 +450,10 @@ __device__ unsigned long long *g_bwd_trace = nullptr;
 #define GCFR_BWD1_WAVES_PER_EU 4
 #endif
 constexpr int kBwdTileW = 32, kBwdTileH = 8;  // 256 threads
+#ifndef GCFR_BWD_WINDOW
+#define GCFR_BWD_WINDOW 1
+#endif
+constexpr int kBwdWinW = 64, kBwdWinH = 48;  // the corner window: 64 columns (one lane each at the flush) x 48 rows of f32 = 12 KiB
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(GCFR_BWD1_WAVES_PER_EU, GCFR_BWD1_WAVES_PER_EU))) void render_bwd_single_light_kernel(ShadeBwdArgs a)
 {
@@ -447,6 +474,19 @@ __attribute__((amdgpu_waves_per_eu(GCFR_BWD1_WAVES_PER_EU, GCFR_BWD1_WAVES_PER_E
     __shared__ double s_dd[6][256];
     __shared__ double s_part[4][4];
     double red[4] = {0.0, 0.0, 0.0, 0.0};  // dC.xyz, d ambient: accumulated over this workgroup's tiles
+#if GCFR_BWD_WINDOW
+    // Corner window (round 4).  The four bilinear-corner gradients of a tile's 256 argmin samples are what the memory system
+    // spends this kernel's time on: every atomic REQUEST (one per wave instruction and 64-B line touched) is a read-modify-write
+    // at the memory side.  Neighbouring pixels' samples land on neighbouring -- often the same -- texels (parallel rays, similar
+    // argmin fractions), so a tile's corners usually fall inside a small rectangle of the image: they are first summed there,
+    // in LDS (ds_add_f32), and the rectangle is then flushed row by row, one lane per column -- whole 64-B lines per request,
+    // each texel at most once per tile.  A tile whose corners do not fit the window (scattered argmins: rough depth; the -1
+    // wrap) falls back to the register run-merge + direct atomics below.
+    __shared__ float s_win[kBwdWinH * kBwdWinW];
+    __shared__ int s_box[4][4];
+    for (int i = (int)threadIdx.x; i < kBwdWinH * kBwdWinW; i += 256)
+        s_win[i] = 0.0f;   // (every flush leaves the cells it read at zero again)
+#endif
 
 #ifdef GCFR_BWD_TRACE
     unsigned long long stamp[8] = {};
@@ -577,6 +617,20 @@ __attribute__((amdgpu_waves_per_eu(GCFR_BWD1_WAVES_PER_EU, GCFR_BWD1_WAVES_PER_E
         s_dd[q][threadIdx.x] = via_lds ? sg.ddu[q] : 0.0;
         s_dd[3 + q][threadIdx.x] = via_lds ? sg.ddv[q] : 0.0;
     }
+#if GCFR_BWD_WINDOW
+    {   // this wave's corner box {r_min, c_min, -r_max, -c_max}; lanes without a sample do not count
+        const bool hc = live && have_corners;
+        const int big = 0x3fffffff;
+        const int wr0 = bwd_wave_min_i32(hc ? min(corners.fy, corners.gy) : big), wc0 = bwd_wave_min_i32(hc ? min(corners.fx, corners.gx) : big);
+        const int wr1 = bwd_wave_min_i32(hc ? -max(corners.fy, corners.gy) : big), wc1 = bwd_wave_min_i32(hc ? -max(corners.fx, corners.gx) : big);
+        if ((threadIdx.x & 63) == 0) {
+            s_box[threadIdx.x >> 6][0] = wr0;
+            s_box[threadIdx.x >> 6][1] = wc0;
+            s_box[threadIdx.x >> 6][2] = wr1;
+            s_box[threadIdx.x >> 6][3] = wc1;
+        }
+    }
+#endif
     GCFR_BWD_STAMP(3);
     __syncthreads();
     GCFR_BWD_STAMP(4);
@@ -602,6 +656,38 @@ __attribute__((amdgpu_waves_per_eu(GCFR_BWD1_WAVES_PER_EU, GCFR_BWD1_WAVES_PER_E
         const double ax = ((double)c - a.nrm.cx) * a.nrm.inv_fx, ay = ((double)r - a.nrm.cy) * a.nrm.inv_fy;
         atomicAdd(gz + p, (float)((ax * Sx + ay * Sy + Sz) + gzb));
     }
+#if GCFR_BWD_WINDOW
+    // (wave-uniform: every thread reduces the four waves' boxes itself)
+    const int box_r0 = min(min(s_box[0][0], s_box[1][0]), min(s_box[2][0], s_box[3][0]));
+    const int box_c0 = min(min(s_box[0][1], s_box[1][1]), min(s_box[2][1], s_box[3][1]));
+    const int box_r1 = -min(min(s_box[0][2], s_box[1][2]), min(s_box[2][2], s_box[3][2]));
+    const int box_c1 = -min(min(s_box[0][3], s_box[1][3]), min(s_box[2][3], s_box[3][3]));
+    const bool any_corner = box_r0 <= box_r1;
+    const bool use_window = any_corner && (box_r1 - box_r0 < kBwdWinH) && (box_c1 - box_c0 < kBwdWinW);
+    if (use_window) {
+        if (live && have_corners) {
+            const int o00 = (corners.fy - box_r0) * kBwdWinW + (corners.fx - box_c0), dgy = (corners.gy - corners.fy) * kBwdWinW,
+                      dgx = corners.gx - corners.fx;
+            __hip_atomic_fetch_add(&s_win[o00], corners.val[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&s_win[o00 + dgx], corners.val[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&s_win[o00 + dgy], corners.val[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&s_win[o00 + dgy + dgx], corners.val[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        {   // flush: wave w takes rows w, w + 4, ...; lane = column
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const int nrows = box_r1 - box_r0 + 1, ncols = box_c1 - box_c0 + 1;
+            for (int rw = wave; rw < nrows; rw += 4) {
+                const float v = s_win[rw * kBwdWinW + lane];
+                if (lane < ncols && v != 0.0f) {
+                    s_win[rw * kBwdWinW + lane] = 0.0f;
+                    atomicAdd(gz + (size_t)(box_r0 + rw) * W + (box_c0 + lane), v);
+                }
+            }
+        }
+    } else
+#endif
+    if (true) {
     // The four bilinear-corner atomics of the argmin samples were 78 of this kernel's 167 us: neighbouring pixels march
     // nearly parallel rays, so at sample fraction t their samples are only (1 - t) texels apart and 2 ... 5 adjacent lanes
     // hit the SAME texel -- the L2 serialises those.  Runs of adjacent lanes (inside aligned groups of 8) with identical
@@ -649,6 +735,7 @@ __attribute__((amdgpu_waves_per_eu(GCFR_BWD1_WAVES_PER_EU, GCFR_BWD1_WAVES_PER_E
         }
     }
 
+    }
     if (live) {
         // (Round 3 measured gathering the tile's 84 halo pixels as well -- one atomic per halo pixel instead of up to five
         //  per edge pixel, 0.9 -> 0.33 atomic elements per pixel: 145 -> 138 us on a dense upstream gradient, but 93 -> 96 us

@@ -327,7 +327,7 @@ __device__ inline int lo32(double v)
 // gcfr_options.counters once per tile.  Compiled out of the product build.
 enum { kCntTiles, kCntGroupsNominal, kCntGroupsVisited, kCntBoundTests, kCntBodies, kCntLaneSamples, kCntEarlyExit,
        kCntTieRemarch, kCntSamplesInRange, kCntBoundsGivenUp, kCntVisitsAfterLastBody, kCntVisitsBeforeFirstBody,
-       kCntTrailEnter, kCntTrailSkips, kCntTrailLeave, kCntUsed };
+       kCntTrailEnter, kCntTrailSkips, kCntTrailLeave, kCntRoughSamples, kCntUsed };
 #ifdef GCFR_COUNTERS
 #define GCFR_COUNT(i, n) (cnt[i] += (unsigned)(n))
 #else
@@ -478,13 +478,42 @@ __device__ inline int fresh_lane_id()
     return l;
 }
 
-template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, int SPLIT, bool ALL_ONES = false, bool LDS = false>
-__device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy, const int tx,
+// OWN (gcfr_options.pixels = 1, round 4): pixels whose OWN mask cell is zero are not marched -- their lanes contribute no
+// sample range, never ask for a body, and get the masked value (minimum distance 1e6, argmin -1, hence shadow weight 1);
+// a tile without an unmasked pixel does no march at all.  The one knob that changes results, and only at those pixels:
+// every consumer of the reference multiplies them by the mask (T8:619, 633, 641, 643).  See include/gcfr.h.
+// MODE (round 4): what a tile does when it marches WITHOUT the depth bounds (it gave them up -- see the give-up test --, the
+// caller switched them off, or the sample table is not one they reason about).
+//   kModeInline  the loops below run with `use_zb` false (k-split and LDS-staged kernels);
+//   kModeFull    the tile RETURNS TRUE instead, before anything is marched or written, and the caller runs it again as
+//   kModeRough   the rough loop only: no bounds machinery compiled in at all.
+// The grid kernels hold both as sibling regions (march_grid): the rough loop inside the bounds variant, as a branch behind
+// its prologue, made the register allocator re-plan the main loops -- the bounds record of the group in flight went to
+// scratch in the six-wave kernel, reloaded at every test -- whereas separate instantiations do not interfere.  The price
+// is a second prologue (~5 % of a rough tile's work).
+enum { kModeInline = 0, kModeFull = 1, kModeRough = 2 };
+#ifndef GCFR_ROUGH
+#define GCFR_ROUGH 1
+#endif
+#ifndef GCFR_MAIN_HORIZON
+#define GCFR_MAIN_HORIZON 0
+#endif
+#ifndef GCFR_ROUGH_CHUNK
+#define GCFR_ROUGH_CHUNK 2      // samples in flight per iteration of the rough loop: six-wave inference march
+#endif
+#ifndef GCFR_ROUGH_CHUNK_ARGMIN
+#define GCFR_ROUGH_CHUNK_ARGMIN 3   // ... five-wave training march
+#endif
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, int SPLIT, bool ALL_ONES = false, bool LDS = false,
+          bool OWN = false, int MODE = kModeInline>
+__device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy, const int tx,
                                            const ImageStats &st)
 {
+    static_assert(MODE == kModeInline || (SPLIT == 0 && !LDS), "full / rough pairs: the grid schedule's global-memory kernels");
     constexpr int TILE_H = 64 / TILE_W;
     static_assert(SPLIT == 0 || SPLIT == 1, "SPLIT: 0 = one wave per tile, 1 = the workgroup's four waves split the sample range");
     static_assert(!(LDS && SPLIT != 0), "the LDS-staged march is a throughput variant: one wave per tile");
+    static_assert(!(OWN && (LDS || SPLIT != 0 || ALL_ONES)), "pixels = mask: the grid schedule's global-memory variant only");
     const int H = a->H, W = a->W, L = a->L;
     // Wave-uniform read-only inputs are read through the CONSTANT address space: in the persistent schedule the
     // previous tile's stores and the queue atomic precede these loads in program order, so through a plain global
@@ -496,7 +525,13 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     typedef const __attribute__((address_space(4))) float *ConstF32Ptr;
     typedef const __attribute__((address_space(4))) int *ConstI32Ptr;
     const TablePtr tt = (TablePtr)(unsigned long long)a->t_table;
-    const int lane = threadIdx.x & 63;
+#ifndef GCFR_FRESH_LANE
+#define GCFR_FRESH_LANE 1
+#endif
+    // (a kernel holds two instantiations of this function -- all-ones masks or not -- one after the other: computed from
+    //  threadIdx the pixel's row / column are common subexpressions of both, hoisted in front of the first and kept alive
+    //  across it for the second; a lane id the optimiser cannot see through is re-derived by each)
+    const int lane = (GCFR_FRESH_LANE != 0) ? fresh_lane_id() : (int)(threadIdx.x & 63);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // sample range of this wave
     constexpr bool KSPLIT = SPLIT == 1;
@@ -511,6 +546,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 #endif
     // the trailing loop, see the sample loop (all-ones masks: there is no mask work to save, but its termination test is the sharper one)
     constexpr bool TRAIL = (GCFR_TRAIL != 0) && !KSPLIT && !LDS && (!ALL_ONES || (GCFR_TRAIL_ALL_ONES != 0));
+    constexpr bool ROUGH = MODE == kModeRough;  // the rough loop, see the sample loops
     const int chunk = KSPLIT ? (a->N + 3) >> 2 : a->N;
     const int k_lo = KSPLIT ? wave * chunk : 0;
     const int N = KSPLIT ? min(a->N, k_lo + chunk) : a->N;  // exclusive upper bound ("N" below)
@@ -535,6 +571,10 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     const __amdgpu_buffer_rsrc_t qr = make_rsrc(a->quad + (size_t)b * Pq, (int)(Pq * 16));
     const __amdgpu_buffer_rsrc_t mr =
         make_rsrc(a->mask + (size_t)(a->mask_batch == 1 ? 0 : b) * P, (int)P);
+
+    // OWN: this lane's pixel is outside the mask (or outside the image): not marched.  Carried by `lane_last` = -1 from the
+    // candidate range on (no register of its own): a lane without a candidate sample has only masked samples either way.
+    const bool own_off = OWN && (!valid || (buf_load_u8(mr, __mul24(r, W) + c) == 0));
 
     const ConstF32Ptr lp = (ConstF32Ptr)(unsigned long long)a->light_pt;
     const float Cx = lp[3 * bl + 0], Cy = lp[3 * bl + 1], Cz = lp[3 * bl + 2];
@@ -577,13 +617,15 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     // always right
     const ConstI32Ptr tfl = (ConstI32Ptr)(unsigned long long)a->tflag;  // the prepass' record about the sample table (scalar loads)
     const bool t_increasing = (a->N >= 2) && (tfl[kTfOk] != 0);  // checked by the prepass (see its table check)
-    bool use_zb = (a->zb != nullptr) && t_increasing;
+    bool use_zb = !ROUGH && (a->zb != nullptr) && t_increasing;
+    if (MODE == kModeFull && !use_zb)
+        return true;  // (wave-uniform: facts about the launch) marched by the rough variant
     const int gz_lo_s = st.gz_lo_s, gz_nhi_s = st.gz_nhi_s;  // image depth range {z_min, -z_max} (sortable ints)
-    int lane_last = a->N - 1;  // last sample of this lane that can be unmasked (mask bounding box), see below
+    int lane_last = (OWN && own_off) ? -1 : a->N - 1;  // last sample of this lane that can be unmasked (mask bounding box), see below
     if (t_increasing) {
         const int r_min = st.r_min, c_min = st.c_min, r_max = st.r_max, c_max = st.c_max;
         int lane_lo = a->N, lane_hi = -1;  // empty
-        if (r_min != kBBoxInit) {
+        if (r_min != kBBoxInit && !(OWN && own_off)) {
             const float X0 = (float)c_min - halfWf - 0.51f, X1 = (float)c_max - halfWf + 0.51f;
             const float Y0 = halfHf - (float)r_max - 0.51f, Y1 = halfHf - (float)r_min + 0.51f;
             float ta = -3.0e38f, tb = 3.0e38f;
@@ -653,6 +695,8 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     if (k_begin >= k_end)
         use_zb = false;  // no ray of this tile reaches the mask's box: nothing to march, so no bounds set-up either
     GCFR_COUNT(kCntTiles, 1);
+    if (ROUGH)
+        GCFR_COUNT(kCntBoundsGivenUp, 1);  // (every tile of the rough variant marches without the bounds, whatever the reason)
     GCFR_COUNT(kCntGroupsNominal, (N - k_lo + DEPTH - 1) / DEPTH);
     GCFR_COUNT(kCntSamplesInRange, k_end > k_begin ? k_end - k_begin : 0);
 
@@ -710,6 +754,8 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         const float band = rec[3] - rec[2];  // c_hi - c_lo (wave-uniform address: scalar loads)
         const bool hopeless = !(fabsf(c1) * t_abs >= GCFR_GIVEUP_FACTOR * nrm * band);  // (NaN / inf bands: hopeless)
         if (__builtin_amdgcn_ballot_w64(!hopeless) == 0ull) {
+            if (MODE == kModeFull)
+                return true;  // nothing has been marched or written: the caller runs the rough variant of this tile
             use_zb = false;
             GCFR_COUNT(kCntBoundsGivenUp, 1);
         }
@@ -868,7 +914,27 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
             //  kernel has once the trailing loop is in place; Kerr = +inf where the bound is not valid: gd = -inf)
             float nrm_l = nrm;  // (laundered: or the loop-invariant sub-expression is hoisted back into a register and spilled)
             asm volatile("" : "+v"(nrm_l));
+#if GCFR_MAIN_HORIZON
+            // EXPERIMENT: the per-ray cap of the trailing loop in the main loop's termination test too
+            float cap_l = gz_cap;
+            {
+                const int hz_off = launder(a)->hz_off;
+                if (hz_off >= 0) {
+                    float dxl, dyl;
+                    dir_f32(dxl, dyl);
+                    const int ci = (int)__builtin_floorf(__builtin_fmaf(tn, dxl, x)), ri = (int)__builtin_floorf(-__builtin_fmaf(tn, dyl, y));
+                    constexpr int C = kHorizonDim / 2, M = kHorizonDim - 1;
+                    const int ic = (dxl >= 0.0f) ? kHorizonDim + min(max(ci + (C - 2), 0), M) : min(max(ci + (C + 3), 0), M);
+                    const int ir = (dyl > 0.0f) ? 2 * kHorizonDim + min(max(ri + (C + 3), 0), M) : 3 * kHorizonDim + min(max(ri + (C - 2), 0), M);
+                    const f32x4 zc4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, hz_off + (ic << 4), 0, 0));
+                    const f32x4 zr4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, hz_off + (ir << 4), 0, 0));
+                    cap_l = fminf(fmaxf(fmaxf(zc4.x, zc4.y), fmaxf(zc4.z, zc4.w)), fmaxf(fmaxf(zr4.x, zr4.y), fmaxf(zr4.z, zr4.w)));
+                }
+            }
+            const float gd = __builtin_fmaf(c1, tn, -(__builtin_fmaf(nrm_l, cap_l, -(nrm_l * zb)) + Kerr));
+#else
             const float gd = __builtin_fmaf(c1, tn, -(__builtin_fmaf(nrm_l, gz_cap, -(nrm_l * zb)) + Kerr));
+#endif
             const float bS = bestS;
             const bool finished = ((c1 > 0.0f) && (gd > 0.0f) && (gd * gd * 0.998f > bS) && (bS < safeS)) ||
                                   (lane_last < k0 + DEPTH);
@@ -910,6 +976,31 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     // group's bounds record, tested here if some lane has an unmasked sample; LAZY = true (LDS-staged variant): the
     // caller has tested it already and passes the lane's verdict in `cw_in`.  ta64 / tb64: the group's first / last
     // table value; tn64: the next group's first one.
+    // One sample's arithmetic behind its texel gather: bilinear depth (T8:480-494, f64), point A (T8:497-502), the squared
+    // distance numerator (T8:503-509, f32, torch.cross's fma placement) and the running minimum with its tie predecessor.
+    // Shared by the group bodies and the rough loop, so both evaluate the reference's rounding sequence with the same code.
+    auto eval_sample = [&](int k, bool masked, double uxj, double uyj, double fxj, double fyj, const f32x4 &q) {
+        const double gxd = __builtin_ceil(uxj), gyd = __builtin_ceil(uyj);
+        const double wx0 = gxd - uxj, wx1 = uxj - fxj;
+        const double wy0 = gyd - uyj, wy1 = uyj - fyj;
+        const double zUL = q.x, zUR = q.y, zLL = q.z, zLR = q.w;
+        const double up = zUL * wx0 + zUR * wx1;
+        const double low = zLL * wx0 + zLR * wx1;
+        const double zA = up * wy0 + low * wy1;
+        const float Ax = (float)(uxj - halfW), Ay = (float)(halfH - uyj), Az = (float)zA;
+        const float BAx = Ax - x, BAy = Ay - y, BAz = Az - zb;
+        const float Xx = __builtin_fmaf(BAy, BCz, -(BAz * BCy));
+        const float Xy = __builtin_fmaf(BAz, BCx, -(BAx * BCz));
+        const float Xz = __builtin_fmaf(BAx, BCy, -(BAy * BCx));
+        const float S = ((Xx * Xx + Xy * Xy) + Xz * Xz) + kEps4;
+        const bool take = !masked && (S < bestS);
+        if (WANT_ARGMIN) {
+            prevS = take ? bestS : prevS;
+            prevk = take ? besti : prevk;
+            besti = take ? k : besti;
+        }
+        bestS = take ? S : bestS;
+    };
     bool all_lazy = false;  // (wave-uniform) set by consume(): the group just consumed could have been skipped without its mask
     auto consume = [&](int k0, const uint32_t (&cm)[DEPTH], const f32x4 &cz, double ta64, double tb64, double tn64,
                        bool check_finished, auto lazy, bool cw_in) -> bool {
@@ -921,12 +1012,14 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 #ifdef GCFR_COUNTERS
         ++cnt_since_body;
 #endif
+        const bool dead = OWN && (lane_last < 0);  // (OWN: a lane whose own pixel is outside the mask sees every sample as masked)
         bool none = true;
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
             none = none && (cm[j] == 0);
             any_masked |= (cm[j] == 0);
         }
+        none = none || dead;
         bool run_body = __builtin_amdgcn_ballot_w64(!none) != 0ull;
         if (LAZY) {
             run_body = __builtin_amdgcn_ballot_w64(!none && !cw_in) != 0ull;
@@ -981,30 +1074,8 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
             }
             // phase 2: bilinear depth, point A, squared distance numerator, running minimum
 #pragma unroll
-            for (int j = h0; j < h0 + GCFR_BODY_CHUNK && j < DEPTH; ++j) {
-                const int k = clampk(k0 + j);
-                const bool masked = (cm[j] == 0);
-                const double gxd = __builtin_ceil(ux[j]), gyd = __builtin_ceil(uy[j]);
-                const double wx0 = gxd - ux[j], wx1 = ux[j] - fxd[j];
-                const double wy0 = gyd - uy[j], wy1 = uy[j] - fyd[j];
-                const double zUL = qv[j].x, zUR = qv[j].y, zLL = qv[j].z, zLR = qv[j].w;
-                const double up = zUL * wx0 + zUR * wx1;
-                const double low = zLL * wx0 + zLR * wx1;
-                const double zA = up * wy0 + low * wy1;
-                const float Ax = (float)(ux[j] - halfW), Ay = (float)(halfH - uy[j]), Az = (float)zA;
-                const float BAx = Ax - x, BAy = Ay - y, BAz = Az - zb;
-                const float Xx = __builtin_fmaf(BAy, BCz, -(BAz * BCy));
-                const float Xy = __builtin_fmaf(BAz, BCx, -(BAx * BCz));
-                const float Xz = __builtin_fmaf(BAx, BCy, -(BAy * BCx));
-                const float S = ((Xx * Xx + Xy * Xy) + Xz * Xz) + kEps4;
-                const bool take = !masked && (S < bestS);
-                if (WANT_ARGMIN) {
-                    prevS = take ? bestS : prevS;
-                    prevk = take ? besti : prevk;
-                    besti = take ? k : besti;
-                }
-                bestS = take ? S : bestS;
-            }
+            for (int j = h0; j < h0 + GCFR_BODY_CHUNK && j < DEPTH; ++j)
+                eval_sample(clampk(k0 + j), (cm[j] == 0) || dead, ux[j], uy[j], fxd[j], fyd[j], qv[j]);
           }
         }
         return finish_check(k0, tn64, check_finished);
@@ -1086,6 +1157,50 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
                 break;
             if (!group_lds(k0 + DEPTH, true))
                 break;
+        }
+    } else if (ROUGH) {
+        // Rough loop (round 4).  A tile that marches WITHOUT the depth bounds -- it gave them up (a surface rougher than its
+        // rays rise: an untrained network's depth, 7,259 of 8,192 tiles at noise amplitude 400), the caller switched them off, or
+        // the sample table is not one the bounds reason about -- executes every sample of its candidate range: nothing is
+        // decided a group ahead, so nothing is gathered a group ahead.  Per sample ONE position (the main loop computes it
+        // twice: for the mask prefetch and again in the body), the mask byte and the texel gathered together, CH samples
+        // in flight, no group bookkeeping, no termination test -- the candidate range's end [k_begin, k_end) IS the wave's
+        // last sample that can be unmasked.  Same arithmetic per sample (eval_sample): bit-identical.
+        constexpr int CH = WANT_ARGMIN ? GCFR_ROUGH_CHUNK_ARGMIN : GCFR_ROUGH_CHUNK;
+        double tr[CH];
+        auto load_tr = [&](int kfirst) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                tr[j] = tt[clampk(kfirst + j)];
+        };
+        if (k_begin < k_end)
+            load_tr(k_begin);
+        for (int k0 = k_begin; k0 < k_end; k0 += CH) {
+            GCFR_COUNT(kCntRoughSamples, min(CH, k_end - k0));
+            double ux[CH], uy[CH], fxd[CH], fyd[CH];
+            f32x4 qv[CH];
+            uint32_t mk[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const double tj = tr[j];
+                const double sx = x64 + tj * dx64, sy = y64 + tj * dy64;  // T8:472 / 480 (mul and add rounded separately)
+                int cr, rr;
+                const int moff = mask_offset(sx, sy, cr, rr);
+                mk[j] = ALL_ONES ? 1u : buf_load_u8(mr, moff);
+                ux[j] = (sx + halfW) - 0.0001;  // unrounded position (T8:480-487)
+                uy[j] = (halfH - sy) - 0.0001;
+                fxd[j] = __builtin_floor(ux[j]);
+                fyd[j] = __builtin_floor(uy[j]);
+                const int texel = __mul24((int)fyd[j], Wp) + (int)fxd[j];  // (-1: the quad grid has that row / column)
+                qv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qr, (texel << 4) + quad_origin, 0, 0));
+            }
+            load_tr(k0 + CH);  // the next iteration's table values (scalar loads, answered while this one runs)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const bool masked = (mk[j] == 0) || (OWN && (lane_last < 0));
+                any_masked |= masked;
+                eval_sample(clampk(k0 + j), masked, ux[j], uy[j], fxd[j], fyd[j], qv[j]);
+            }
         }
     } else {
     Prefetched bufA, bufB;
@@ -1219,7 +1334,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         sM[wave][lane] = any_masked ? 1 : 0;
         __syncthreads();
         if (wave != 0)
-            return;
+            return false;
 #pragma unroll
         for (int q = 1; q < 4; ++q) {
             const float Sq = sS[q][lane];
@@ -1274,6 +1389,10 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
     }
     if (!finite_ray)
         d = __builtin_nanf("");
+    if (OWN && (lane_last < 0)) {  // not marched (or a ray that never reaches the mask: the same value either way): the masked value
+        d = kMaskedDistance;
+        besti = -1;
+    }
     const EpiPtr ep = launder((EpiPtr)&a->epi);
     const bool inside = (Cx >= ep->bx_lo) && (Cx <= ep->bx_hi) && (Cy >= ep->by_lo) && (Cy <= ep->by_hi);
     if (inside)
@@ -1289,7 +1408,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
         r = valid_e ? r_e : H - 1;
         c = valid_e ? c_e : W - 1;
         if (!valid_e)
-            return;
+            return false;
     }
     {
         const size_t pix = (size_t)r * W + c;
@@ -1358,6 +1477,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
                  ((unsigned long long)(cnt[kCntBodies] & 0xfff) << 36) | ((unsigned long long)(cnt[kCntGroupsVisited] & 0xfff) << 48);
     }
 #endif
+    return false;
 }
 
 // The __global__ entry points of the march.  Occupancy is forced (the register allocator would settle at
@@ -1377,7 +1497,7 @@ __device__ GCFR_TILE_INLINE void march_tile(ArgPtr a, const int bl, const int qy
 
 // Grid schedule: one workgroup = four horizontally adjacent tiles (one per wave), 3-D grid x = tile-quad column,
 // y = tile row, z = (image, light) -- no integer divisions, dispatch order image-major with row-major tiles.
-template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool LDS = false>
+template <int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool LDS = false, bool OWN = false>
 __device__ __forceinline__ void march_grid(ArgPtr a)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1392,21 +1512,38 @@ __device__ __forceinline__ void march_grid(ArgPtr a)
             __syncthreads();  // (the barrier the marching waves pass in front of their sample loop)
         return;  // (without LDS staging the waves of a workgroup never synchronise)
     }
-    if (st.mask_all_ones != 0)  // wave-uniform (a fact about the mask: valid for any sample table)
-        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, true, LDS>(a, bl, (int)blockIdx.y, tx, st);
+    // (the all-ones test is wave-uniform -- a fact about the mask, valid for any sample table; no pixel is outside such a mask)
+    constexpr int FULL = (LDS || GCFR_ROUGH == 0) ? kModeInline : kModeFull;
+    bool rough;
+    if (st.mask_all_ones != 0)
+        rough = march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, true, LDS, false, FULL>(a, bl, (int)blockIdx.y, tx, st);
     else
-        march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, false, LDS>(a, bl, (int)blockIdx.y, tx, st);
+        rough = march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, false, LDS, OWN, FULL>(a, bl, (int)blockIdx.y, tx, st);
+    if (FULL == kModeFull && __builtin_amdgcn_readfirstlane((int)rough) != 0) {  // the tile marches without the depth bounds
+        // (the image statistics are reduced AGAIN, through a laundered pointer -- a dozen scalar loads: kept alive across the
+        //  bounds variant for this call they were eleven more SGPRs than the kernel has, spilled into a VGPR's lanes for the
+        //  whole kernel: one register less in the main loops and a v_readlane at every use, -1.2 % on the bench faces)
+        //  (the five-wave training kernels have the SGPRs to spare in VGPR lanes, and re-plan worse with the second reduction:
+        //   20-44 B of scratch; they pass the statistics on)
+        const ArgPtr a2 = WANT_ARGMIN ? a : launder(a);
+        const int bl2 = WANT_ARGMIN ? bl : a2->bl_offset + (int)blockIdx.z;
+        const ImageStats st2 = WANT_ARGMIN ? st : reduce_image_stats(a2, bl2 / a2->L, threadIdx.x & 63, false);
+        if (st2.mask_all_ones != 0)
+            march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, true, false, false, kModeRough>(a2, bl2, (int)blockIdx.y, tx, st2);
+        else
+            march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, false, false, OWN, kModeRough>(a2, bl2, (int)blockIdx.y, tx, st2);
+    }
 }
 
 // (SCHED is the schedule the kernel was built for; the product has the grid only -- the parameter keeps the kernel
 //  names of rounds 1-2 in profiles and tools: shadow_fwd_quad_kernel<16, true, 4, true, 0>.)
 enum { kSchedGrid = 0 };
 
-template <int SCHED, int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool LDS = false>
+template <int SCHED, int TILE_W, bool EVEN_HALF, bool WANT_ARGMIN, int DEPTH, bool FUSE_SHADE, bool LDS = false, bool OWN = false>
 __device__ __forceinline__ void march_dispatch()
 {
     static_assert(SCHED == kSchedGrid, "the product library has the grid schedule only");
-    march_grid<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, LDS>(kernel_args());
+    march_grid<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, LDS, OWN>(kernel_args());
 }
 
 template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE, int SCHED>
@@ -1420,6 +1557,13 @@ __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(GCFR_MARCH_ARGMIN_WAVES_PER_EU, GCFR_MARCH_ARGMIN_WAVES_PER_EU))) void shadow_fwd_quad_argmin_kernel(ShadowQuadArgs)
 {
     march_dispatch<SCHED, TILE_W, EVEN_HALF, true, DEPTH, FUSE_SHADE>();
+}
+// pixels = mask (gcfr_options.pixels = 1): the training march that leaves out the pixels outside the mask (OWN, see march_tile)
+template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE, int SCHED>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(GCFR_MARCH_ARGMIN_WAVES_PER_EU, GCFR_MARCH_ARGMIN_WAVES_PER_EU))) void shadow_fwd_quad_argmin_own_kernel(ShadowQuadArgs)
+{
+    march_dispatch<SCHED, TILE_W, EVEN_HALF, true, DEPTH, FUSE_SHADE, false, true>();
 }
 // LDS-staged variants (see group_lds in march_tile): the same kernels with the image's mask bitmap and bounds records in LDS
 template <int TILE_W, bool EVEN_HALF, int DEPTH, bool FUSE_SHADE, int SCHED>
@@ -1449,7 +1593,7 @@ __global__ __launch_bounds__(256) void shadow_fwd_quad_ksplit_kernel(ShadowQuadA
 // ----------------------------------------------------------------------------------------------
 // launchers: pick the kernel for (parity of W/2 and H/2, argmin wanted, schedule) and enqueue it
 // ----------------------------------------------------------------------------------------------
-enum Schedule { kGrid = kSchedGrid, kKSplit, kGridLds };
+enum Schedule { kGrid = kSchedGrid, kKSplit, kGridLds, kGridOwn };
 
 template <int TILE_W, int DEPTH, bool FUSE>
 static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argmin, Schedule sch, dim3 grid,
@@ -1497,6 +1641,11 @@ static void launch_quad4(const ShadowQuadArgs &a, bool even_half, bool want_argm
                     GCFR_LAUNCH_LDS(shadow_fwd_quad_lds_kernel, false, DEPTH, FUSE, kSchedGrid);
             }
         }
+    } else if (sch == kGridOwn) {  // (argmin wanted: checked by the caller)
+        if (even_half)
+            GCFR_LAUNCH(shadow_fwd_quad_argmin_own_kernel, true, DEPTH, FUSE, kSchedGrid);
+        else
+            GCFR_LAUNCH(shadow_fwd_quad_argmin_own_kernel, false, DEPTH, FUSE, kSchedGrid);
     } else {
         GCFR_LAUNCH_SCHED(kSchedGrid);
     }

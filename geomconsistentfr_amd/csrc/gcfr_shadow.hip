@@ -691,9 +691,9 @@ static inline int launch_status()
 extern "C" const char *gcfr_version(void)
 {
 #if defined(GCFR_COUNTERS)
-    return "gcfr-hip 0.3.0 gfx950 +counters";
+    return "gcfr-hip 0.4.0 gfx950 +counters";
 #else
-    return "gcfr-hip 0.3.0 gfx950";
+    return "gcfr-hip 0.4.0 gfx950";
 #endif
 }
 
@@ -733,6 +733,7 @@ struct Knobs {
     int ksplit = -1;     // sample-range split over the 4 waves of a workgroup: 0 off, 1 on, -1 auto
     int zbound = 1;      // depth-bound group skip (exact): 1 on, 0 off
     int lds_stage = -1;  // mask bitmap + bounds records of the workgroup's image in LDS: 0 off, 1 on (where the shape allows), -1 auto
+    int pixels = 0;      // 1: pixels outside the mask are not marched (gcfr_options.pixels; the one knob that changes results)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     unsigned long long *counters = nullptr;
 };
@@ -747,13 +748,14 @@ static int resolve_options(const gcfr_options *opt, Knobs &k)
     if ((tw != 0 && tw != 8 && tw != 16 && tw != 32 && tw != 64) || (g != 0 && g != 1 && g != 2 && g != 4) ||
         opt->ksplit < -1 || opt->ksplit > 1 || opt->depth_bound_skip < -1 || opt->depth_bound_skip > 1 ||
         opt->schedule < -1 || opt->schedule > 0 || opt->tile_order < -1 || opt->tile_order > 0 || opt->lds_stage < -1 ||
-        opt->lds_stage > 1)
+        opt->lds_stage > 1 || opt->pixels < -1 || opt->pixels > 1)
         return GCFR_ERR_INVALID_ARGUMENT;  // (schedule / tile_order: the grid is the only schedule; the fields keep the struct layout)
     k.tile_w = tw;
     k.group = g ? g : 4;
     k.ksplit = opt->ksplit;
     k.zbound = opt->depth_bound_skip < 0 ? 1 : opt->depth_bound_skip;
     k.lds_stage = opt->lds_stage;
+    k.pixels = opt->pixels == 1 ? 1 : 0;
     k.ev_start = (hipEvent_t)opt->event_start;
     k.ev_stop = (hipEvent_t)opt->event_stop;
     k.counters = (unsigned long long *)opt->counters;
@@ -849,6 +851,8 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
     Knobs kn;
     if (resolve_options(opt, kn) != GCFR_OK)
         return GCFR_ERR_INVALID_ARGUMENT;
+    if (kn.pixels == 1 && (!workspace || !argmin))
+        return GCFR_ERR_INVALID_ARGUMENT;  // pixels = mask lives in the workspace path's training (argmin) march
 
     // auto tile shape (measured): with the depth-bound skip compact tiles win (the lanes of a wave
     // agree more often).  16x4 everywhere: on the smooth bench faces it ties with 8x8 at 256 px (1690 vs 1688 G
@@ -891,21 +895,22 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
         // without a running minimum, so it loses from B = 4 up).  Otherwise the grid: one wave per tile -- with the
         // image's mask bitmap and bounds records staged in LDS where they fit beside five other workgroups of the CU
         // (26 KiB at 256 x 256; not at 512 x 512) and the rows are whole bitmap dwords.
-        const bool ksplit = (kn.ksplit < 0) ? (tiles_total <= 2048 && N >= 16) : (kn.ksplit == 1);
+        const bool own = kn.pixels == 1;  // pixels = mask: the grid schedule's own kernel
+        const bool ksplit = !own && ((kn.ksplit < 0) ? (tiles_total <= 2048 && N >= 16) : (kn.ksplit == 1));
         const unsigned lds_bytes = (unsigned)bitmap_stride_bytes(H, W) + (use_zb ? (unsigned)zb_stride(H, W) * 16u : 0u);
         const bool lds_fits = ((W & 31) == 0) && (((uintptr_t)mask_u8 & 15u) == 0) && lds_bytes <= 26u * 1024u &&
                               TILE_W == 16 && kn.group == 4;
 #ifndef GCFR_LDS_STAGE_AUTO
 #define GCFR_LDS_STAGE_AUTO 0
 #endif
-        const bool lds_stage = !ksplit && lds_fits && (kn.lds_stage < 0 ? (GCFR_LDS_STAGE_AUTO != 0) : (kn.lds_stage == 1));
-        const Schedule sch = ksplit ? kKSplit : (lds_stage ? kGridLds : kGrid);
+        const bool lds_stage = !own && !ksplit && lds_fits && (kn.lds_stage < 0 ? (GCFR_LDS_STAGE_AUTO != 0) : (kn.lds_stage == 1));
+        const Schedule sch = own ? kGridOwn : (ksplit ? kKSplit : (lds_stage ? kGridLds : kGrid));
         const int quad_blocks = (texels + 256 * GCFR_QUAD_PER_THREAD - 1) / (256 * GCFR_QUAD_PER_THREAD);
         const int zb_blocks = use_zb ? (zb_max_tiles(H, W) + 4 * kZbTilesPerWave - 1) / (4 * kZbTilesPerWave) : 0;  // sized for the finest stride
         const int bitmap_blocks = lds_stage ? ((H * W) / 32 + 255) / 256 : 0;
         // horizon tables: for the trailing loop of the grid schedule's bounds-skipping march (not the k-split's quarter
         // ranges, not the LDS-staged variant), where the shape and the planes' alignment allow vector loads
-        const bool horizon = (GCFR_HORIZON != 0) && use_zb && sch == kGrid && hz_shape_ok(H, W) && (((uintptr_t)depth & 15u) == 0) &&
+        const bool horizon = (GCFR_HORIZON != 0) && use_zb && (sch == kGrid || sch == kGridOwn) && hz_shape_ok(H, W) && (((uintptr_t)depth & 15u) == 0) &&
                              (((uintptr_t)mask_u8 & 3u) == 0);
         const int hz_blocks = horizon ? kHorizonBands : 0;
         const int vec_ok = ((W & 15) == 0) && (((uintptr_t)depth & 15u) == 0) && (((uintptr_t)mask_u8 & 15u) == 0);

@@ -152,6 +152,8 @@ class TrainConfig:
     shortcut: str = "3x3"
     bucket_cap_mb: int = 32     # one flat bucket per model (see module docstring)
     miopen_find: bool = True    # torch.backends.cudnn.benchmark: MIOpen picks the fastest conv algorithm (+9 % step rate)
+    render_pixels: str = "all"  # "mask": the render block leaves out the pixels outside the mask (RenderParams.pixels; every loss
+                                # multiplies them by the mask, T8:619-643: bit-equal losses, half the training march)
 
 
 LAST_GATED_EPOCH = 14      # T8:245, 258, 271, 283: the decoders' skip additions switch on after epochs 8 / 10 / 12 / 14
@@ -184,6 +186,9 @@ class Trainer:
         if cfg.miopen_find and self.device.type == "cuda":
             torch.backends.cudnn.benchmark = True
         self.model = (model or RelightNet(cfg.shortcut)).float().to(self.device)
+        if cfg.render_pixels != "all":
+            import dataclasses
+            self.model.render_params = dataclasses.replace(self.model.render_params, pixels=cfg.render_pixels)
         self.patchgan = (patchgan or PatchGAN()).float().to(self.device)
         self.net, self.disc = self.model, self.patchgan
         self.distributed, self._net_find_unused = distributed, None

@@ -45,14 +45,15 @@ const char *gcfr_version(void);
  * compares gcfr_abi_version() of the library it loaded with the GCFR_ABI_VERSION it was written against and refuses
  * to proceed on a mismatch (geomconsistentfr_amd/_lib.py does).
  *   3: round 3 -- gcfr_inference_images_u8 gained `mask_f32`; gcfr_abi_version itself; the metrics entry points.
+ *   4: round 4 -- gcfr_options gained `pixels`.
  */
-#define GCFR_ABI_VERSION 3
+#define GCFR_ABI_VERSION 4
 int32_t gcfr_abi_version(void);
 
 /*
  * Per-call options of the forward entry points (HOST struct, read during the call only; NULL = defaults).
- * Nothing here changes a result bit: the knobs select among kernels / schedules that are bit-identical
- * (tests/test_gpu_parity.py asserts it for every combination), the hooks only observe.
+ * With ONE exception (`pixels`, off by default) nothing here changes a result bit: the knobs select among kernels /
+ * schedules that are bit-identical (tests/test_gpu_parity.py asserts it for every combination), the hooks only observe.
  */
 #define GCFR_N_COUNTERS 16
 typedef struct gcfr_options {
@@ -78,6 +79,22 @@ typedef struct gcfr_options {
                                   GCFR_N_COUNTERS and writes a 4-word timeline record per tile behind them
                                   (tools/trace_timeline.py); only a library built with -DGCFR_COUNTERS touches it
                                   (gcfr_version() then ends in "+counters"), else ignored */
+    int32_t pixels;            /* WHICH PIXELS are marched.  0 (default; also -1): every pixel, as the reference does
+                                  (T8:371-515 computes minimum_distance for all H x W pixels).
+                                  1 ("mask"; DEVIATES from the reference's returned tensors, opt-in): pixels whose OWN mask cell
+                                  is zero are not marched -- they get the masked value the reference assigns to a ray without
+                                  an unmasked sample (minimum_distance 1e6, T8:512; argmin -1), hence shadow_mask_weights 1,
+                                  final_shading = full_shading, rendered_images = albedo x full_shading there -- and a tile
+                                  without an unmasked pixel does no march at all.  Every other pixel is bit-identical to
+                                  pixels = 0.  Why it is safe for the training script: each consumer of the block's outputs
+                                  multiplies them by that same mask (T8:619, 633, 641, 643: `rendered_images * masks` in the
+                                  reconstruction, adversarial and DSSIM terms), so the losses are bit-equal and the masked-out
+                                  pixels receive a zero upstream gradient either way; `shadow_mask_weights` / `full_shading` /
+                                  `ambient_light` are returned by T8:524 but used by no loss.  Not for callers that
+                                  look at the shadow OUTSIDE the mask (the inference scripts write the un-masked shadow image
+                                  only after multiplying by the mask as well, S8:603-608).  Honoured by the workspace path when
+                                  `argmin` is requested (the training forward; halves its march on face-shaped masks);
+                                  GCFR_ERR_INVALID_ARGUMENT without a workspace or without `argmin`. */
 } gcfr_options;
 
 /* Fills `opt` with the defaults (struct_size set, every knob "auto", no hooks). */

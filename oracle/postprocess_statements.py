@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE -- numpy statements of what the reference's inference / evaluation scripts do with the render
 block's outputs.  Only tests/ may import this module; the product's device kernels
-(csrc/gcfr_postprocess.hip, csrc/gcfr_metrics.hip) are CHECKED against it, never routed through it.
+(csrc/gcfr_postprocess.hip, csrc/gcfr_dataset.hip) are CHECKED against it, never routed through it.
 
 Pinned to the reference itself: oracle/make_golden_slt_main.py runs the unmodified main() of
 test_relight_single_image_lighting_transfer.py (SLT:516-579) and stores the relighting pass's model outputs next to the

@@ -62,8 +62,9 @@ def test_options_struct_defaults_and_layout():
     L = _lib.load()
     o = _lib.Options()
     L.gcfr_options_default(ctypes.byref(o))
-    assert o.struct_size == ctypes.sizeof(_lib.Options) == 56
+    assert o.struct_size == ctypes.sizeof(_lib.Options) == 64
     assert (o.tile_w, o.group, o.ksplit, o.depth_bound_skip, o.schedule, o.tile_order, o.lds_stage) == (0, 0, -1, -1, -1, -1, -1)
+    assert o.pixels == 0                 # the one result-changing knob is off unless asked for
     assert not o.event_start and not o.event_stop and not o.counters
     # argument validation happens on the host before any launch, so it can be exercised without a GPU: dummy non-null
     # pointers, a valid shape, then a bad options struct
@@ -78,6 +79,9 @@ def test_options_struct_defaults_and_layout():
     assert L.gcfr_shadow_fwd(*args, ctypes.byref(bad)) == -1
     assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(schedule=2))) == -1      # the grid is the only schedule
     assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(tile_order=2))) == -1
+    assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(pixels=2))) == -1
+    # pixels = mask lives in the workspace path's argmin march: refused (not ignored) without a workspace or without argmin
+    assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(pixels=1))) == -1
 
 
 def test_product_has_no_cpu_fallback():

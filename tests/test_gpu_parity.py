@@ -564,3 +564,31 @@ def test_non_finite_inputs_never_make_the_skipping_kernels_differ_from_the_plain
         assert np.array_equal(a[ok], b[ok]), (zb, lds)
         assert np.array_equal(am.cpu().numpy()[ok], ref_am.cpu().numpy()[ok]), (zb, lds)
     assert np.isnan(ref_md.cpu().numpy()[3]).all() and np.isfinite(ref_md.cpu().numpy()[0]).all()
+
+
+@pytest.mark.parametrize("knobs", [dict(ksplit=0), dict(ksplit=0, depth_bound_skip=0), dict(ksplit=0, tile_w=8, group=2),
+                                   dict(ksplit=0, tile_w=32, depth_bound_skip=0)])
+def test_rough_depth_marches_bit_identically_through_the_rough_loop(knobs):
+    """Round 4: tiles that march without the depth bounds -- they gave them up (depth rougher than the rays rise: noise of
+    amplitude 400, an untrained network's output), or the caller switched the bounds off -- run the rough loop (one position per
+    sample, mask byte and texel gathered together, no group bookkeeping).  Against the C oracle, both marches, bit for bit;
+    image 2 is smooth on its left half and rough on its right (both variants in one launch), image 3 has an all-ones mask."""
+    import c_oracle
+    from geomconsistentfr_amd import _lib, RenderParams, shadow_min_distance, light_prep
+    depth, mask, lights = _full_size_inputs(4)
+    rng = np.random.default_rng(9)
+    noise = (400.0 * rng.random(depth.shape)).astype(np.float32)
+    noise[2, :, :128] = 0.0
+    depth = depth + noise
+    mask[3] = 1
+    prm = RenderParams()
+    _, pt = light_prep(to_dev(lights), prm)
+    _, pt_o = c_oracle.light_prep(lights, clamp_z_min=0.0)
+    md_o, am_o = c_oracle.shadow_min_distance(depth, mask, pt_o[:, None, :], c_oracle.sample_table(prm.t0, prm.dt, prm.n_samples))
+    lit = md_o < 1e5
+    for want_argmin in (False, True):
+        md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt.reshape(4, 1, 3), prm, want_argmin=want_argmin,
+                                     options=_lib.options(**knobs))
+        np.testing.assert_array_equal(md.cpu().numpy(), md_o)
+        if want_argmin:
+            np.testing.assert_array_equal(am.cpu().numpy()[lit], am_o[lit])

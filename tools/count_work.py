@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--depth-noise", type=float, default=0.0)
     ap.add_argument("--argmin", action="store_true", help="the training-time (argmin) kernel variant")
     ap.add_argument("--tune", type=str, default="")
+    ap.add_argument("--normals-in", action="store_true", help="normals as an input (rounds 1-3's step) instead of from depth")
     ap.add_argument("--out", type=str, default="")
     a = ap.parse_args()
     L_ = _lib.load()
@@ -66,8 +67,9 @@ def main():
     counters = torch.zeros(_lib.N_COUNTERS + 4 * n_tiles, dtype=torch.int64, device=dev)   # tallies + per-tile records
     knobs = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)}
     opt = _lib.options(**knobs, counters=counters.data_ptr())
-    R.render_fwd(t(depth), t(mask), t(light).reshape(B, L, 3), t(amb).reshape(B, L), t(normals), t(albedo), prm,
-                 want_argmin=a.argmin, options=opt)
+    cam = (1570.0 * S / 256.0, 1570.0 * S / 256.0, S / 2.0, S / 2.0, 1610.0)
+    R.render_fwd(t(depth), t(mask), t(light).reshape(B, L, 3), t(amb).reshape(B, L), t(normals) if a.normals_in else None, t(albedo), prm,
+                 want_argmin=a.argmin, camera=None if a.normals_in else cam, options=opt)
     torch.cuda.synchronize()
     c = dict(zip(_lib.COUNTER_NAMES, counters[:_lib.N_COUNTERS].cpu().tolist()))
     group = knobs.get("group", 0) or 4
@@ -75,8 +77,9 @@ def main():
     out = {"library": ver, "workload": {"faces": B, "size": S, "lights": L, "samples": N, "mask": a.mask,
                                         "depth_noise": a.depth_noise, "argmin": a.argmin, "knobs": knobs},
            "counters": c, "nominal_ray_steps": nominal,
-           "executed_ray_steps_wave_level": c["bodies"] * group * 64,
-           "executed_fraction_of_nominal": c["bodies"] * group * 64 / nominal,
+           # (tiles in the tile function's rough variant count their samples one by one: rough_samples, wave level)
+           "executed_ray_steps_wave_level": (c["bodies"] * group + c.get("rough_samples", 0)) * 64,
+           "executed_fraction_of_nominal": (c["bodies"] * group + c.get("rough_samples", 0)) * 64 / nominal,
            "useful_lane_samples": c["lane_samples"],
            "lane_utilisation_of_executed_bodies": c["lane_samples"] / max(c["bodies"] * group * 64, 1),
            "groups_visited_per_tile": c["groups_visited"] / max(c["tiles"], 1),

@@ -20,7 +20,7 @@ from geomconsistentfr_amd import RenderParams, light_prep, shadow_min_distance  
 
 def random_case(rng, H, W):
     r, c = np.mgrid[0:H, 0:W]
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 6)
     depth = (0.3 * H * np.exp(-(((c - rng.uniform(0.3, 0.7) * W) / (0.25 * W)) ** 2
                                 + ((r - rng.uniform(0.3, 0.7) * H) / (0.3 * H)) ** 2))).astype(np.float32)
     if kind == 0:
@@ -29,6 +29,10 @@ def random_case(rng, H, W):
         depth += (3 * np.sin(c / rng.uniform(3, 9)) * np.cos(r / rng.uniform(3, 9))).astype(np.float32)
     elif kind == 2:
         depth = np.round(depth)                       # plateaus -> exact ties between samples
+    elif kind == 4:                                   # rough: rougher than the rays rise -- the tiles give the depth bounds up
+        depth += (rng.uniform(20.0, 400.0) * rng.random((H, W))).astype(np.float32)      # (round 4: the rough loop)
+    elif kind == 5:                                   # half smooth, half rough: both variants of a kernel in one launch
+        depth += (rng.uniform(50.0, 400.0) * rng.random((H, W)) * (c > rng.uniform(0.3, 0.7) * W)).astype(np.float32)
     shift = rng.integers(0, 6)                        # depth sign / offset variants (exercise the depth-bound skip)
     if shift == 1:
         depth = -depth
@@ -55,7 +59,7 @@ def random_case(rng, H, W):
     return depth, mask.astype(np.uint8), l.astype(np.float32)
 
 
-def run_soak(n_cases, seed=0, options=None, sizes=None, want_argmin=True):
+def run_soak(n_cases, seed=0, options=None, sizes=None, want_argmin=True, pixels_mask=False):
     """`n_cases` random (depth, mask, light) cases in batches of 8: HIP workspace kernel vs the C oracle.
     Returns the tallies (pixels compared, lit/masked disagreements, worst min-distance error, argmin differences)."""
     rng = np.random.default_rng(seed)
@@ -82,9 +86,14 @@ def run_soak(n_cases, seed=0, options=None, sizes=None, want_argmin=True):
                                      pt.reshape(B, 1, 3), prm, options=options, want_argmin=want_argmin)
         _, pt_o = c_oracle.light_prep(lights, clamp_z_min=0.0, light_distance=ld)
         md_o, am_o = c_oracle.shadow_min_distance(depth, mask, pt_o[:, None, :], c_oracle.sample_table(0.025, 0.8 / N, N))
+        if pixels_mask:    # gcfr_options.pixels = 1: a pixel whose own mask cell is zero carries the masked value, every other pixel the oracle's
+            md_o[:, 0][mask == 0] = 1e6
+            am_o[:, 0][mask == 0] = -1
         md, am = md.cpu().numpy(), (am.cpu().numpy() if am is not None else am_o)   # (kernels without argmin: distances only)
         lit_o, lit = md_o < 1e5, md < 1e5
         n_lit_mismatch += int((lit_o != lit).sum())
+        if pixels_mask:
+            n_lit_mismatch += int((md[~lit] != md_o[~lit]).sum()) + (int((am[~lit] != -1).sum()) if want_argmin else 0)
         both = lit & lit_o
         err = np.abs(md[both] - md_o[both])
         if err.size:
@@ -107,7 +116,8 @@ def main():
     a = ap.parse_args()
     from geomconsistentfr_amd import _lib
     knobs = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)}
-    r = run_soak(a.cases, a.seed, _lib.options(**knobs) if knobs else None, want_argmin=not a.no_argmin)
+    r = run_soak(a.cases, a.seed, _lib.options(**knobs) if knobs else None, want_argmin=not a.no_argmin,
+                 pixels_mask=knobs.get("pixels", 0) == 1)
     r.update(library=_lib.load().gcfr_version().decode(), knobs=knobs, argmin_kernel=not a.no_argmin)
     print(json.dumps(r))
 
