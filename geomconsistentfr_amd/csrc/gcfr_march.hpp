@@ -495,9 +495,6 @@ enum { kModeInline = 0, kModeFull = 1, kModeRough = 2 };
 #ifndef GCFR_ROUGH
 #define GCFR_ROUGH 1
 #endif
-#ifndef GCFR_MAIN_HORIZON
-#define GCFR_MAIN_HORIZON 0
-#endif
 #ifndef GCFR_ROUGH_CHUNK
 #define GCFR_ROUGH_CHUNK 2      // samples in flight per iteration of the rough loop: six-wave inference march
 #endif
@@ -597,6 +594,41 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
     const double Mx = EVEN_HALF ? kRintMagic + halfW : kRintMagic;
     const double My = EVEN_HALF ? kRintMagic + halfH : kRintMagic;
     const int quad_origin = (Wp + 1) << 4;  // byte offset of texel (r=0, c=0)
+    const ConstI32Ptr tfl = (ConstI32Ptr)(unsigned long long)a->tflag;  // the prepass' record about the sample table (scalar loads)
+    const bool t_increasing = (a->N >= 2) && (tfl[kTfOk] != 0);  // checked by the prepass (see its table check)
+    bool use_zb = !ROUGH && (a->zb != nullptr) && t_increasing;
+    if (MODE == kModeFull && !use_zb)
+        return true;  // (wave-uniform: facts about the launch) marched by the rough variant
+    const int zrec = tfl[kTfStride];
+    const int zls = use_zb ? (zrec & 0xff) : 3;
+    const int zntw = (W >> zls) + 1;
+    const float nrm = __builtin_sqrtf(BCx * BCx + BCy * BCy);
+    const float c1 = BCz * ((dxf * BCx + dyf * BCy) / nrm);
+    // (round 4: the give-up test sits in FRONT of the candidate-range computation -- a tile that hands itself to the rough
+    //  variant has then paid for the end point and this test only, not for the box / octagon clipping it would do twice)
+    const float t_abs = __builtin_bit_cast(float, tfl[kTfTabs]);  // max(|tt[0]|, |tt[N-1]|)
+    // Give-up test (a heuristic about WORK, never about results: without the bounds every group is marched).  A group
+    // can only be skipped while the ray's height over the pixel, c1 t / n, exceeds what the surface band leaves open,
+    // about half its width; on a surface rougher than the rays rise (an untrained network's depth) no test can ever
+    // succeed and the tests, the bounds gathers and the termination checks are pure cost (round 1: -24 % against the
+    // kernel without them at noise amplitude 400).  The band of the tile under the wave's own pixels stands for the
+    // roughness of its neighbourhood: if for every lane the whole ray rises less than GCFR_GIVEUP_FACTOR band widths,
+    // the wave marches this tile without the bounds machinery.
+#ifndef GCFR_GIVEUP_FACTOR
+#define GCFR_GIVEUP_FACTOR 0.5f
+#endif
+    if (use_zb) {
+        const int own = __mul24((qy * TILE_H) >> zls, zntw) + ((tx * TILE_W) >> zls);
+        const ConstF32Ptr rec = (ConstF32Ptr)(unsigned long long)a->zb + 4 * ((size_t)b * zb_slot(H, W) + own);
+        const float band = rec[3] - rec[2];  // c_hi - c_lo (wave-uniform address: scalar loads)
+        const bool hopeless = !(fabsf(c1) * t_abs >= GCFR_GIVEUP_FACTOR * nrm * band);  // (NaN / inf bands: hopeless)
+        if (__builtin_amdgcn_ballot_w64(!hopeless) == 0ull) {
+            if (MODE == kModeFull)
+                return true;  // nothing has been marched or written: the caller runs the rough variant of this tile
+            use_zb = false;
+            GCFR_COUNT(kCntBoundsGivenUp, 1);
+        }
+    }
 
     float bestS = __builtin_inff();
     int besti = -1;
@@ -615,11 +647,6 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
     // the pruning / skipping machinery below reasons about an increasing, uniform sample table inside [0, 1]
     // (gcfr_sample_table with dt > 0, the reference's np.arange); anything else marches every sample, which is
     // always right
-    const ConstI32Ptr tfl = (ConstI32Ptr)(unsigned long long)a->tflag;  // the prepass' record about the sample table (scalar loads)
-    const bool t_increasing = (a->N >= 2) && (tfl[kTfOk] != 0);  // checked by the prepass (see its table check)
-    bool use_zb = !ROUGH && (a->zb != nullptr) && t_increasing;
-    if (MODE == kModeFull && !use_zb)
-        return true;  // (wave-uniform: facts about the launch) marched by the rough variant
     const int gz_lo_s = st.gz_lo_s, gz_nhi_s = st.gz_nhi_s;  // image depth range {z_min, -z_max} (sortable ints)
     int lane_last = (OWN && own_off) ? -1 : a->N - 1;  // last sample of this lane that can be unmasked (mask bounding box), see below
     if (t_increasing) {
@@ -715,17 +742,12 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
     // 0.2 %, so a skipped sample could not have been taken and the minimum, its index and the tie predecessor
     // are what the full march gives.
     // (stride and fit of the bounds grid for groups of DEPTH samples: zb_log2_stride(), evaluated once by the prepass)
-    const int zrec = tfl[kTfStride];
     const bool zfits = use_zb && ((zrec & 0x100) != 0);
-    const int zls = use_zb ? (zrec & 0xff) : 3;
     // With a checked table every sample lies on the segment pixel -> end point, i.e. inside the image, and the
     // stride was chosen so that a group's footprint fits the tile its lowest cell selects: no per-lane test.
     const bool zb_trusted = __builtin_amdgcn_readfirstlane((int)zfits) != 0;
-    const int zntw = (W >> zls) + 1;
     const __amdgpu_buffer_rsrc_t zr =
         make_rsrc(a->zb + (size_t)b * zb_slot(H, W), zb_slot(H, W) * (int)sizeof(float4));  // (records, then the horizon tables)
-    const float nrm = __builtin_sqrtf(BCx * BCx + BCy * BCy);
-    const float c1 = BCz * ((dxf * BCx + dyf * BCy) / nrm);
     // From here on the ray's f32 direction is RE-DERIVED from the f64 one where it is needed (the bounds test, the horizon
     // look-up, the tie re-march): (float)dx64 == dxf for every finite ray, and a non-finite ray takes no decision from either
     // (Kerr = +inf, c1 = NaN).  Two conversions per bounds test buy two registers -- the ones the six-wave kernel lacked with
@@ -737,29 +759,6 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         dxl = (float)dx_l;
         dyl = (float)dy_l;
     };
-    const float t_abs = __builtin_bit_cast(float, tfl[kTfTabs]);  // max(|tt[0]|, |tt[N-1]|)
-    // Give-up test (a heuristic about WORK, never about results: without the bounds every group is marched).  A group
-    // can only be skipped while the ray's height over the pixel, c1 t / n, exceeds what the surface band leaves open,
-    // about half its width; on a surface rougher than the rays rise (an untrained network's depth) no test can ever
-    // succeed and the tests, the bounds gathers and the termination checks are pure cost (round 1: -24 % against the
-    // kernel without them at noise amplitude 400).  The band of the tile under the wave's own pixels stands for the
-    // roughness of its neighbourhood: if for every lane the whole ray rises less than GCFR_GIVEUP_FACTOR band widths,
-    // the wave marches this tile without the bounds machinery.
-#ifndef GCFR_GIVEUP_FACTOR
-#define GCFR_GIVEUP_FACTOR 0.5f
-#endif
-    if (use_zb) {
-        const int own = __mul24((qy * TILE_H) >> zls, zntw) + ((tx * TILE_W) >> zls);
-        const ConstF32Ptr rec = (ConstF32Ptr)(unsigned long long)a->zb + 4 * ((size_t)b * zb_slot(H, W) + own);
-        const float band = rec[3] - rec[2];  // c_hi - c_lo (wave-uniform address: scalar loads)
-        const bool hopeless = !(fabsf(c1) * t_abs >= GCFR_GIVEUP_FACTOR * nrm * band);  // (NaN / inf bands: hopeless)
-        if (__builtin_amdgcn_ballot_w64(!hopeless) == 0ull) {
-            if (MODE == kModeFull)
-                return true;  // nothing has been marched or written: the caller runs the rough variant of this tile
-            use_zb = false;
-            GCFR_COUNT(kCntBoundsGivenUp, 1);
-        }
-    }
     float Kerr = __builtin_inff();  // never skips
     // Early termination (exact).  Once the ray is above max(image depth maximum, 0) by more than the running
     // minimum allows (same bound as above, with the image-wide zmax instead of a tile's) and is still rising
@@ -914,27 +913,10 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             //  kernel has once the trailing loop is in place; Kerr = +inf where the bound is not valid: gd = -inf)
             float nrm_l = nrm;  // (laundered: or the loop-invariant sub-expression is hoisted back into a register and spilled)
             asm volatile("" : "+v"(nrm_l));
-#if GCFR_MAIN_HORIZON
-            // EXPERIMENT: the per-ray cap of the trailing loop in the main loop's termination test too
-            float cap_l = gz_cap;
-            {
-                const int hz_off = launder(a)->hz_off;
-                if (hz_off >= 0) {
-                    float dxl, dyl;
-                    dir_f32(dxl, dyl);
-                    const int ci = (int)__builtin_floorf(__builtin_fmaf(tn, dxl, x)), ri = (int)__builtin_floorf(-__builtin_fmaf(tn, dyl, y));
-                    constexpr int C = kHorizonDim / 2, M = kHorizonDim - 1;
-                    const int ic = (dxl >= 0.0f) ? kHorizonDim + min(max(ci + (C - 2), 0), M) : min(max(ci + (C + 3), 0), M);
-                    const int ir = (dyl > 0.0f) ? 2 * kHorizonDim + min(max(ri + (C + 3), 0), M) : 3 * kHorizonDim + min(max(ri + (C - 2), 0), M);
-                    const f32x4 zc4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, hz_off + (ic << 4), 0, 0));
-                    const f32x4 zr4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, hz_off + (ir << 4), 0, 0));
-                    cap_l = fminf(fmaxf(fmaxf(zc4.x, zc4.y), fmaxf(zc4.z, zc4.w)), fmaxf(fmaxf(zr4.x, zr4.y), fmaxf(zr4.z, zr4.w)));
-                }
-            }
-            const float gd = __builtin_fmaf(c1, tn, -(__builtin_fmaf(nrm_l, cap_l, -(nrm_l * zb)) + Kerr));
-#else
+            // (Round 4 measured the trailing loop's per-ray cap -- two horizon-table gathers -- in THIS test too (VERDICT r03 item
+            //  5a): bit-identical, and slower: -2.7 % on the bench faces, -3.0 % on the FFHQ fixtures, -3.5 % at B = 128
+            //  (profiles/r04_pixels_mainhz_ab.txt).  The main loop rarely terminates, it hands over to the trailing loop.)
             const float gd = __builtin_fmaf(c1, tn, -(__builtin_fmaf(nrm_l, gz_cap, -(nrm_l * zb)) + Kerr));
-#endif
             const float bS = bestS;
             const bool finished = ((c1 > 0.0f) && (gd > 0.0f) && (gd * gd * 0.998f > bS) && (bS < safeS)) ||
                                   (lane_last < k0 + DEPTH);
@@ -1195,6 +1177,9 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
                 qv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qr, (texel << 4) + quad_origin, 0, 0));
             }
             load_tr(k0 + CH);  // the next iteration's table values (scalar loads, answered while this one runs)
+            // (Round 4 measured skipping the evaluation when NO lane of the wave has an unmasked sample among these CH -- holes in
+            //  the mask, the gap between octagon and face: a ballot and a branch per iteration cost more than they save, -2.4 % at
+            //  noise 400, -2 % on the FFHQ masks with noise; profiles/r04_rough_ab.txt.)
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 const bool masked = (mk[j] == 0) || (OWN && (lane_last < 0));
