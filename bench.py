@@ -113,7 +113,7 @@ def synth_faces(B, seed0, light_seed0=None):
             np.asarray(amb, np.float32))
 
 
-def cpu_baseline(seed0=0, runs=3, with_backward=True):
+def cpu_baseline(seed0=0, runs=2, with_backward=True):
     """The CPU baseline of record: oracle/materialised.py -- the op-for-op torch-CPU port
     of T8:352-524, bit-equal to the imported reference (tests/test_oracle_vs_reference.py); the reference's own .py
     cannot travel to the GPU box -- in the reference's training form: a batch of B = 3 faces, normals from depth
@@ -425,7 +425,8 @@ class RenderRig:
     returns the fenced wall time (max over ranks)."""
 
     def __init__(self, rk, B, size=256, lights=1, samples=160, mask="ellipse", depth_noise=0.0, data="synthetic",
-                 streams=4, from_depth=False, want_argmin=False, knobs=None, graph=True, mode="plan", pixels="all"):
+                 streams=4, from_depth=False, want_argmin=False, knobs=None, graph=True, mode="plan", pixels="all",
+                 normals_stage="fused"):
         from geomconsistentfr_amd import RenderParams, _lib
         from geomconsistentfr_amd import block as R
         self.rk, self.R, self._lib = rk, R, _lib
@@ -433,6 +434,7 @@ class RenderRig:
         self.mask, self.depth_noise, self.data = mask, depth_noise, data
         self.from_depth, self.want_argmin, self.mode = from_depth, want_argmin, mode
         self.knobs = knobs or {}
+        self.normals_stage = normals_stage
         self.base_opt = _lib.options(**self.knobs) if self.knobs else None
         self.n_streams = max(1, streams)
         dev = self.dev = rk.dev
@@ -505,7 +507,7 @@ class RenderRig:
     def _new_plan(self):
         return self.R.RenderFwdPlan(self.B, self.L, self.size, self.size, self.prm, self.dev, want_argmin=self.want_argmin,
                                     mask_batch=self.batches[0][1].shape[0], camera=self.cam if self.from_depth else None,
-                                    options=self.base_opt)
+                                    options=self.base_opt, normals_stage=self.normals_stage)
 
     # -- issue ---------------------------------------------------------------------------------
     def eager_step(self, opt):
@@ -614,9 +616,9 @@ def run_render(a, rk):
     from_depth = (not a.normals_in) and mode in ("plan", "eager")      # (the direct / unfused A/B forms take normals as input)
     headline = (a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse" and a.depth_noise == 0.0
                 and a.data == "synthetic" and B == FACES_PER_GPU and not knobs and mode == "plan" and from_depth
-                and not a.argmin and a.pixels == "all")
+                and not a.argmin and a.pixels == "all" and a.normals_stage == "fused")
     rig = RenderRig(rk, B, a.size, a.lights, a.samples, a.mask, a.depth_noise, a.data, a.streams, from_depth,
-                    a.argmin, knobs, graph=not a.no_graph, mode=mode, pixels=a.pixels)
+                    a.argmin, knobs, graph=not a.no_graph, mode=mode, pixels=a.pixels, normals_stage=a.normals_stage)
     n_streams, world, rank = rig.n_streams, rk.world, rk.rank
     ev = HipEvents()
     legs = {"setup_s": time.perf_counter() - T_START}           # wall seconds per leg of this run (how the default run spends its minutes)
@@ -651,7 +653,9 @@ def run_render(a, rk):
         worst = {}
         for key, kw in (("ones_mask", dict(mask="ones")), ("depth_noise_400", dict(depth_noise=400.0)),
                         ("ffhq", dict(data="ffhq")),
-                        ("train_depth_b32", dict(data="train_depth", B=32, from_depth=True, want_argmin=True, streams=1))):
+                        ("train_depth_b32", dict(data="train_depth", B=32, from_depth=True, want_argmin=True, streams=1)),
+                        ("train_depth_b32_pixels_mask", dict(data="train_depth", B=32, from_depth=True, want_argmin=True, streams=1,
+                                                             pixels="mask"))):
             try:
                 kw = dict(kw)
                 kw.setdefault("from_depth", True)                              # the headline's form of the step
@@ -673,7 +677,8 @@ def run_render(a, rk):
         worst["note"] = ("same kernels, same run: all-ones masks (nothing is ever masked), uniform depth noise of amplitude 400 "
                          "(what an untrained network emits: the depth bounds never separate ray and surface), the three "
                          "checkpoint-derived FFHQ fixture faces tiled to the batch (--data ffhq), and the training step's "
-                         "march -- batch 32, argmin variant, normals fused, depth of a freshly initialised RelightNet")
+                         "march -- batch 32, argmin variant, normals fused, depth of a freshly initialised RelightNet -- as the reference "
+                         "defines it (every pixel) and with the opt-in pixels = mask (gcfr_options.pixels, include/gcfr.h)")
     leg("worst_case_s")
     # the dominant kernel on a launch long enough that its tail does not matter (128 faces, one launch at a time): how busy
     # the VALU issue ports are when the chip is full -- one launch of 8 faces ends with its heaviest tiles, most SIMDs idle
@@ -726,8 +731,7 @@ def run_render(a, rk):
             aux["train"] = {"skipped": "time budget: %.0f s used before the training leg" % (time.perf_counter() - T_START)}
         else:
             try:
-                torch.cuda.empty_cache()
-                aux["train"] = measure_train(rk, 32, steps=12, warmup=6)
+                aux["train"] = train_leg_subprocess(steps=12, warmup=6)
             except Exception as e:
                 aux["train"] = {"error": repr(e)}
         leg("train_s")
@@ -837,7 +841,7 @@ def run_render(a, rk):
     }
     if worst is not None:
         out["worst_case"] = worst
-        for k in ("ones_mask", "depth_noise_400", "ffhq", "train_depth_b32"):    # scalars at the top level too
+        for k in ("ones_mask", "depth_noise_400", "ffhq", "train_depth_b32", "train_depth_b32_pixels_mask"):    # scalars at the top level too
             if "ray_steps_per_sec" in worst.get(k, {}):
                 out["worst_case_%s_ray_steps_per_sec" % k] = worst[k]["ray_steps_per_sec"]
     if aux:
@@ -861,7 +865,7 @@ def run_render(a, rk):
             out["roofline"].update({"aux_" + k: v for k, v in flat.items()})
             if worst is not None:
                 out["roofline"].update({"aux_worst_case_%s_ray_steps_per_sec" % k: worst[k]["ray_steps_per_sec"]
-                                        for k in ("ones_mask", "depth_noise_400", "ffhq", "train_depth_b32")
+                                        for k in ("ones_mask", "depth_noise_400", "ffhq", "train_depth_b32", "train_depth_b32_pixels_mask")
                                         if "ray_steps_per_sec" in worst.get(k, {})})
     if rig.graph_error:
         out["config"]["graph_capture_failed"] = rig.graph_error
@@ -959,6 +963,26 @@ def measure_train(rk, B, steps, warmup, epoch=200, pixels="all"):
                                            "" if rk.world == 1 else ", DistributedDataParallel over RCCL")}
 
 
+def train_leg_subprocess(steps, warmup, timeout_s=420):
+    """The configs[2] leg of the headline line, run as `bench.py --workload train` in its OWN process while this one idles:
+    exactly the stand-alone measurement (MIOpen's find mode tunes its convolutions against a quiet, freshly initialised
+    device context -- run in-process behind the render legs' graphs, plans and streams the same 12 steps took 131 ms each
+    instead of 32 in one of two runs, profiles/r04_report.md).  Returns measure_train()'s scalars."""
+    import subprocess
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "train", "--steps", str(steps), "--warmup", str(warmup), "--gpus", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+    if r.returncode != 0:
+        raise RuntimeError("train leg exited with %d: %s" % (r.returncode, r.stderr[-400:]))
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    return {"step_ms": d["ms_per_step"], "faces_per_sec": d["faces_per_sec"], "ray_steps_per_sec": d["value"],
+            "march_kernel_ms": d["train_march_kernel_ms"], "bwd_kernel_ms": d["train_bwd_kernel_ms"],
+            "render_block_share_of_step": d["render_block_ms"]["share_of_step"], "faces_per_gpu": d["config"]["faces_per_gpu"],
+            "steps": d["steps"], "warmup": d["warmup"], "workload": d["config"]["workload"], "process": "subprocess (bench.py --workload train)"}
+
+
 def run_train(a, rk):
     rank, world = rk.rank, rk.world
     B = a.faces if a.faces != FACES_PER_GPU else 32                          # configs[2]: batch=32 per GPU
@@ -1038,6 +1062,9 @@ def main():
     ap.add_argument("--normals-in", action="store_true",
                     help="SURVEY 8d's accounting form instead: normals handed in as a 12 B/pixel input (gcfr_render_fwd; rounds "
                          "1-3's headline step -- the default line carries it as normals_in_*)")
+    ap.add_argument("--normals-stage", choices=["fused", "kernel"], default="fused",
+                    help="A/B: 'kernel' = the normals stage as its own launch (gcfr_normals_fwd) in front of gcfr_render_fwd instead of "
+                         "fused into the march epilogue (three launches per step, the same bits)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the configs[2] training-step leg of the headline line")
     ap.add_argument("--pixels", choices=["all", "mask"], default="all",
                     help="mask = RenderParams(pixels='mask') / gcfr_options.pixels = 1: pixels outside the mask are not marched (opt-in "

@@ -344,7 +344,7 @@ class RenderFwdPlan:
     Inputs must already be device tensors of the planned shapes and dtypes (f32, mask u8)."""
 
     def __init__(self, B, L, H, W, params: RenderParams = RenderParams(), device="cuda", want_argmin=False,
-                 mask_batch=None, camera=None, options=None):
+                 mask_batch=None, camera=None, options=None, normals_stage="fused"):
         self.L_ = _lib.load()
         want_argmin, options = _pixels_options(params, want_argmin, options)
         self.options = options          # _lib.Options or None; kept alive here, read by the library at every call
@@ -354,6 +354,11 @@ class RenderFwdPlan:
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
         self.dev, self.params, self.shape, self.camera = dev, params, (B, L, H, W), camera
+        # "fused": the march epilogue evaluates the normals stencil (gcfr_render_from_depth_fwd, two launches);
+        # "kernel": gcfr_normals_fwd first, then gcfr_render_fwd reads its output (three launches; the same bits -- A/B knob)
+        if normals_stage not in ("fused", "kernel"):
+            raise _lib.GcfrError("normals_stage must be 'fused' or 'kernel'")
+        self.normals_stage = normals_stage
         f32 = dict(dtype=torch.float32, device=dev)
         self.tt = sample_table(params, dev)
         o = dict(unit_light_direction=torch.empty((B, L, 3), **f32), light_pt=torch.empty((B, L, 3), **f32),
@@ -425,6 +430,14 @@ class RenderFwdPlan:
         if self.camera is None:
             rc = self.L_.gcfr_render_fwd(light.data_ptr(), *self._head, depth.data_ptr(), mask_u8.data_ptr(),
                                          self.mask_batch, normals.data_ptr(), albedo.data_ptr(), ambient.data_ptr(),
+                                         *self._tail, *self._outs, st, _lib.opt_ref(self.options))
+        elif self.normals_stage == "kernel":
+            fx, fy, cx, cy, z_off = [float(v) for v in self.camera]
+            nrm = self.out["surface_normals"]
+            _lib.check(self.L_.gcfr_normals_fwd(depth.data_ptr(), self.shape[0], self.shape[2], self.shape[3], fx, fy, cx, cy, z_off, 1,
+                                                nrm.data_ptr(), st), "gcfr_normals_fwd (plan)")
+            rc = self.L_.gcfr_render_fwd(light.data_ptr(), *self._head, depth.data_ptr(), mask_u8.data_ptr(),
+                                         self.mask_batch, nrm.data_ptr(), albedo.data_ptr(), ambient.data_ptr(),
                                          *self._tail, *self._outs, st, _lib.opt_ref(self.options))
         else:
             fx, fy, cx, cy, z_off = [float(v) for v in self.camera]
