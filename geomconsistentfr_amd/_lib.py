@@ -20,10 +20,10 @@ _ERRORS = {-1: "GCFR_ERR_INVALID_ARGUMENT", -2: "GCFR_ERR_LAUNCH"}
 
 _p, _i, _f, _d = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_double
 
-N_COUNTERS = 16      # GCFR_N_COUNTERS
+N_COUNTERS = 20      # GCFR_N_COUNTERS
 COUNTER_NAMES = ("tiles", "groups_nominal", "groups_visited", "bound_tests", "bodies", "lane_samples", "early_exits",
                  "tie_remarches", "samples_in_range", "bounds_given_up", "visits_after_last_body", "visits_before_first_body",
-                 "trail_enter", "trail_skips", "trail_leave", "rough_samples")
+                 "trail_enter", "trail_skips", "trail_leave", "rough_samples", "wave_samples", "wave_samples_taken", "lane_takes")
 
 
 class Options(ctypes.Structure):

@@ -327,7 +327,8 @@ __device__ inline int lo32(double v)
 // gcfr_options.counters once per tile.  Compiled out of the product build.
 enum { kCntTiles, kCntGroupsNominal, kCntGroupsVisited, kCntBoundTests, kCntBodies, kCntLaneSamples, kCntEarlyExit,
        kCntTieRemarch, kCntSamplesInRange, kCntBoundsGivenUp, kCntVisitsAfterLastBody, kCntVisitsBeforeFirstBody,
-       kCntTrailEnter, kCntTrailSkips, kCntTrailLeave, kCntRoughSamples, kCntUsed };
+       kCntTrailEnter, kCntTrailSkips, kCntTrailLeave, kCntRoughSamples, kCntWaveSamples, kCntWaveSamplesTaken, kCntLaneTakes, kCntUsed };
+static_assert(kCntUsed <= GCFR_N_COUNTERS, "gcfr_options.counters holds GCFR_N_COUNTERS tallies");
 #ifdef GCFR_COUNTERS
 #define GCFR_COUNT(i, n) (cnt[i] += (unsigned)(n))
 #else
@@ -976,6 +977,14 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         const float Xz = __builtin_fmaf(BAx, BCy, -(BAy * BCx));
         const float S = ((Xx * Xx + Xy * Xy) + Xz * Xz) + kEps4;
         const bool take = !masked && (S < bestS);
+#ifdef GCFR_COUNTERS   // (round 4) per executed wave-sample: does ANY lane lower its minimum?  (the question an f32 pre-filter would ask)
+        {
+            const unsigned long long tk = __builtin_amdgcn_ballot_w64(take);
+            cnt[kCntWaveSamples] += 1u;
+            cnt[kCntWaveSamplesTaken] += (tk != 0ull) ? 1u : 0u;
+            cnt[kCntLaneTakes] += (unsigned)__builtin_popcountll(tk);
+        }
+#endif
         if (WANT_ARGMIN) {
             prevS = take ? bestS : prevS;
             prevk = take ? besti : prevk;

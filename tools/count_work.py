@@ -80,6 +80,10 @@ def main():
            # (tiles in the tile function's rough variant count their samples one by one: rough_samples, wave level)
            "executed_ray_steps_wave_level": (c["bodies"] * group + c.get("rough_samples", 0)) * 64,
            "executed_fraction_of_nominal": (c["bodies"] * group + c.get("rough_samples", 0)) * 64 / nominal,
+           # (round 4) per executed wave-sample: how often does ANY lane lower its running minimum -- what an f32 pre-filter in front
+           # of the exact body could at best avoid is the rest
+           "wave_samples_in_which_some_lane_takes": c.get("wave_samples_taken", 0) / max(c.get("wave_samples", 0), 1),
+           "lanes_taking_per_executed_wave_sample": c.get("lane_takes", 0) / max(c.get("wave_samples", 0), 1),
            "useful_lane_samples": c["lane_samples"],
            "lane_utilisation_of_executed_bodies": c["lane_samples"] / max(c["bodies"] * group * 64, 1),
            "groups_visited_per_tile": c["groups_visited"] / max(c["tiles"], 1),
