@@ -126,3 +126,21 @@ def test_source_hash_ignores_comments_and_sees_code(tmp_path, monkeypatch):
     assert build._code_only(code) == 'int a;\n  int b = 1; const char *s = "// kept /* kept */";\n   int c;\n#define Q \'"\''
     assert build._code_only(code.replace("one", "another remark").replace("two", "2")) == build._code_only(code)
     assert build._code_only(code.replace("b = 1", "b = 2")) != build._code_only(code)
+
+
+def test_pixels_option_reaches_gcfr_options_and_bad_values_are_refused():
+    """RenderParams.pixels -> gcfr_options.pixels (host logic; no GPU needed): "mask" sets the field on a COPY of the caller's
+    options and asks for the argmin plane (the option lives in the training march); anything else is refused loudly."""
+    import ctypes
+    import pytest
+    from geomconsistentfr_amd import RenderParams, _lib
+    from geomconsistentfr_amd.block import _pixels_options
+    base = _lib.options(tile_w=32)
+    want, opt = _pixels_options(RenderParams(pixels="mask"), False, base)
+    assert want is True and opt.pixels == 1 and opt.tile_w == 32 and opt.struct_size == ctypes.sizeof(_lib.Options)
+    assert base.pixels == 0                                           # the caller's struct is not modified
+    want, opt = _pixels_options(RenderParams(pixels="mask"), False, None)
+    assert want is True and opt.pixels == 1 and opt.ksplit == -1      # defaults + the flag
+    assert _pixels_options(RenderParams(), False, base) == (False, base)
+    with pytest.raises(_lib.GcfrError):
+        _pixels_options(RenderParams(pixels="face"), True, None)

@@ -53,18 +53,22 @@ def test_trainer_distributed_over_rccl_world1_d_step_and_g_step_from_epoch_zero(
         dist.destroy_process_group()
 
 
-def _rccl_world2_worker(rank, world, port, q):
-    """One rank of the 2-GPU test below (spawned; its own process, its own GPU)."""
+def _rccl_world2_worker(rank, world, port, q, backend="nccl", share_gpu=False):
+    """One rank of the 2-rank tests below (spawned; its own process; its own GPU over `nccl`, or -- the rehearsal on a 1-GPU
+    box -- GPU 0 shared by both ranks with the collectives over `gloo`)."""
     try:
         import copy
         import torch.distributed as dist
         from geomconsistentfr_amd.train import TrainConfig, Trainer, shard_range, synthetic_batch
         os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"            # dmabuf IPC: what RCCL needs on this driver
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-        dev = torch.device("cuda", rank)
+        dev = torch.device("cuda", 0 if share_gpu else rank)
         torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        assert dist.get_backend() == "nccl"
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_backend() == backend
         torch.manual_seed(0)                                       # the same initial weights on every rank
         tr = Trainer(TrainConfig(miopen_find=False), device=dev, distributed=True)
         full = synthetic_batch(2 * world, 0, device=dev)           # whole faces per rank, no data-path collective
@@ -122,7 +126,31 @@ def test_trainer_over_rccl_world2_gradients_are_the_mean_of_the_shards_and_param
         p.join(timeout=120)
     assert all(r[1] is None for r in res), res
     assert all(p.exitcode == 0 for p in procs)
+    _check_world2(res)
+
+
+def _check_world2(res):
     for rank, _, g_err, g_scale, p_diff, ok_logs in res:
         assert g_scale > 0 and g_err <= 1e-4 * g_scale, (rank, g_err, g_scale)   # (depth-gradient atomics: order jitter)
         assert p_diff == 0.0, (rank, p_diff)
         assert ok_logs
+
+
+def test_trainer_world2_rehearsal_two_ranks_share_the_gpu_over_gloo():
+    """The same two-rank check on the hardware there is: both ranks on GPU 0 (RCCL refuses two ranks on one device), DDP's
+    gradient all-reduce over `gloo`.  It exercises everything of the test above except the transport -- the HIP render block
+    forward and backward inside DistributedDataParallel on two processes, whole faces per rank, gradients = mean of the shards,
+    parameters equal after a D+G step and a G step at epoch 0."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 38500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_rccl_world2_worker, args=(r, 2, port, q, "gloo", True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert all(r[1] is None for r in res), res
+    assert all(p.exitcode == 0 for p in procs)
+    _check_world2(res)
