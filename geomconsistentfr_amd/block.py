@@ -107,7 +107,9 @@ def shadow_min_distance(depth: torch.Tensor, mask: torch.Tensor, light_pt: torch
     Replaces T8:371-515.  use_workspace=False selects the direct-gather kernel (same bits, slower).
     `options`: a `_lib.Options` (kernel / schedule selection and hooks; never changes a result bit)."""
     _require_device(depth, mask, light_pt)
-    if params.pixels != "all" and use_workspace:
+    if params.pixels != "all":
+        if not use_workspace:
+            raise _lib.GcfrError("RenderParams.pixels = %r needs the workspace path (use_workspace=True)" % (params.pixels,))
         want_argmin, options = _pixels_options(params, want_argmin, options)
     L_ = _lib.load()
     depth = _f32c(depth)

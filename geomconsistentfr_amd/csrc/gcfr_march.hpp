@@ -1381,12 +1381,12 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         d = kMaskedDistance;
         besti = -1;
     }
-    if (!finite_ray)
-        d = __builtin_nanf("");
     if (OWN && (lane_last < 0)) {  // not marched (or a ray that never reaches the mask: the same value either way): the masked value
         d = kMaskedDistance;
         besti = -1;
     }
+    if (!finite_ray)  // (after the line above: a non-finite ray has no candidate range either, and is NaN with or without the option)
+        d = __builtin_nanf("");
     const EpiPtr ep = launder((EpiPtr)&a->epi);
     const bool inside = (Cx >= ep->bx_lo) && (Cx <= ep->bx_hi) && (Cy >= ep->by_lo) && (Cy <= ep->by_hi);
     if (inside)

@@ -170,6 +170,25 @@ def test_reference_golden_batches_through_the_option(name, case):
     w = out["shadow_mask_weights"].cpu().numpy()
     assert np.abs(w - exp["shadow_mask_weights"])[on].max() <= 2e-5
     assert (w[~on] == 1.0).all()
-    rgb = out["rendered_images"].cpu().numpy()
-    on3 = np.repeat(on[:, None], 3, axis=1)
-    assert np.abs(rgb - exp["rendered_images"])[on3].max() <= 2e-5
+    if "rendered_images" in exp:                         # (the shadow-path-only batches record no RGB)
+        rgb = out["rendered_images"].cpu().numpy()
+        on3 = np.repeat(on[:, None], 3, axis=1)
+        assert np.abs(rgb - exp["rendered_images"])[on3].max() <= 2e-5
+
+
+def test_non_finite_rays_are_nan_with_and_without_the_option():
+    """A non-finite light point makes every ray of its image non-finite: minimum distance NaN (deviations), inside
+    and outside the mask, whether or not pixels outside the mask are marched; the other images are unaffected."""
+    from geomconsistentfr_amd import RenderParams, shadow_min_distance
+    B = 3
+    depth, mask, _, _, light, _ = _faces(B, False)
+    pt = torch.from_numpy(4013.0 * light / np.linalg.norm(light, axis=1, keepdims=True)).float().to(DEV).reshape(B, 1, 3).contiguous()
+    pt[1, 0, 0] = float("nan")
+    d, m = torch.from_numpy(depth).to(DEV), torch.from_numpy(mask).to(DEV)
+    md0, _ = shadow_min_distance(d, m, pt, RenderParams())
+    md1, _ = shadow_min_distance(d, m, pt, RenderParams(pixels="mask"))
+    md0, md1 = md0.cpu().numpy()[:, 0], md1.cpu().numpy()[:, 0]
+    assert np.isnan(md0[1]).all() and np.isnan(md1[1]).all()
+    on = mask != 0
+    assert np.array_equal(md1[on], md0[on], equal_nan=True)
+    assert (md1[0][~on[0]] == 1e6).all()
