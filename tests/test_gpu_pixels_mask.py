@@ -180,7 +180,7 @@ def test_non_finite_rays_are_nan_with_and_without_the_option():
     """A non-finite light point makes every ray of its image non-finite: minimum distance NaN (deviations), inside
     and outside the mask, whether or not pixels outside the mask are marched; the other images are unaffected."""
     from geomconsistentfr_amd import RenderParams, shadow_min_distance
-    B = 3
+    B = 4
     depth, mask, _, _, light, _ = _faces(B, False)
     pt = torch.from_numpy(4013.0 * light / np.linalg.norm(light, axis=1, keepdims=True)).float().to(DEV).reshape(B, 1, 3).contiguous()
     pt[1, 0, 0] = float("nan")
