@@ -171,17 +171,15 @@ def cpu_baseline(seed0=0, runs=2, with_backward=True):
     out = {"value": by_threads[best]["ray_steps_per_sec"], "unit": "ray-steps/s", "cores": best, "kind": "port",
            "host_threads_available": cores, "faces_per_s": B / by_threads[best]["median_s"],
            "forward_by_threads": {str(k): v for k, v in by_threads.items()},
-           "sample": "T8 form: batch of 3 faces 256x256x160 incl. normals from depth, forward no_grad, "
-                     "oracle/materialised.py (op-for-op torch-CPU port of T8:352-524), median of %d runs after a "
-                     "warm-up at each of %s threads; best = %d threads, %.2f s per batch"
-                     % (runs, sorted(by_threads), best, by_threads[best]["median_s"])}
+           "sample": "T8 form, 3 faces 256x256x160 incl. normals, forward no_grad, oracle/materialised.py, median of %d runs, "
+                     "best of %s threads: %.2f s/batch" % (runs, sorted(by_threads), by_threads[best]["median_s"])}
     if with_backward:
         torch.set_num_threads(best)
         med, ts = median_time(forward_backward, runs)
         out["forward_backward"] = {"value": steps / med, "unit": "ray-steps/s", "cores": best, "median_s": med,
                                    "runs_s": ts, "faces_per_s": B / med,
-                                   "sample": "same batch, forward with autograd graph + backward of sum(rendered) + "
-                                             "sum(shadow weights), median of %d runs" % runs}
+                                   "sample": "same batch, forward + autograd backward of sum(rendered) + sum(shadow weights), "
+                                             "median of %d runs" % runs}
     torch.set_num_threads(cores)
     return out
 
@@ -1023,6 +1021,26 @@ def run_train(a, rk):
     }
 
 
+def compact(obj):
+    """The ONE JSON line without its prose: `note` / `sample` / `workload` strings longer than 120 characters are cut (what every
+    key means and how it is measured is DESIGN.md section 5's table), per-run lists go.  Keeps the line under ~8 KB so that a
+    consumer that stores only the tail of stdout still holds all of it.  `--verbose-json` prints everything."""
+    if isinstance(obj, dict):
+        out = {}
+        for k, v in obj.items():
+            if k in ("runs_s", "forward_by_threads"):
+                continue
+            if k == "note" and isinstance(v, str) and len(v) > 120:
+                continue
+            if isinstance(v, str) and len(v) > 240:
+                v = v[:237] + "..."
+            out[k] = compact(v)
+        return out
+    if isinstance(obj, list):
+        return [compact(v) for v in obj]
+    return obj
+
+
 def run_dry(a, rk):
     """--dry-run: the process layout only (rendezvous, one collective, the JSON line) -- what a CPU-only container can
     check of `bench.py --gpus N` (tests/test_bench_launch.py); no kernels, no numbers."""
@@ -1065,6 +1083,7 @@ def main():
     ap.add_argument("--normals-stage", choices=["fused", "kernel"], default="fused",
                     help="A/B: 'kernel' = the normals stage as its own launch (gcfr_normals_fwd) in front of gcfr_render_fwd instead of "
                          "fused into the march epilogue (three launches per step, the same bits)")
+    ap.add_argument("--verbose-json", action="store_true", help="print the line with every note / sample description (default: compact)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the configs[2] training-step leg of the headline line")
     ap.add_argument("--pixels", choices=["all", "mask"], default="all",
                     help="mask = RenderParams(pixels='mask') / gcfr_options.pixels = 1: pixels outside the mask are not marched (opt-in "
@@ -1106,7 +1125,7 @@ def main():
         raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (a.gpus, rk.world))
     out = run_dry(a, rk) if a.dry_run else (run_render if a.workload == "render" else run_train)(a, rk)
     if rk.rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(compact(out) if not a.verbose_json else out), flush=True)
     rk.close()
 
 
