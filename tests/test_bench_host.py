@@ -46,3 +46,17 @@ def test_spec_rate_pricing_of_the_committed_mix():
     assert 0.6 * fwd["issue_cycles_per_launch"] < spec < fwd["issue_cycles_per_launch"]
     assert abs(sum(fwd["by_class"].values()) - fwd["insts_per_launch"]) < 1.0
     assert pm.get("library_srchash")                                            # what bench.py's `roofline.stale` compares
+
+
+def test_compact_line_keeps_the_contract_keys_and_drops_the_prose():
+    """bench.compact(): long `note`s and per-run lists go, every number and the contract's strings (`sample`, `workload`) stay."""
+    line = {"metric": "ray_steps_per_sec", "value": 1.0, "config": {"workload": "w" * 300, "faces_per_gpu": 8},
+            "roofline": {"frac": 0.3, "note": "n" * 500, "hbm": {"frac": 2.7, "note": "short"}},
+            "cpu_baseline": {"value": 8e6, "unit": "ray-steps/s", "cores": 8, "kind": "port", "sample": "s" * 100,
+                             "forward_by_threads": {"8": {"runs_s": [1.0, 2.0]}}, "forward_backward": {"value": 4e6, "runs_s": [3.0]}}}
+    c = bench.compact(line)
+    assert c["roofline"] == {"frac": 0.3, "hbm": {"frac": 2.7, "note": "short"}}
+    assert c["cpu_baseline"]["sample"] == "s" * 100 and "forward_by_threads" not in c["cpu_baseline"]
+    assert c["cpu_baseline"]["forward_backward"] == {"value": 4e6}
+    assert c["config"]["workload"].endswith("...") and len(c["config"]["workload"]) == 240 and c["config"]["faces_per_gpu"] == 8
+    assert json.loads(json.dumps(c)) == c
