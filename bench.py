@@ -201,22 +201,67 @@ def cpu_baseline_c(sample_faces=8, seed0=0):
             "kind": "port", "sample": "%d faces 256x256x160, oracle/gcfr_oracle.c (scalar C, OpenMP), %.2f s" % (sample_faces, dt)}
 
 
-def measured_copy_bandwidth_gbs(dev, mb=1024, iters=5):
-    """Device-to-device copy rate (read + write bytes) -- the achievable-HBM denominator SURVEY.md 8d asks to
-    report beside the 8 TB/s spec peak."""
-    n = mb * 1024 * 1024 // 4
-    a = torch.empty(n, dtype=torch.float32, device=dev)
+def measured_copy_bandwidth_gbs(dev, mb=1024, iters=10):
+    """Achievable HBM rate (read + write bytes) -- the denominator SURVEY.md 8d asks to report beside the 8 TB/s spec peak:
+    the library's float4 grid-stride copy kernel (gcfr_copy_probe: 16 B per lane and step, 8192 workgroups, the recipe
+    MI355X_MICROARCH.md quotes 6.29 TB/s for), 1 GiB in and 1 GiB out, HIP events on the launch stream.  Rounds 1-4 timed
+    torch's copy_ here, which reached 4.8 TB/s."""
+    import ctypes
+    from geomconsistentfr_amd import _lib
+    L = _lib.load()
+    n = mb * 1024 * 1024
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
     b = torch.empty_like(a)
-    a.fill_(1.0)
-    b.copy_(a)
+    a.fill_(1)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(L.gcfr_copy_probe(a.data_ptr(), b.data_ptr(), ctypes.c_size_t(n), st), "gcfr_copy_probe")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(iters):
-        b.copy_(a)
+        _lib.check(L.gcfr_copy_probe(a.data_ptr(), b.data_ptr(), ctypes.c_size_t(n), st), "gcfr_copy_probe")
     e1.record()
     torch.cuda.synchronize()
-    return 2.0 * n * 4 * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return 2.0 * n * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def parity_spot_check(rig):
+    """CHECKER LEG (the only use of oracle/ in the timed process besides cpu_baseline): face 0 of the timed batch 0, through the
+    TIMED plan (a replay of its hipGraph), against the C oracle -- minimum distance bit for bit, shadow weight and RGB <= 2e-5
+    (gates: 1e-4 / 1e-3, BASELINE.json).  Raises on a difference: a fast library that renders something else must not produce a
+    line.  Returns a short description for config.parity_spot_check."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    from normals_restatement import depth_to_normals
+    rig.issue(0, 1)
+    torch.cuda.synchronize()
+    out = rig.plans[0].out
+    dd, mm, al, nr, li, am = [None if t is None else t.detach().cpu().numpy() for t in rig.batches[0]]
+    size, Ll, N = rig.size, rig.L, rig.N
+    depth, mask, albedo = dd[:1].reshape(1, size, size), mm[:1].reshape(1, size, size), al[:1]
+    light, amb = li.reshape(rig.B, Ll, 3)[:1], am.reshape(rig.B, Ll)[:1]
+    _, pt = c_oracle.light_prep(light.reshape(-1, 3), clamp_z_min=0.0)
+    pt = pt.reshape(1, Ll, 3)
+    md, _ = c_oracle.shadow_min_distance(depth, mask, pt, c_oracle.sample_table(rig.prm.t0, rig.prm.dt, N))
+    got_md = out["minimum_distance"][:1].cpu().numpy().reshape(md.shape)
+    if not np.array_equal(got_md, md):
+        raise SystemExit("bench.py: parity spot check FAILED: %d of %d minimum distances differ from the C oracle"
+                         % (int((got_md != md).sum()), md.size))
+    if rig.from_depth:
+        fx, fy, cx, cy, zoff = rig.cam
+        K = torch.zeros(1, 3, 3, dtype=torch.float64)
+        K[:, 0, 0], K[:, 1, 1], K[:, 2, 2], K[:, 0, 2], K[:, 1, 2] = fx, fy, 1.0, cx, cy
+        n = depth_to_normals(torch.from_numpy(depth)[:, None] + zoff, K)
+        n[:, 1] = -n[:, 1]
+        normals = n.numpy()
+    else:
+        normals = nr[:1].astype(np.float64)
+    ref = c_oracle.shade(normals, depth, albedo, pt, amb, md, intensity=float(rig.prm.directional_intensity))
+    e_w = float(np.abs(out["shadow_mask_weights"][:1].cpu().numpy().reshape(ref["shadow_w"].shape) - ref["shadow_w"]).max())
+    e_rgb = float(np.abs(out["rendered_images"][:1].cpu().numpy().reshape(ref["rendered"].shape) - ref["rendered"]).max())
+    if not (e_w <= 2e-5 and e_rgb <= 2e-5):
+        raise SystemExit("bench.py: parity spot check FAILED: max|dw| = %.3g, max|dRGB| = %.3g against the C oracle (2e-5)" % (e_w, e_rgb))
+    return "ok: face 0 of the timed batch through the timed plan vs the C oracle -- min_dist bit-equal (%d pixels), max|dw| %.1e, max|dRGB| %.1e" % (md.size, e_w, e_rgb)
 
 
 def pmc_summary():
@@ -562,6 +607,32 @@ class RenderRig:
                      "note": "a region of `steps` steps lasts < 200 ms: it was repeated %d times (each fenced by barrier + "
                              "synchronize on both sides, max over ranks); value / ms_per_step are the MEDIAN region" % n}, own, host
 
+    def timed_march_only(self, n_steps):
+        """The latency of one batch when its prepass has been issued EARLIER (gcfr_options.phase: in RelightNet.forward it runs
+        on a side stream under the albedo decoder): `n_steps` replays of plan 0's march-only hipGraph, one at a time on one
+        stream, on the workspace its prepass graph prepared once -- the march only reads the workspace.  Fenced wall seconds
+        (median of the repeated regions), or None where the plans are not graphs."""
+        if not self.use_graph:
+            return None
+        p0 = self.plans[0]
+        if not hasattr(p0, "graph_march"):
+            p0.capture_split(*self.inputs[0])
+        with torch.cuda.stream(self.streams[0]):
+            p0.replay_prepass()
+        torch.cuda.synchronize()
+
+        def once():
+            self.rk.fence()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(self.streams[0]):
+                for _ in range(n_steps):
+                    p0.replay_march()
+            self.rk.fence()
+            return time.perf_counter() - t0
+        first = once()
+        n = regions_needed(n_steps, 1e3 * first / n_steps)
+        return float(np.median([once() for _ in range(n)])) if n > 1 else first
+
     def kernel_launch_ms(self, ev, n=100):
         """the march kernel's un-overlapped launch duration: plan calls (not graph replays) on ONE stream, each with
         its own event pair recorded by the library immediately before / after the march kernel on that stream"""
@@ -627,6 +698,10 @@ def run_render(a, rk):
         now = time.perf_counter()
         legs[name] = now - t_leg
         t_leg = now
+    # in-run parity spot check: the timed binary is checked in the run that times it
+    spot = None
+    if rig.use_plans and not a.no_parity_check and not a.argmin and a.pixels == "all":
+        spot = parity_spot_check(rig)
     for i in range(a.warmup):
         rig.issue(i, n_streams)
     elapsed, regions, own_elapsed, host_issue = rig.timed_regions(a.steps)
@@ -642,6 +717,10 @@ def run_render(a, rk):
     single = {"ms_per_step": 1e3 * single_elapsed / single_steps,
               "ray_steps_per_sec": world * rsps * single_steps / single_elapsed, "regions": single_regions,
               "note": "the same steps one at a time on ONE stream (hipGraph replay): the latency of one batch"}
+    march_only_s = rig.timed_march_only(single_steps) if headline else None
+    if march_only_s:
+        single["march_only_ms_per_step"] = 1e3 * march_only_s / single_steps
+        single["march_only_ray_steps_per_sec"] = world * rsps * single_steps / march_only_s
     layout = rk.describe()                                                    # (a collective: every rank calls it)
     leg("headline_s")
 
@@ -812,6 +891,10 @@ def run_render(a, rk):
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+f32",
         "data": "synthetic" if a.data != "ffhq" else "ffhq-fixtures (3 checkpoint-derived faces tiled)",
+        # (advisor r04: `value` of rounds 1-3 timed gcfr_render_fwd with the normals handed in -- today's `normals_in_*`; since round 4
+        #  the step includes the normals stage, so `value` is not comparable across that boundary by itself)
+        "step_definition": ("gcfr_render_from_depth_fwd (normals stage inside the step; rounds 1-3: gcfr_render_fwd = normals_in_*)"
+                            if from_depth else "gcfr_render_fwd (normals handed in)"),
         "config": {"workload": ("BASELINE configs[1]: " + desc) if headline else
                                ("non-headline: batch=%d %s %dx%d faces per GPU, %d light(s) each, %d march steps, mask=%s, "
                                 "depth noise %g, knobs %s, %s%sforward-only shadow+shade; %d batch(es) in flight"
@@ -831,6 +914,8 @@ def run_render(a, rk):
         "ray_steps_per_sec_per_gpu": value / world,
         "single_stream": single,
         "latency_one_batch_ms": single["ms_per_step"],
+        # ... and with the prepass issued earlier on a side stream (gcfr_options.phase; RelightNet.forward does, under the albedo decoder)
+        "latency_one_batch_prepass_hoisted_ms": single.get("march_only_ms_per_step"),
         # `value` is a throughput with `hip_streams` batches in flight (faces_in_flight below), not the rate of one batch
         # of `faces_per_gpu` on its own -- that one is `single_stream` (VERDICT r01 asked for both to be named)
         "faces_in_flight_per_gpu": B * n_streams,
@@ -857,16 +942,26 @@ def run_render(a, rk):
                         train_march_kernel_ms=tr["march_kernel_ms"], train_bwd_kernel_ms=tr["bwd_kernel_ms"],
                         train_ray_steps_per_sec=tr["ray_steps_per_sec"])
         out.update(flat)
-        # ... and once more inside `roofline`, whose scalar keys the driver's parsed record is known to keep (BENCH_r03.json kept
-        # every scalar of `roofline` and `config` but only the NAMES of extra top-level keys)
-        if isinstance(out.get("roofline"), dict):
-            out["roofline"].update({"aux_" + k: v for k, v in flat.items()})
-            if worst is not None:
-                out["roofline"].update({"aux_worst_case_%s_ray_steps_per_sec" % k: worst[k]["ray_steps_per_sec"]
-                                        for k in ("ones_mask", "depth_noise_400", "ffhq", "train_depth_b32", "train_depth_b32_pixels_mask")
-                                        if "ray_steps_per_sec" in worst.get(k, {})})
+    # `roofline`: the scalars a reader needs FIRST (the driver's parsed record keeps the first ~20 scalar keys of `roofline` and of
+    # `config`, and only the names of extra top-level keys: BENCH_r04.json lost the worst cases and the saturated fraction off the
+    # end): the contract's six, then the fractions, the traffic, the executed share, staleness, the worst cases, the one-batch rate
+    if isinstance(out.get("roofline"), dict):
+        roof_in = out["roofline"]
+        extra = {"single_stream_ray_steps_per_sec": single["ray_steps_per_sec"]}
+        if worst is not None:
+            for k in ("ffhq", "ones_mask", "depth_noise_400", "train_depth_b32"):
+                if "ray_steps_per_sec" in worst.get(k, {}):
+                    extra["worst_case_" + k] = worst[k]["ray_steps_per_sec"]
+        roof_in.update(extra)
+        first = ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_measured_costs", "frac_at_throughput", "frac_spec_saturated",
+                 "wait_any_frac_of_wave_time", "hbm_traffic_frac_of_peak", "executed_fraction_of_nominal_ray_steps", "stale",
+                 "worst_case_ffhq", "worst_case_ones_mask", "worst_case_depth_noise_400", "worst_case_train_depth_b32",
+                 "single_stream_ray_steps_per_sec", "avg_launch_ms", "valu_insts_per_launch", "hbm_measured_copy_GBs", "library_srchash")
+        out["roofline"] = {**{k: roof_in[k] for k in first if k in roof_in}, **{k: v for k, v in roof_in.items() if k not in first}}
     if rig.graph_error:
         out["config"]["graph_capture_failed"] = rig.graph_error
+    out["config"]["parity_spot_check"] = spot if spot is not None else "skipped (%s)" % (
+        "--no-parity-check" if a.no_parity_check else "not a plan-mode / all-pixels / inference-march run")
     if world == 1 and not a.no_cpu_baseline and headline:
         out["cpu_baseline"] = cpu_baseline()
         out["cpu_baseline_c_openmp"] = cpu_baseline_c()
@@ -1065,6 +1160,8 @@ def main():
                     help="ffhq = the three checkpoint-derived FFHQ fixture faces (tests/golden/inputs.npz) tiled to the batch; "
                          "train_depth = depth / light / albedo of a freshly initialised RelightNet (use with --from-depth --argmin)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true",
+                    help="skip the in-run parity spot check (face 0 of the timed batch through the timed plan vs the C oracle)")
     ap.add_argument("--no-worst-case", action="store_true", help="skip the secondary workloads of the headline line")
     ap.add_argument("--regions", type=int, default=0,
                     help="number of fenced timed regions of `steps` steps (0 = auto: repeated when a region is shorter than 200 ms; "

@@ -7,4 +7,4 @@ the reference's only callable boundary, RelightNet.forward.
 """
 from .block import RenderParams, render, shadow_min_distance, light_prep  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.5.0"   # = the library's (gcfr_version(): "gcfr-hip 0.5.0 gfx950")

@@ -15,7 +15,7 @@ from . import build as _build
 _LIB = None
 
 GCFR_OK = 0
-ABI_VERSION = 4      # include/gcfr.h GCFR_ABI_VERSION this binding was written against
+ABI_VERSION = 5      # include/gcfr.h GCFR_ABI_VERSION this binding was written against
 _ERRORS = {-1: "GCFR_ERR_INVALID_ARGUMENT", -2: "GCFR_ERR_LAUNCH"}
 
 _p, _i, _f, _d = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_double
@@ -32,18 +32,30 @@ class Options(ctypes.Structure):
     RenderFwdPlan."""
     _fields_ = [("struct_size", ctypes.c_uint32), ("tile_w", _i), ("group", _i), ("ksplit", _i),
                 ("depth_bound_skip", _i), ("schedule", _i), ("tile_order", _i), ("lds_stage", _i),
-                ("event_start", _p), ("event_stop", _p), ("counters", _p), ("pixels", _i)]
+                ("event_start", _p), ("event_stop", _p), ("counters", _p), ("pixels", _i), ("phase", _i)]
 
 
 def options(tile_w=0, group=0, ksplit=-1, depth_bound_skip=-1, schedule=-1, tile_order=-1, event_start=None,
-            event_stop=None, counters=None, lds_stage=-1, pixels=0) -> Options:
+            event_stop=None, counters=None, lds_stage=-1, pixels=0, phase=0) -> Options:
     o = Options()
     load().gcfr_options_default(ctypes.byref(o))
     o.tile_w, o.group, o.ksplit, o.depth_bound_skip = tile_w, group, ksplit, depth_bound_skip
     o.schedule, o.tile_order, o.lds_stage = schedule, tile_order, lds_stage
     o.event_start, o.event_stop, o.counters = event_start, event_stop, counters
     o.pixels = pixels
+    o.phase = phase
     return o
+
+
+def with_phase(o, phase: int) -> Options:
+    """a copy of `o` (or the defaults) with `phase` set: 1 = the prepass only, 2 = the march only (include/gcfr.h)"""
+    n = Options()
+    if o is None:
+        load().gcfr_options_default(ctypes.byref(n))
+    else:
+        ctypes.memmove(ctypes.byref(n), ctypes.byref(o), ctypes.sizeof(Options))
+    n.phase = phase
+    return n
 
 
 def with_pixels(o, pixels: int) -> Options:
@@ -87,6 +99,7 @@ _SIGNATURES = {
     "gcfr_assemble_batch_u8": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "gcfr_masked_metrics_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i]),
     "gcfr_masked_metrics_u8": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, ctypes.c_size_t, _p]),
+    "gcfr_copy_probe": (_i, [_p, _p, ctypes.c_size_t, _p]),
 }
 
 

@@ -105,7 +105,10 @@ def shadow_min_distance(depth: torch.Tensor, mask: torch.Tensor, light_pt: torch
                         use_workspace: bool = True, options=None):
     """depth (B,H,W) f32, mask (B|1,H,W), light_pt (B,L,3) -> min_dist (B,L,H,W) f32, argmin i32|None.
     Replaces T8:371-515.  use_workspace=False selects the direct-gather kernel (same bits, slower).
-    `options`: a `_lib.Options` (kernel / schedule selection and hooks; never changes a result bit)."""
+    `options`: a `_lib.Options` (kernel / schedule selection and hooks; none changes a result bit EXCEPT `pixels`, see
+    include/gcfr.h).  `params.pixels = "mask"` reaches the library as `options.pixels = 1`, lives in the training (argmin) march
+    and therefore FORCES want_argmin: an argmin tensor is returned (and the five-wave argmin kernel runs) even if the caller
+    passed want_argmin=False."""
     _require_device(depth, mask, light_pt)
     if params.pixels != "all":
         if not use_workspace:
@@ -163,13 +166,90 @@ def shade(normals, depth, albedo, light_pt, ambient, min_dist, params: RenderPar
     return dict(shadow_mask_weights=w, full_shading=full, final_shading=fin, rendered_images=ren)
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device) -> torch.cuda.Stream:
+    """the device's stream for hoisted prepasses (one per device, created on first use)"""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=torch.device("cuda", key))
+    return s
+
+
+class Prepared:
+    """What `render_prepass()` leaves behind for the `render_fwd(..., prepared=...)` / `render_from_depth(..., prepared=...)`
+    that follows: the workspace the prepass filled, the light outputs it wrote, the event that marks its end on the side
+    stream, and the arguments it was issued with (the march must be issued with the same ones)."""
+    __slots__ = ("ws", "ws_bytes", "unit", "pt", "event", "key", "depth", "mask_u8", "light")
+
+
+def _prepass_key(depth, mask_u8, light, params, options):
+    import ctypes
+    knobs = None
+    if options is not None:
+        o = _lib.with_phase(options, 0)
+        o.event_start = o.event_stop = None
+        knobs = bytes(ctypes.string_at(ctypes.byref(o), ctypes.sizeof(o)))
+    return (depth.data_ptr(), tuple(depth.shape), mask_u8.data_ptr(), tuple(mask_u8.shape), light.data_ptr(), tuple(light.shape),
+            params, knobs)
+
+
+def render_prepass(depth, mask, light, params: RenderParams = RenderParams(), want_argmin: bool = True, options=None,
+                   stream: Optional[torch.cuda.Stream] = None) -> Prepared:
+    """The FIRST of the forward's two launches on its own (gcfr_options.phase = 1): depth repack, mask statistics, depth
+    bounds, horizon tables, light preparation, sample-table check -- everything that depends on depth (B,H,W), mask (B|1,H,W)
+    and light (B,L,3) only.  Enqueued on `stream` (default: the device's side stream) behind whatever the CURRENT stream
+    has enqueued so far, so that it runs under the work the caller enqueues next on the current stream (RelightNet.forward:
+    the albedo decoder's convolutions, T8:226-290).  Pass the result as `prepared=` to render_fwd / render_from_depth with the
+    same depth, mask, light, params, want_argmin and options: that call waits for the prepass and enqueues the march alone.
+    Bit-identical to the one-call form (the same two launches with the same arguments)."""
+    _require_device(depth, mask, light)
+    want_argmin, options = _pixels_options(params, want_argmin, options)
+    L_ = _lib.load()
+    depth = _f32c(depth)
+    B, H, W = depth.shape
+    dev = depth.device
+    mask_u8 = mask_to_u8(mask).reshape(-1, H, W)
+    light = _f32c(light).reshape(B, -1, 3)
+    L = light.shape[1]
+    tt = sample_table(params, dev)
+    p = Prepared()
+    p.depth, p.mask_u8, p.light = depth, mask_u8, light          # (kept alive until the march has been enqueued)
+    p.unit = torch.empty((B, L, 3), dtype=torch.float32, device=dev)
+    p.pt = torch.empty((B, L, 3), dtype=torch.float32, device=dev)
+    p.ws_bytes = int(L_.gcfr_shadow_workspace_bytes(B, H, W))
+    p.ws = torch.empty(p.ws_bytes, dtype=torch.uint8, device=dev)
+    p.key = _prepass_key(depth, mask_u8, light, params, options)
+    box = ctypes_float4(params.bonus_box) if params.bonus_box is not None else None
+    clamp = params.clamp_light_z_min is not None
+    side = stream if stream is not None else side_stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))              # depth / light are produced on the current stream
+    opt1 = _lib.with_phase(options, 1)
+    with torch.cuda.device(dev), torch.cuda.stream(side):
+        _lib.check(L_.gcfr_render_fwd(
+            light.data_ptr(), int(clamp), float(params.clamp_light_z_min or 0.0), float(params.light_distance),
+            depth.data_ptr(), mask_u8.data_ptr(), mask_u8.shape[0], None, None, None, B, L, H, W, params.n_samples,
+            tt.data_ptr(), float(params.inside_bonus), box, float(params.directional_intensity), p.unit.data_ptr(),
+            p.pt.data_ptr(), None, None, None, None, None, None, p.ws.data_ptr(), p.ws_bytes, side.cuda_stream,
+            _lib.opt_ref(opt1)), "gcfr_render_fwd (prepass)")
+        p.event = torch.cuda.Event()
+        p.event.record(side)
+    return p
+
+
 def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParams = RenderParams(),
-               want_argmin: bool = True, camera=None, options=None):
+               want_argmin: bool = True, camera=None, options=None, prepared: Optional[Prepared] = None):
     """One enqueue for the whole forward block (gcfr_render_fwd): light prep, depth repack, ray march with
     the shading fused into its epilogue.  depth (B,H,W), mask (B|1,H,W), light (B,L,3) raw/target,
     ambient (B,L), normals/albedo (B,3,H,W).  Returns a dict of f32 tensors (B,L,...).
     normals=None with camera=(fx, fy, cx, cy, z_offset): the normals stage (T8:353-354) is fused into the
-    epilogue as well (gcfr_render_from_depth_fwd); the dict then also carries "surface_normals"."""
+    epilogue as well (gcfr_render_from_depth_fwd); the dict then also carries "surface_normals".
+    `options`: a `_lib.Options`; only `pixels` changes a result bit, and `params.pixels = "mask"` forces the argmin plane (see
+    shadow_min_distance).  `prepared`: the result of `render_prepass()` on the same depth / mask / light / params / options --
+    the prepass has been enqueued already (side stream), this call waits for it and enqueues the march only."""
     _require_device(depth, mask, light, ambient, albedo)
     if normals is None and camera is None:
         raise _lib.GcfrError("render_fwd needs either normals or camera=(fx, fy, cx, cy, z_offset)")
@@ -181,23 +261,35 @@ def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParam
     mask_u8 = mask_to_u8(mask).reshape(-1, H, W)
     light = _f32c(light).reshape(B, -1, 3)
     L = light.shape[1]
-    ambient = _f32c(ambient).reshape(B, L)
+    if prepared is not None:
+        # the march reads the very tensors the prepass read (its f32 / u8 copies where the caller's were converted)
+        if tuple(prepared.depth.shape) != (B, H, W) or tuple(prepared.light.shape) != (B, L, 3) or \
+                tuple(prepared.mask_u8.shape) != tuple(mask_u8.shape):
+            raise _lib.GcfrError("render_fwd(prepared=...): shapes differ from the prepass call's")
+        depth, mask_u8, light = prepared.depth, prepared.mask_u8, prepared.light
+        if prepared.key != _prepass_key(depth, mask_u8, light, params, options):
+            raise _lib.GcfrError("render_fwd(prepared=...): params / options differ from the prepass call's")
     if normals is not None:
         _require_device(normals)
         normals = _f32c(normals).reshape(B, 3, H, W)
     albedo = _f32c(albedo).reshape(B, 3, H, W)
     tt = sample_table(params, dev)
     f32 = dict(dtype=torch.float32, device=dev)
-    unit = torch.empty((B, L, 3), **f32)
-    pt = torch.empty((B, L, 3), **f32)
     md = torch.empty((B, L, H, W), **f32)
     am = torch.empty((B, L, H, W), dtype=torch.int32, device=dev) if want_argmin else None
     w = torch.empty((B, L, H, W), **f32)
     full = torch.empty((B, L, H, W), **f32)
     fin = torch.empty((B, L, H, W), **f32)
     ren = torch.empty((B, L, 3, H, W), **f32)
-    ws_bytes = int(L_.gcfr_shadow_workspace_bytes(B, H, W))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    if prepared is None:
+        unit = torch.empty((B, L, 3), **f32)
+        pt = torch.empty((B, L, 3), **f32)
+        ws_bytes = int(L_.gcfr_shadow_workspace_bytes(B, H, W))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    else:
+        unit, pt, ws, ws_bytes = prepared.unit, prepared.pt, prepared.ws, prepared.ws_bytes
+        torch.cuda.current_stream(dev).wait_event(prepared.event)     # the march starts behind the prepass
+        options = _lib.with_phase(options, 2)
     box = ctypes_float4(params.bonus_box) if params.bonus_box is not None else None
     clamp = params.clamp_light_z_min is not None
     out = dict(unit_light_direction=unit, light_pt=pt, minimum_distance=md, argmin=am, shadow_mask_weights=w,
@@ -417,9 +509,35 @@ class RenderFwdPlan:
         self.graph.replay()
         return self.out
 
-    def __call__(self, depth, mask_u8, light, ambient, normals, albedo):
+    def capture_split(self, depth, mask_u8, light, ambient, normals, albedo):
+        """The two launches as two hipGraphs (gcfr_options.phase 1 / 2): `replay_prepass()` -- on whatever stream is current,
+        typically a side stream, as soon as depth, mask and light are in the captured tensors -- and `replay_march()` behind it
+        (the caller orders the two: same stream or an event).  The same bits as `replay()`."""
+        self._static = (depth, mask_u8, light, ambient, normals, albedo)
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            self(*self._static)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self.graph_pre, self.graph_march = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_pre):
+            self(*self._static, phase=1)
+        with torch.cuda.graph(self.graph_march):
+            self(*self._static, phase=2)
+        return self
+
+    def replay_prepass(self):
+        self.graph_pre.replay()
+
+    def replay_march(self):
+        self.graph_march.replay()
+        return self.out
+
+    def __call__(self, depth, mask_u8, light, ambient, normals, albedo, phase: int = 0):
         """depth (B,H,W) f32, mask_u8 (B|1,H,W) u8, light (B,L,3) f32, ambient (B,L) f32, albedo (B,3,H,W) f32,
-        normals (B,3,H,W) f32 or None (plan built with camera=...).  All contiguous, on the plan's device."""
+        normals (B,3,H,W) f32 or None (plan built with camera=...).  All contiguous, on the plan's device.
+        phase: 0 both launches; 1 the prepass only; 2 the march only (gcfr_options.phase)."""
         # (the checks cost ~14 us of host time: once per set of buffers, not per call.  The key is what the kernels
         # actually consume -- address, shape, dtype, device -- so a new tensor that happens to reuse a Python id,
         # or a tensor whose storage was reassigned, is validated again.)
@@ -429,25 +547,27 @@ class RenderFwdPlan:
             self._validate(depth, mask_u8, light, ambient, normals, albedo)
             self._validated = key
         st = torch.cuda.current_stream(self.dev).cuda_stream
+        opts = self.options if phase == 0 else _lib.with_phase(self.options, phase)
         if self.camera is None:
             rc = self.L_.gcfr_render_fwd(light.data_ptr(), *self._head, depth.data_ptr(), mask_u8.data_ptr(),
                                          self.mask_batch, normals.data_ptr(), albedo.data_ptr(), ambient.data_ptr(),
-                                         *self._tail, *self._outs, st, _lib.opt_ref(self.options))
+                                         *self._tail, *self._outs, st, _lib.opt_ref(opts))
         elif self.normals_stage == "kernel":
             fx, fy, cx, cy, z_off = [float(v) for v in self.camera]
             nrm = self.out["surface_normals"]
-            _lib.check(self.L_.gcfr_normals_fwd(depth.data_ptr(), self.shape[0], self.shape[2], self.shape[3], fx, fy, cx, cy, z_off, 1,
-                                                nrm.data_ptr(), st), "gcfr_normals_fwd (plan)")
+            if phase != 1:
+                _lib.check(self.L_.gcfr_normals_fwd(depth.data_ptr(), self.shape[0], self.shape[2], self.shape[3], fx, fy, cx, cy, z_off, 1,
+                                                    nrm.data_ptr(), st), "gcfr_normals_fwd (plan)")
             rc = self.L_.gcfr_render_fwd(light.data_ptr(), *self._head, depth.data_ptr(), mask_u8.data_ptr(),
                                          self.mask_batch, nrm.data_ptr(), albedo.data_ptr(), ambient.data_ptr(),
-                                         *self._tail, *self._outs, st, _lib.opt_ref(self.options))
+                                         *self._tail, *self._outs, st, _lib.opt_ref(opts))
         else:
             fx, fy, cx, cy, z_off = [float(v) for v in self.camera]
             rc = self.L_.gcfr_render_from_depth_fwd(light.data_ptr(), *self._head, depth.data_ptr(),
                                                     mask_u8.data_ptr(), self.mask_batch, fx, fy, cx, cy, z_off, 1,
                                                     albedo.data_ptr(), ambient.data_ptr(), *self._tail,
                                                     self.out["surface_normals"].data_ptr(), *self._outs, st,
-                                                    _lib.opt_ref(self.options))
+                                                    _lib.opt_ref(opts))
         _lib.check(rc, "gcfr_render_fwd (plan)")
         return self.out
 
@@ -458,7 +578,7 @@ class _RenderFromDepthFunction(torch.autograd.Function):
     ray-march and normals-stencil backward fused per pixel) + gcfr_light_prep_bwd."""
 
     @staticmethod
-    def forward(ctx, depth, albedo, light, ambient, mask_u8, cam, params):
+    def forward(ctx, depth, albedo, light, ambient, mask_u8, cam, params, prepared=None):
         B, _, H, W = depth.shape
         depth3 = _f32c(depth).reshape(B, H, W)
         light2 = _f32c(light).reshape(B, 3)
@@ -466,7 +586,9 @@ class _RenderFromDepthFunction(torch.autograd.Function):
         albedo_c = _f32c(albedo)
         need_grad = any(ctx.needs_input_grad[:4])
         o = render_fwd(depth3, mask_u8, light2.reshape(B, 1, 3), amb, None, albedo_c, params,
-                       want_argmin=need_grad, camera=cam)
+                       want_argmin=need_grad, camera=cam, prepared=prepared)
+        if prepared is not None:
+            depth3, light2 = prepared.depth, prepared.light.reshape(B, 3)     # (what the kernels read: saved for the backward)
         ctx.params, ctx.cam = params, cam
         if need_grad:
             ctx.save_for_backward(depth3, albedo_c, light2, amb, o["light_pt"].reshape(B, 3), o["minimum_distance"],
@@ -505,7 +627,7 @@ class _RenderFromDepthFunction(torch.autograd.Function):
             _lib.check(L_.gcfr_light_prep_bwd(light2.data_ptr(), B, int(clamp), float(prm.clamp_light_z_min or 0.0),
                                               float(prm.light_distance), _opt_ptr(gu), grad_pt.data_ptr(),
                                               grad_light.data_ptr(), st), "gcfr_light_prep_bwd")
-        return (grad_depth.reshape(B, 1, H, W), grad_albedo, grad_light, grad_amb.reshape(B).float(), None, None, None)
+        return (grad_depth.reshape(B, 1, H, W), grad_albedo, grad_light, grad_amb.reshape(B).float(), None, None, None, None)
 
 
 _CAMERA_CACHE = {}      # id(tensor) -> (weakref to the tensor, its in-place version, scalars)
@@ -538,12 +660,28 @@ def camera_scalars(camera_matrix: torch.Tensor):
     return scalars
 
 
+def render_from_depth_prepass(depth, light, camera_matrix, mask, params: RenderParams = RenderParams()):
+    """The prepass of the `render_from_depth()` call that is about to follow, enqueued NOW on the device's side stream (see
+    `render_prepass`): call it as soon as depth (B,1,H,W), light (B,3) and the mask exist -- in RelightNet.forward that is
+    before the albedo decoder runs -- and hand the result to `render_from_depth(..., prepared=...)`.  Returns None where the
+    one-call form has to be used (per-image camera matrices: the three-stage path).  (Whether the march will track the argmin
+    -- autograd or not -- does not concern the prepass.)"""
+    B, _, H, W = depth.shape
+    if camera_scalars(camera_matrix) is None:
+        return None
+    _require_device(depth, light, mask)
+    mask_u8 = mask_to_u8(mask).reshape(-1, H, W)
+    return render_prepass(depth.reshape(B, H, W), mask_u8, light.reshape(B, 1, 3), params)
+
+
 def render_from_depth(depth, albedo, light, ambient, camera_matrix, z_offset, mask,
-                      params: RenderParams = RenderParams()):
+                      params: RenderParams = RenderParams(), prepared: Optional[Prepared] = None):
     """The whole T8:353-522 seam for one light per image: normals from depth, shading, ray march, composite.
     Two launches forward (`gcfr_render_from_depth_fwd`: prepass, march with normals + shading in its epilogue) and,
     with autograd active, one fused backward launch (`gcfr_render_bwd`) plus the tiny light-prep backward.
-    Same dict as `render()` plus "surface_normals" (unit, y negated)."""
+    Same dict as `render()` plus "surface_normals" (unit, y negated).
+    `prepared`: the result of `render_from_depth_prepass()` on the same depth / light / mask / params: the prepass is already
+    on its way on the side stream and this call enqueues the march only (bit-identical)."""
     from .normals import depth_to_normals
     B, _, H, W = depth.shape
     needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (depth, albedo, light, ambient))
@@ -558,13 +696,13 @@ def render_from_depth(depth, albedo, light, ambient, camera_matrix, z_offset, ma
         _require_device(depth, albedo, light, ambient, mask)
         mask_u8 = mask_to_u8(mask).reshape(-1, H, W)
         w, full, fin, ren, unit, nrm, md = _RenderFromDepthFunction.apply(
-            depth, albedo, light.reshape(B, 3), ambient.reshape(B), mask_u8, cam, params)
+            depth, albedo, light.reshape(B, 3), ambient.reshape(B), mask_u8, cam, params, prepared)
         amb = ambient.to(torch.float32).reshape(B, 1, 1)
         return dict(shadow_mask_weights=w, ambient_light=amb.expand(B, H, W), full_shading=full, rendered_images=ren,
                     unit_light_direction=unit.reshape(B, 3, 1, 1), ambient_values=amb, final_shading=fin,
                     minimum_distance=md, surface_normals=nrm)
     o = render_fwd(depth.reshape(B, H, W), mask.reshape(-1, H, W), light.reshape(B, 1, 3), ambient.reshape(B, 1),
-                   None, albedo, params, want_argmin=False, camera=cam)
+                   None, albedo, params, want_argmin=False, camera=cam, prepared=prepared)
     amb = ambient.detach().to(torch.float32).reshape(B, 1, 1)
     return dict(shadow_mask_weights=o["shadow_mask_weights"][:, 0], ambient_light=amb.expand(B, H, W),
                 full_shading=o["full_shading"][:, 0], rendered_images=o["rendered_images"][:, 0],

@@ -19,6 +19,7 @@ constexpr float kMaskedDistance = 1000000.0f;  // T8:512
 // drop writes, so a corrupted index can never fault the GPU.
 constexpr int kBufferRsrcWord3 = 0x00020000;
 
+// census: tile set-up: lane, pixel, descriptors, light, own depth
 __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void *p, int bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, kBufferRsrcWord3);
@@ -32,6 +33,7 @@ __device__ inline uint32_t buf_load_u8(__amdgpu_buffer_rsrc_t r, int byte_off)
     return __builtin_amdgcn_raw_buffer_load_b8(r, byte_off, 0, 0);
 }
 
+// census: end point (T8:378-465) + ray constants
 // Image box in image-plane coordinates (T8:386-387, 416, 399).
 struct Box {
     float x_lo, x_hi, y_lo, y_hi;
@@ -94,12 +96,31 @@ __device__ inline void end_point(float x, float y, float Cx, float Cy, const Box
     Ey = ey;
 }
 
+// census: epilogue: distance finish, tie, masked value, bonus
+// sqrt(x), correctly rounded (== __builtin_sqrtf, bit for bit), for x >= 2^-96, +inf or NaN: the compiler's own IEEE expansion
+// (v_sqrt_f32, then the two neighbouring floats tried with an fma residual each) WITHOUT the parts that serve inputs the march's
+// epilogue cannot produce -- the 2^32 pre-scaling of denormal-range arguments and its undoing, the 0 / inf class test: 9
+// instructions instead of 19.  The arguments there are S + 1e-4 and |BC|^2 + 1e-4 (T8:509, 508).  tests/test_gpu_sqrt_rn.py
+// compares it with __builtin_sqrtf over EVERY float of that domain.
+__device__ inline float sqrt_rn_normal(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const int si = __builtin_bit_cast(int, s);
+    const float s_dn = __builtin_bit_cast(float, si - 1), s_up = __builtin_bit_cast(float, si + 1);
+    const float e_dn = __builtin_fmaf(-s_dn, s, x), e_up = __builtin_fmaf(-s_up, s, x);
+    float o = (e_dn <= 0.0f) ? s_dn : s;
+    o = (e_up > 0.0f) ? s_up : o;
+    return o;
+}
+
+// census: epilogue: shading: norms (norm3_torch)
 // torch's vector 2-norm accumulates acc = fma(v, v, acc) (probed; see oracle/gcfr_oracle.c).
 __device__ inline float norm3_torch(float a, float b, float c)
 {
     return __builtin_sqrtf(__builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a)));
 }
 
+// census: epilogue: shading: shadow transfer (expf, division; T8:517)
 // T8:517: w = 1 - 4 e^-d / (1 + e^-d)^2   (== tanh^2(d/2)); evaluated as written, in f32.
 __device__ inline float shadow_transfer(float d)
 {
@@ -108,30 +129,43 @@ __device__ inline float shadow_transfer(float d)
     return (-4.0f * e) / (onepe * onepe) + 1.0f;
 }
 
+// census: epilogue: shading: Lambert dot (six divisions; T8:364-366)
 // Shading of one pixel for one light, T8:364-369 and 517-518 (shared by the stand-alone shade kernel
 // and the fused epilogue of the march kernel so that both produce the same bits).
 struct Shaded {
     float w, full, fin;
 };
-// n_hat . l_hat of one pixel and one light, T8:364-366 -- the forward's own arithmetic (separately rounded, IEEE divisions).
+// n_hat . l_hat of one pixel and one light, T8:364-366 -- the forward's own arithmetic (separately rounded products and sums).
 // Also called by the backward kernels where their fast evaluation of the same quantity comes out within 1e-4 of zero: the
 // Lambert term max(n.l, 0) has a kink there, and which side of it a pixel is on must be the FORWARD's decision (round 3: a
 // randomised soak found one pixel in 6000 cases where the multi-light backward's reciprocal-based dot had the other sign than
 // the forward's -- a gradient flowed through a term the forward had clamped to zero).
+// 1 / max(|v|, 1e-12) of a 3-vector (F.normalize's denominator, T8:364-365): v_rsq_f32 (1 ulp) and one Newton step instead of
+// an IEEE square root (19 instructions) and, per component, an IEEE division (11): round 5's census counted 110 VALU
+// instructions per pixel for the two normalisations of lambert_dot(), a seventh of the march's per-tile fixed cost.  The unit
+// vector's components come out within ~1 ulp of the exactly rounded quotient (the reference's own sqrt-then-divide is within ~1
+// ulp as well); shading is compared under tolerances (full_shading <= 1e-5 against the golden cases), never bit for bit.
+// (|v|^2 overflowing to +inf -- |v| > 1.8e19 -- gives NaN where sqrt-then-divide gives 0; no light or normal is that long.)
+__device__ inline float inv_norm3_clamped(float a, float b, float c)
+{
+    const float s2 = __builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a));  // torch's accumulation order (norm3_torch)
+    const float r = __builtin_amdgcn_rsqf(s2);
+    const float r1 = r * __builtin_fmaf(-0.5f * s2 * r, r, 1.5f);  // Newton: r (3 - s2 r^2) / 2
+    return s2 > 1e-24f ? r1 : 1e12f;                                 // |v| <= 1e-12 (or NaN): the clamp
+}
 __device__ inline float lambert_dot(float x, float y, float zb, float nx, float ny, float nz, float Cx, float Cy, float Cz)
 {
     // incident light direction, T8:364
     const float lx = Cx - x, ly = Cy - y, lz = Cz - zb;
-    float ln = norm3_torch(lx, ly, lz);
-    ln = ln > 1e-12f ? ln : 1e-12f;
-    const float ux = lx / ln, uy = ly / ln, uz = lz / ln;
+    const float rl = inv_norm3_clamped(lx, ly, lz);
+    const float ux = lx * rl, uy = ly * rl, uz = lz * rl;
     // surface normal, re-normalised (T8:365)
-    float nn = norm3_torch(nx, ny, nz);
-    nn = nn > 1e-12f ? nn : 1e-12f;
-    const float n0 = nx / nn, n1 = ny / nn, n2 = nz / nn;
+    const float rn = inv_norm3_clamped(nx, ny, nz);
+    const float n0 = nx * rn, n1 = ny * rn, n2 = nz * rn;
     return (n0 * ux + n1 * uy) + n2 * uz;  // T8:366
 }
 
+// census: epilogue: shading: combine (T8:366-369, 518)
 __device__ inline Shaded shade_pixel(float x, float y, float zb, float nx, float ny, float nz, float Cx,
                                      float Cy, float Cz, float amb, float intensity, float min_dist)
 {
@@ -143,6 +177,7 @@ __device__ inline Shaded shade_pixel(float x, float y, float zb, float nx, float
     return o;
 }
 
+// census: epilogue: normals stencil (T8:353-354)
 // ---- surface normals from depth (kornia 0.4.1 restatement; see gcfr_normals.hip for the algorithm) ----
 struct NormalsArgs {
     const float *depth;  // (B,H,W)
@@ -245,19 +280,63 @@ __device__ inline Grad3 point_gradients(const NormalsArgs &a, const float *z, in
     return g;
 }
 
+// 1/sqrt(x) to ~1 ulp of f64 in 5 instructions: v_rsq_f64 seed (about 2^-26) and one Newton step.  x normal and > 0.
+__device__ inline double fast_rsqrt64(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y, h = 0.5 * y;
+    return __builtin_fma(y, __builtin_fma(-h, g, 0.5), y);
+}
+
 // Unit normal of pixel (r,c) as f32, y negated if requested (T8:353-354) -- shared by normals_fwd_kernel, the march
-// kernel's fused epilogue and the backward kernels' recomputation.  |n| by v_rsq_f64 + Newton and one reciprocal
-// instead of an IEEE sqrt and three IEEE divisions (~1 ulp of f64 each, then rounded to f32).
+// kernel's fused epilogue and the backward kernels' recomputation of the forward's normal.
+//
+// Round 5 (census: 168 VALU instructions per pixel, 106 of them f64 -- a quarter of the march's per-tile fixed cost): the same
+// normal from a fifth of the f64 work.  With D = depth + offset (f32, T8:353), e_ij = D_ij - D_11 the eight neighbours'
+// DIFFERENCES to the centre, a = dZ/du, b = dZ/dv (Sobel / 8 of D), r = (ax, ay, 1) the pixel's own ray and ax_j = ax +- 1/fx,
+// ay_i = ay +- 1/fy the neighbours' (replicate padding: the neighbour IS the pixel, "+- 0"), the point gradients are
+//     dP/du = a r + p,   p = (px, py, 0),   px = [D_11 (wr + wl)/2 + (wr er + wl el)/8] / fx,   py = (wd h_2 - wu h_0) / (8 fy)
+//     dP/dv = b r + q,   q = (qx, qy, 0),   qx = (wr g_2 - wl g_0) / (8 fx),   qy = [D_11 (wd + wu)/2 + (wd eb + wu et)/8] / fy
+// (h_i = e_i2 - e_i0, g_j = e_2j - e_0j, er / el / eb / et the Sobel-weighted sums of the right / left column and bottom / top
+// row of e, w* = 1 where that neighbour exists, 0 at the image's edge), so that
+//     n = dP/du x dP/dv = r x (a q - b p) + p x q = (-my, mx, ax my - ay mx + px qy - py qx),   m = a q - b p,
+// with the large common term a b (r x r) gone algebraically instead of cancelling numerically.  The differences and their small
+// sums are f32: D_ij - D_11 is EXACT whenever the two are within a factor of two of each other (Sterbenz) -- every depth map
+// with the reference's offset of 1610 in front of it -- and so are the sums while they stay below |D_11| / 8; everything after
+// them is f64 as before.  Against the f64 restatement (oracle/normals_restatement.py): <= 0.5 f32 ulp on face-like and on
+// noisy depth (amplitude 400), <= 3 ulp with an offset as small as the depth's own range; where neighbouring values differ by
+// more than a factor of two the differences carry f32 rounding (relative 6e-8 of the DIFFERENCE: a perturbation of the
+// surface, not of the normal's digits).  A non-finite cell poisons the same pixels as the convolution's taps do: every
+// neighbour is part of a or of b, the centre of every e.
 __device__ inline void unit_normal(const NormalsArgs &a, const float *z, int r, int c, float (&n)[3])
 {
-    const Grad3 g = point_gradients(a, z, r, c);
-    const double nx = __builtin_fma(g.du[1], g.dv[2], -(g.du[2] * g.dv[1]));
-    const double ny = __builtin_fma(g.du[2], g.dv[0], -(g.du[0] * g.dv[2]));
-    const double nz = __builtin_fma(g.du[0], g.dv[1], -(g.du[1] * g.dv[0]));
+    const int W = a.W;
+    const bool has_l = c > 0, has_r = c < W - 1, has_u = r > 0, has_d = r < a.H - 1;
+    const float *z1 = z + (size_t)r * W + c;
+    const int ol = has_l ? -1 : 0, orr = has_r ? 1 : 0, ou = has_u ? -W : 0, od = has_d ? W : 0;
+    const float off = a.z_offset;
+    const float D11 = z1[0] + off;  // depth + 1610 in f32 (T8:353)
+    const float e00 = (z1[ou + ol] + off) - D11, e01 = (z1[ou] + off) - D11, e02 = (z1[ou + orr] + off) - D11;
+    const float e10 = (z1[ol] + off) - D11, e12 = (z1[orr] + off) - D11;
+    const float e20 = (z1[od + ol] + off) - D11, e21 = (z1[od] + off) - D11, e22 = (z1[od + orr] + off) - D11;
+    const float h0 = e02 - e00, h1 = e12 - e10, h2 = e22 - e20;
+    const float g0 = e20 - e00, g1 = e21 - e01, g2 = e22 - e02;
+    const float a8 = __builtin_fmaf(2.0f, h1, h0 + h2), b8 = __builtin_fmaf(2.0f, g1, g0 + g2);  // (2 h exact: the fma rounds once, as the sum would)
+    const float er = __builtin_fmaf(2.0f, e12, e02 + e22), el = __builtin_fmaf(2.0f, e10, e00 + e20);
+    const float eb = __builtin_fmaf(2.0f, e21, e20 + e22), et = __builtin_fmaf(2.0f, e01, e00 + e02);
+    const float s_x = (has_r ? er : 0.0f) + (has_l ? el : 0.0f), s_y = (has_d ? eb : 0.0f) + (has_u ? et : 0.0f);
+    const float v_y = (has_d ? h2 : 0.0f) - (has_u ? h0 : 0.0f), v_x = (has_r ? g2 : 0.0f) - (has_l ? g0 : 0.0f);
+    const float Dx = (has_l && has_r) ? D11 : 0.5f * D11, Dy = (has_u && has_d) ? D11 : 0.5f * D11;  // (H, W >= 2: one side always exists)
+    const double inv_fx = a.inv_fx, inv_fy = a.inv_fy;
+    const double px = inv_fx * __builtin_fma(0.125, (double)s_x, (double)Dx), py = (0.125 * inv_fy) * (double)v_y;
+    const double qx = (0.125 * inv_fx) * (double)v_x, qy = inv_fy * __builtin_fma(0.125, (double)s_y, (double)Dy);
+    const double da = 0.125 * (double)a8, db = 0.125 * (double)b8;
+    const double mx = __builtin_fma(da, qx, -(db * px)), my = __builtin_fma(da, qy, -(db * py));
+    const double ax = ((double)c - a.cx) * inv_fx, ay = ((double)r - a.cy) * inv_fy;
+    const double nx = -my, ny = mx;
+    const double nz = __builtin_fma(ax, my, -(ay * mx)) + __builtin_fma(px, qy, -(py * qx));
     const double n2sum = __builtin_fma(nz, nz, __builtin_fma(ny, ny, nx * nx));
-    double nn = n2sum > 1e-24 ? fast_sqrt64(n2sum) : 1e-12;  // (NaN: 1e-12, and the products below stay NaN)
-    nn = nn > 1e-12 ? nn : 1e-12;
-    const double inv = fast_rcp64(nn);
+    const double inv = n2sum > 1e-24 ? fast_rsqrt64(n2sum) : 1e12;  // 1 / max(|n|, 1e-12)  (NaN: 1e12, and the products below stay NaN)
     n[0] = (float)(nx * inv);
     n[1] = (float)(a.negate_y ? -(ny * inv) : (ny * inv));  // T8:354
     n[2] = (float)(nz * inv);

@@ -10,6 +10,7 @@
 #pragma once
 
 #include "gcfr_device.hpp"
+#include "gcfr_mutants.hpp"
 
 #include "../../include/gcfr.h"
 
@@ -44,6 +45,7 @@ struct RayConst {
     int H, W;
 };
 
+// census: tie re-march (plain sample)
 __device__ inline float ray_sample(const RayConst &rc, double t, __amdgpu_buffer_rsrc_t zr,
                                    __amdgpu_buffer_rsrc_t mr, bool &masked)
 {
@@ -142,6 +144,7 @@ constexpr int kBBoxInit = 0x7f7f7f7f;  // "+infinity" for the int minima below
 // VALU-speed steps instead of six dependent ds_bpermute round trips (__shfl_xor) in the kernels'
 // latency-bound prologues (measured: fixed cost of the march at B=8 20.5 -> 19.5 us; LDS atomics instead
 // were 2.4x worse).
+// census: wave reductions (DPP)
 template <int CTRL, int ROW_MASK>
 __device__ inline int dpp_min_step(int v)
 {
@@ -180,6 +183,7 @@ __device__ inline float f32_unsortable(int i)
 // group of `group` consecutive samples can touch, derived from the sample table on the device by both
 // kernels.  The host sizes the grid for s = 8.
 // ----------------------------------------------------------------------------------------------
+// census: bounds grid stride
 template <class TablePtrT>
 __device__ inline int zb_log2_stride(int H, int W, int N, TablePtrT t_table, int group, bool *fits = nullptr)
 {
@@ -191,7 +195,7 @@ __device__ inline int zb_log2_stride(int H, int W, int N, TablePtrT t_table, int
     // rint(s) moves by <= floor(fd) + 1 cells over a group (1.002: the table may deviate 0.1 % from uniform, see
     // the prepass' table check, plus the f32 roundings here)
     const float fd = (float)(group - 1) * step * (float)max(H, W) * 1.002f;
-    const int need = (int)fminf(fmaxf(fd, 0.0f), 1024.0f) + 3;      // + the cell either side (floor / ceil)
+    const int need = (int)fminf(fmaxf(fd, 0.0f), 1024.0f) + GCFR_M(22, 1, 3);      // + the cell either side (floor / ceil)
     int ls = 3;
     while ((1 << ls) < need && ls < 5)  // capped at 32: coarser tiles bound nothing (their footprints fail the coverage test)
         ++ls;
@@ -222,6 +226,7 @@ __host__ __device__ inline bool hz_shape_ok(int H, int W) { return ((W & 3) == 0
 __host__ __device__ inline int zb_slot(int H, int W) { return hz_shape_ok(H, W) ? zb_stride(H, W) + 4 * kHorizonDim : zb_stride(H, W); }
 
 // Sum over each 16-lane row of the wave, result in every lane of the row's last lane ... read with readlane(row*16+15).
+// census: wave reductions (DPP)
 __device__ inline float row_sum_f32(float v)
 {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
@@ -318,6 +323,7 @@ __device__ __forceinline__ T launder(T p)
 constexpr double kRintMagic = 6755399441055744.0;  // 2^52 + 2^51
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// census: rint magic (lo32)
 __device__ inline int lo32(double v)
 {
     return (int)(unsigned)(__builtin_bit_cast(unsigned long long, v) & 0xffffffffull);
@@ -336,6 +342,7 @@ static_assert(kCntUsed <= GCFR_N_COUNTERS, "gcfr_options.counters holds GCFR_N_C
 #endif
 
 // Per-image statistics, wave-uniform: the reduction of the prepass' partial records (build_stats_block).
+// census: image statistics (reduce_image_stats)
 struct ImageStats {
     int r_min, c_min, r_max, c_max;  // bounding box of the mask's non-zero cells (r_min == kBBoxInit: none)
     int s_min, s_max, d_min, d_max;  // ... and their diagonal extents: c + r and c - r (the bounding octagon)
@@ -453,6 +460,7 @@ extern __shared__ uint4 gcfr_lds_stage[];
 // 1-KiB pieces, piece i by wave i mod 4, each ONE global_load_lds_dwordx4 -- global -> LDS without passing through
 // registers, issued at kernel entry and awaited by the workgroup barrier in front of the sample loop, so the copy runs
 // behind the tile prologue's ~750 instructions.
+// census: LDS staging
 __device__ inline void stage_lds(ArgPtr a, int b, bool with_bitmap)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -472,6 +480,7 @@ __device__ inline void stage_lds(ArgPtr a, int b, bool with_bitmap)
     }
 }
 // lane id from the hardware (two VALU), opaque to the optimiser: a value derived from it has no live range before this point
+// census: tile set-up: lane, pixel, descriptors, light, own depth
 __device__ inline int fresh_lane_id()
 {
     int l;
@@ -512,6 +521,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
     static_assert(SPLIT == 0 || SPLIT == 1, "SPLIT: 0 = one wave per tile, 1 = the workgroup's four waves split the sample range");
     static_assert(!(LDS && SPLIT != 0), "the LDS-staged march is a throughput variant: one wave per tile");
     static_assert(!(OWN && (LDS || SPLIT != 0 || ALL_ONES)), "pixels = mask: the grid schedule's global-memory variant only");
+// census: tile set-up: lane, pixel, descriptors, light, own depth
     const int H = a->H, W = a->W, L = a->L;
     // Wave-uniform read-only inputs are read through the CONSTANT address space: in the persistent schedule the
     // previous tile's stores and the queue atomic precede these loads in program order, so through a plain global
@@ -572,7 +582,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
 
     // OWN: this lane's pixel is outside the mask (or outside the image): not marched.  Carried by `lane_last` = -1 from the
     // candidate range on (no register of its own): a lane without a candidate sample has only masked samples either way.
-    const bool own_off = OWN && (!valid || (buf_load_u8(mr, __mul24(r, W) + c) == 0));
+    const bool own_off = OWN && (GCFR_M(17, false, !valid) || (buf_load_u8(mr, __mul24(r, W) + c) == 0));
 
     const ConstF32Ptr lp = (ConstF32Ptr)(unsigned long long)a->light_pt;
     const float Cx = lp[3 * bl + 0], Cy = lp[3 * bl + 1], Cz = lp[3 * bl + 2];
@@ -584,6 +594,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
 
     const float x = (float)c - halfWf, y = halfHf - (float)r;
     const float zb = a->depth[(size_t)b * P + (size_t)r * W + c];
+// census: end point (T8:378-465) + ray constants
     float Ex, Ey;
     end_point(x, y, Cx, Cy, box, lc, Ex, Ey);
     const float dxf = Ex - x, dyf = Ey - y;
@@ -595,6 +606,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
     const double Mx = EVEN_HALF ? kRintMagic + halfW : kRintMagic;
     const double My = EVEN_HALF ? kRintMagic + halfH : kRintMagic;
     const int quad_origin = (Wp + 1) << 4;  // byte offset of texel (r=0, c=0)
+// census: give-up test (incl. nrm, c1)
     const ConstI32Ptr tfl = (ConstI32Ptr)(unsigned long long)a->tflag;  // the prepass' record about the sample table (scalar loads)
     const bool t_increasing = (a->N >= 2) && (tfl[kTfOk] != 0);  // checked by the prepass (see its table check)
     bool use_zb = !ROUGH && (a->zb != nullptr) && t_increasing;
@@ -603,8 +615,11 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
     const int zrec = tfl[kTfStride];
     const int zls = use_zb ? (zrec & 0xff) : 3;
     const int zntw = (W >> zls) + 1;
-    const float nrm = __builtin_sqrtf(BCx * BCx + BCy * BCy);
-    const float c1 = BCz * ((dxf * BCx + dyf * BCy) / nrm);
+    // (v_sqrt_f32 / v_rcp_f32, 1 ulp each: n and c1 only ever enter the BOUNDS -- the give-up heuristic, Kerr, the skip and the
+    //  termination tests -- whose error terms K1 = ... + 1e-6 |c1| t and K2 r = (1e-6 n + ...) r budget sixteen ulp for each; the
+    //  IEEE square root and division cost 27 instructions more per tile, round 5's census)
+    const float nrm = __builtin_amdgcn_sqrtf(BCx * BCx + BCy * BCy);
+    const float c1 = BCz * ((dxf * BCx + dyf * BCy) * __builtin_amdgcn_rcpf(nrm));
     // (round 4: the give-up test sits in FRONT of the candidate-range computation -- a tile that hands itself to the rough
     //  variant has then paid for the end point and this test only, not for the box / octagon clipping it would do twice)
     const float t_abs = __builtin_bit_cast(float, tfl[kTfTabs]);  // max(|tt[0]|, |tt[N-1]|)
@@ -631,6 +646,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         }
     }
 
+// census: candidate range: box + octagon clip, wave reductions
     float bestS = __builtin_inff();
     int besti = -1;
     float prevS = __builtin_inff();  // the running minimum replaced last (distance-tie resolution, see epilogue)
@@ -654,8 +670,8 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         const int r_min = st.r_min, c_min = st.c_min, r_max = st.r_max, c_max = st.c_max;
         int lane_lo = a->N, lane_hi = -1;  // empty
         if (r_min != kBBoxInit && !(OWN && own_off)) {
-            const float X0 = (float)c_min - halfWf - 0.51f, X1 = (float)c_max - halfWf + 0.51f;
-            const float Y0 = halfHf - (float)r_max - 0.51f, Y1 = halfHf - (float)r_min + 0.51f;
+            const float X0 = (float)c_min - halfWf - GCFR_M(1, 0.49f, 0.51f), X1 = (float)c_max - halfWf + GCFR_M(1, 0.49f, 0.51f);
+            const float Y0 = halfHf - (float)r_max - GCFR_M(1, 0.49f, 0.51f), Y1 = halfHf - (float)r_min + GCFR_M(1, 0.49f, 0.51f);
             float ta = -3.0e38f, tb = 3.0e38f;
             bool empty = !finite_ray;
             // (v_rcp_f32, 1 ulp: the 0.01-pixel margin dwarfs it; four IEEE divisions cost ~50 VALU per wave)
@@ -680,8 +696,8 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             // an elliptical mask the octagon cuts four fifths of the box's corners: -18 % visited groups (tools/sim_octagon.py).
             if (st.mask_all_ones == 0) {  // (wave-uniform; an all-ones mask's octagon is its box)
                 const float hs = 0.5f * (float)(W + H), hd = 0.5f * (float)(W - H);
-                const float U0 = (float)st.s_min - hs - 1.02f, U1 = (float)st.s_max - hs + 1.02f;
-                const float V0 = (float)st.d_min - hd - 1.02f, V1 = (float)st.d_max - hd + 1.02f;
+                const float U0 = (float)st.s_min - hs - GCFR_M(2, 0.98f, 1.02f), U1 = (float)st.s_max - hs + GCFR_M(2, 0.98f, 1.02f);
+                const float V0 = (float)st.d_min - hd - GCFR_M(2, 0.98f, 1.02f), V1 = (float)st.d_max - hd + GCFR_M(2, 0.98f, 1.02f);
                 const float u = x - y, du = dxf - dyf, v = x + y, dv = dxf + dyf;
                 if (du != 0.0f) {
                     const float inv = __builtin_amdgcn_rcpf(du);
@@ -705,8 +721,8 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
                 const float inv_dt = __builtin_bit_cast(float, tfl[kTfInvDt]);   // (N - 1) / (tt[N-1] - tt[0]), v_rcp_f32
                 const float ka = (ta - t_first) * inv_dt, kb = (tb - t_first) * inv_dt;
                 // clamp in float first: ta / tb may be +-3e38
-                lane_lo = (int)fminf(fmaxf(floorf(ka) - 1.0f, 0.0f), (float)a->N);
-                lane_hi = (int)fmaxf(fminf(ceilf(kb) + 1.0f, (float)(a->N - 1)), -1.0f);
+                lane_lo = (int)fminf(fmaxf(floorf(ka) - GCFR_M(12, 0.0f, 1.0f), 0.0f), (float)a->N);
+                lane_hi = (int)fmaxf(fminf(ceilf(kb) + GCFR_M(12, 0.0f, 1.0f), (float)(a->N - 1)), -1.0f);
             }
         }
         // readfirstlane: the reductions are wave-uniform by construction, but only an SGPR tells the
@@ -716,10 +732,11 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         const int w_lo = __builtin_amdgcn_readfirstlane(wave_min_i32(lane_lo));
         const int w_hi = -__builtin_amdgcn_readfirstlane(wave_min_i32(-lane_hi));
         const int nb = max(k_begin, w_lo), ne = min(k_end, w_hi + 1);
-        any_masked = (nb > k_begin) || (ne < k_end);  // some sample of this wave's range was pruned
+        any_masked = GCFR_M(24, false, (nb > k_begin) || (ne < k_end));  // some sample of this wave's range was pruned
         k_begin = nb;
         k_end = ne;
     }
+// census: bounds set-up: Kerr, cap, safeS
     if (k_begin >= k_end)
         use_zb = false;  // no ray of this tile reaches the mask's box: nothing to march, so no bounds set-up either
     GCFR_COUNT(kCntTiles, 1);
@@ -773,13 +790,13 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         // r: bound on |BA|'s components over the whole image (x, y extent; depth range incl. the sampled 0)
         const float gz_lo = f32_unsortable(gz_lo_s), gz_hi = -f32_unsortable(gz_nhi_s);  // all-NaN image: +inf, -inf
         const float rr = fmaxf(fmaxf(fabsf(gz_lo - zb), fabsf(gz_hi - zb)), fmaxf(fabsf(zb), (float)max(H, W)));
-        const float K1 = 4e-3f * fabsf(BCz) + 1e-6f * fabsf(c1) * t_abs;
-        const float K2 = 1e-6f * nrm + 2e-7f * ((fabsf(BCx) + fabsf(BCy)) + fabsf(BCz));
+        const float K1 = GCFR_M(3, 0.0f, 4e-3f * fabsf(BCz) + 1e-6f * fabsf(c1) * t_abs);
+        const float K2 = GCFR_M(4, 0.0f, 1e-6f * nrm + 2e-7f * ((fabsf(BCx) + fabsf(BCy)) + fabsf(BCz)));
         // + the plane evaluation: position offsets (1e-4, t d vs the rounded BA_xy) times |a| + |b| <= 8, and the
         //   f32 roundings of a X + b Y (|.| <= 8 max(H, W)) at build and at test time
-        const float K = __builtin_fmaf(K2, rr, K1) + nrm * (1.2e-2f + 8e-6f * (float)max(H, W));
+        const float K = __builtin_fmaf(K2, rr, K1) + GCFR_M(5, 0.0f, nrm * (1.2e-2f + 8e-6f * (float)max(H, W)));
         if ((nrm > 0.0f) && finite_ray && (K - K == 0.0f)) {
-            Kerr = K;
+            Kerr = GCFR_M(23, 0.0f, K);
         }
         // the cap: the depth maximum over what an unmasked sample can read where the prepass built the horizon tables
         // (col_suf[0], see build_horizon_block), else over the whole image; either way >= 0 (NaN / inf: the test fails)
@@ -787,15 +804,16 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             const ConstF32Ptr e = (ConstF32Ptr)(unsigned long long)a->zb + 4 * ((size_t)b * zb_slot(H, W) + zb_stride(H, W) + kHorizonDim);
             gz_cap = fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3]));
         } else {
-            gz_cap = fmaxf(gz_hi, 0.0f);
+            gz_cap = GCFR_M(25, gz_hi, fmaxf(gz_hi, 0.0f));
         }
         gz_cap = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gz_cap)));  // (an SGPR, for the compiler)
         // d = sqrt(S)/den < 1e6 for certain when S < 0.98e12 den^2; wave minimum -> SGPR
         const float den2 = (BCx * BCx + BCy * BCy) + BCz * BCz;
-        const float s_lane = (den2 - den2 == 0.0f) ? 0.98e12f * den2 : 0.0f;
+        const float s_lane = (den2 - den2 == 0.0f) ? GCFR_M(9, 1.02e12f, 0.98e12f) * den2 : 0.0f;
         safeS = f32_unsortable(__builtin_amdgcn_readfirstlane(wave_min_i32(f32_sortable(s_lane))));
     }
 
+// census: loop: bounds record fetch
     // bounds of the cells a group can touch, given the rounded cells of its first and last sample:
     // floor(u) and ceil(u) lie in [rint(s) - 1, rint(s) + 1], so the extended indices are [min, max + 2].
     // A footprint the selected tile does not cover reads the sentinel record (-inf, +inf): it never skips.
@@ -829,6 +847,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         return *(const __attribute__((address_space(3))) f32x4 *)((__attribute__((address_space(3))) const char *)gcfr_lds_stage + lds_zb_base + off);
     };
 
+// census: loop: mask prefetch (positions, rint, gathers)
     // Two-stage software pipeline.  Stage A (sample k+1): position, rounded cell, issue the mask byte
     // gather.  Stage B (sample k): if NO lane of the wave has an unmasked sample, the whole bilinear /
     // distance body is skipped -- masked samples only contribute "1e6" (T8:512), which `any_masked`
@@ -899,6 +918,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         if (use_zb)
             p.z = zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1]);
     };
+// census: loop: termination test
     // One group: issue the next group's gathers into `nxt`, then consume `cur`.  Returns false when the wave is
     // finished (early termination).  The loop below alternates two buffers, so that the loaded registers are
     // consumed in place -- with a single buffer copied at the loop's back edge the compiler waits for the
@@ -919,16 +939,17 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             //  (profiles/r04_pixels_mainhz_ab.txt).  The main loop rarely terminates, it hands over to the trailing loop.)
             const float gd = __builtin_fmaf(c1, tn, -(__builtin_fmaf(nrm_l, gz_cap, -(nrm_l * zb)) + Kerr));
             const float bS = bestS;
-            const bool finished = ((c1 > 0.0f) && (gd > 0.0f) && (gd * gd * 0.998f > bS) && (bS < safeS)) ||
-                                  (lane_last < k0 + DEPTH);
+            const bool finished = (GCFR_M(11, true, (c1 > 0.0f)) && (gd > 0.0f) && (gd * gd * GCFR_M(7, 1.002f, 0.998f) > bS) && (bS < safeS)) ||
+                                  (lane_last < k0 + DEPTH GCFR_M(26, + 1, ));
             if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) {
-                any_masked |= (lane_last < k0 + DEPTH);
+                any_masked |= (lane_last < k0 + DEPTH GCFR_M(26, + 1, ));
                 GCFR_COUNT(kCntEarlyExit, 1);
                 return false;
             }
         }
         return true;
     };
+// census: loop: depth-bound test
     // bound_cw(): the depth-bound test of one group for this lane -- true: no sample of the group can lower (or tie) the
     // lane's running minimum.  cz: the group's bounds record, ta64 / tb64: its first / last table value.
     auto bound_cw = [&](const f32x4 &cz, double ta64, double tb64) -> bool {
@@ -949,12 +970,13 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             const float A0 = __builtin_fmaf(cz.x, x, cz.y * y), A1 = __builtin_fmaf(cz.x, dxl, cz.y * dyl);
             const float E = __builtin_fmaf(nrm, A1, -c1);
             const float Flo = __builtin_fmaf(nrm, A0 + cz.z, -Qz), Fhi = __builtin_fmaf(nrm, A0 + cz.w, -Qz);
-            const float eA = ta * E, eB = tb * E;
+            const float eA = ta * E, eB = GCFR_M(29, ta, tb) * E;
             const float gap = fmaxf(Flo + fminf(eA, eB), -(Fhi + fmaxf(eA, eB)));  // > 0 iff the band stays clear of the ray
             const float gap0 = fmaxf(-Qz - Thi, Tlo + Qz);     // the same for the isolated value z = 0
-            const float g = fminf(gap, gap0) - Kerr;
-            return (g > 0.0f) && (g * g * 0.998f > bestS);
+            const float g = GCFR_M(10, gap, fminf(gap, gap0)) - Kerr;
+            return (g > 0.0f) && (g * g * GCFR_M(6, 1.002f, 0.998f) > bestS);
     };
+// census: loop: sample body (bilinear, distance, minimum)
     // consume(): what happens to one group once its mask values `cm` (0 = masked) are known.  LAZY = false: `cz` is the
     // group's bounds record, tested here if some lane has an unmasked sample; LAZY = true (LDS-staged variant): the
     // caller has tested it already and passes the lane's verdict in `cw_in`.  ta64 / tb64: the group's first / last
@@ -992,6 +1014,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         }
         bestS = take ? S : bestS;
     };
+// census: loop: group bookkeeping (ballots, branches)
     bool all_lazy = false;  // (wave-uniform) set by consume(): the group just consumed could have been skipped without its mask
     auto consume = [&](int k0, const uint32_t (&cm)[DEPTH], const f32x4 &cz, double ta64, double tb64, double tn64,
                        bool check_finished, auto lazy, bool cw_in) -> bool {
@@ -1018,7 +1041,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             const bool cannot_win = bound_cw(cz, ta64, tb64);
             run_body = __builtin_amdgcn_ballot_w64(!none && !cannot_win) != 0ull;
             if (TRAIL)  // (see the trailing loop below) nothing of this group mattered to any lane, masked or not
-                all_lazy = !run_body && __builtin_amdgcn_ballot_w64(!((cannot_win && (bestS < safeS)) || (lane_last < k0))) == 0ull;
+                all_lazy = !run_body && __builtin_amdgcn_ballot_w64(!((cannot_win && GCFR_M(18, true, (bestS < safeS))) || (lane_last < k0))) == 0ull;
         }
         // samples of the group evaluated together (texel gathers in flight): one at a time in the six-wave inference
         // variant (fewer live registers -> forced occupancy, see the __global__ wrappers), two in the argmin variant, the
@@ -1040,6 +1063,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
               cnt[kCntLaneSamples] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(cm[j] != 0));
 #endif
 #pragma unroll
+// census: loop: sample body (bilinear, distance, minimum)
           for (int h0 = 0; h0 < DEPTH; h0 += GCFR_BODY_CHUNK) {
             // phase 1: positions and texel gathers for the whole group (all in flight together)
             double ux[DEPTH], uy[DEPTH], fxd[DEPTH], fyd[DEPTH];
@@ -1069,6 +1093,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
                 eval_sample(clampk(k0 + j), (cm[j] == 0) || dead, ux[j], uy[j], fxd[j], fyd[j], qv[j]);
           }
         }
+// census: loop: group bookkeeping (ballots, branches)
         return finish_check(k0, tn64, check_finished);
     };
     auto group = [&](int k0, const Prefetched &cur, Prefetched &nxt, bool check_finished) -> bool {
@@ -1080,6 +1105,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         return consume(k0, cur.m, cur.z, ta64, tb64, tc0, check_finished, std::false_type{}, false);
     };
 
+// census: loop: LDS-staged variant
     // LDS-staged variant (round 3).  The workgroup's image -- its mask as a BITMAP and its depth-bounds
     // records -- was copied into LDS by the four waves at kernel entry (stage_lds, global_load_lds_dwordx4); what the
     // global variant gathers one group ahead through the texture path (four 1-byte mask gathers, each occupying the
@@ -1137,6 +1163,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         return consume(k0, cm, f32x4{}, ta64, tb64, tq[0], check_finished, std::true_type{}, cw);
     };
 
+// census: loop: LDS-staged variant
     if (LDS) {
         __syncthreads();  // the staged image is complete (every wave of the workgroup gets here exactly once)
         if (k_begin < k_end)
@@ -1150,6 +1177,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
                 break;
         }
     } else if (ROUGH) {
+// census: loop: rough loop
         // Rough loop (round 4).  A tile that marches WITHOUT the depth bounds -- it gave them up (a surface rougher than its
         // rays rise: an untrained network's depth, 7,259 of 8,192 tiles at noise amplitude 400), the caller switched them off, or
         // the sample table is not one the bounds reason about -- executes every sample of its candidate range: nothing is
@@ -1197,6 +1225,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             }
         }
     } else {
+// census: loop: main loop driver
     Prefetched bufA, bufB;
     bufA.z = bufB.z = f32x4{0.0f, 0.0f, -__builtin_inff(), __builtin_inff()};
     const int k_first = k_begin;
@@ -1227,6 +1256,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             break;
         }
     }
+// census: loop: trailing loop
     // Trailing loop (round 3).  72 % of the groups a tile visits on face-shaped data come AFTER its last body: the rays run on
     // above the surface, the bounds test rejects group after group, and each of them still paid for four f64 sample
     // positions and four mask gathers one group ahead.  Once the test of a group has come out "nothing here matters to
@@ -1264,10 +1294,10 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             const bool check_hz = hz_off >= 0;
             const float tn = (float)tc0;  // the next group's first table value
             const bool cw = bound_cw(zcur, ta64, tb64);
-            const bool gone = lane_last < k0;
+            const bool gone = lane_last < k0 GCFR_M(27, + 1, );
             GCFR_COUNT(kCntGroupsVisited, 1);
-            if (__builtin_amdgcn_ballot_w64(!((cw && (bestS < safeS)) || gone)) == 0ull) {
-                any_masked |= gone;
+            if (__builtin_amdgcn_ballot_w64(!((cw && GCFR_M(18, true, (bestS < safeS))) || gone)) == 0ull) {
+                any_masked |= GCFR_M(19, false, gone);
                 GCFR_COUNT(kCntTrailSkips, 1);
 #ifdef GCFR_COUNTERS
                 ++cnt_since_body;
@@ -1279,8 +1309,8 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
                     dir_f32(dxl, dyl);
                     const int ci = (int)__builtin_floorf(__builtin_fmaf(tn, dxl, x)), ri = (int)__builtin_floorf(-__builtin_fmaf(tn, dyl, y));
                     constexpr int C = kHorizonDim / 2, M = kHorizonDim - 1;
-                    const int ic = (dxl >= 0.0f) ? kHorizonDim + min(max(ci + (C - 2), 0), M) : min(max(ci + (C + 3), 0), M);               // col_suf : col_pre
-                    const int ir = (dyl > 0.0f) ? 2 * kHorizonDim + min(max(ri + (C + 3), 0), M) : 3 * kHorizonDim + min(max(ri + (C - 2), 0), M);  // row_pre : row_suf
+                    const int ic = (dxl >= 0.0f) ? kHorizonDim + min(max(ci + (C - GCFR_M(21, 0, 2)), 0), M) : min(max(ci + (C + GCFR_M(21, 1, 3)), 0), M);               // col_suf : col_pre
+                    const int ir = (dyl > 0.0f) ? 2 * kHorizonDim + min(max(ri + (C + GCFR_M(21, 1, 3)), 0), M) : 3 * kHorizonDim + min(max(ri + (C - GCFR_M(21, 0, 2)), 0), M);  // row_pre : row_suf
                     const f32x4 zc4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, hz_off + (ic << 4), 0, 0));
                     const f32x4 zr4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, hz_off + (ir << 4), 0, 0));
                     const float zc = fmaxf(fmaxf(zc4.x, zc4.y), fmaxf(zc4.z, zc4.w)), zr_ = fmaxf(fmaxf(zr4.x, zr4.y), fmaxf(zr4.z, zr4.w));
@@ -1288,8 +1318,8 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
                     asm volatile("" : "+v"(nrm_l));
                     const float Dc = __builtin_fmaf(nrm_l, fminf(zc, zr_), -(nrm_l * zb)) + Kerr;  // (Kerr = inf: never finished)
                     const float gd = __builtin_fmaf(c1, tn, -Dc);
-                    const bool past = lane_last < k0 + DEPTH;
-                    const bool finished = ((c1 > 0.0f) && (gd > 0.0f) && (gd * gd * 0.998f > bestS) && (bestS < safeS)) || past;
+                    const bool past = lane_last < k0 + DEPTH GCFR_M(26, + 1, );
+                    const bool finished = (GCFR_M(11, true, (c1 > 0.0f)) && (gd > 0.0f) && (gd * gd * GCFR_M(8, 1.002f, 0.998f) > bestS) && (bestS < safeS)) || past;
                     if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) {
                         any_masked |= past;
                         GCFR_COUNT(kCntEarlyExit, 1);
@@ -1317,6 +1347,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
     }
     }
 
+// census: k-split combine
     if (KSPLIT) {  // combine the four waves' partial results for this tile
         __shared__ float sS[4][64], sPS[4][64];
         __shared__ int sK[4][64], sPK[4][64];
@@ -1345,15 +1376,17 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         }
     }
 
+// census: epilogue: distance finish, tie, masked value, bonus
     // (BCx laundered: otherwise the prologue's BCx^2 + BCy^2 is kept in a register across the whole sample loop for this
     //  one use -- the last value the six-wave build spilled)
     float BCx_e = BCx;
     asm volatile("" : "+v"(BCx_e));
-    const float den = __builtin_sqrtf(((BCx_e * BCx_e + BCy * BCy) + BCz * BCz) + kEps4);
-    float d = __builtin_sqrtf(bestS) / den;
+    // (sqrt_rn_normal: the correctly rounded square root for arguments >= 1e-4 -- both carry the reference's + 0.0001 -- see gcfr_device.hpp)
+    const float den = sqrt_rn_normal(((BCx_e * BCx_e + BCy * BCy) + BCz * BCz) + kEps4);
+    float d = sqrt_rn_normal(bestS) / den;
     // torch.min (T8:514) returns the FIRST index of the minimal distance: see first_tied_sample.
     if (WANT_ARGMIN) {
-        const bool tie = (prevk >= 0) && (__builtin_sqrtf(prevS) / den == d);
+        const bool tie = GCFR_M(16, false &&, ) (prevk >= 0) && (sqrt_rn_normal(prevS) / den == d);
         if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {  // rare; wave-uniform branch
             GCFR_COUNT(kCntTieRemarch, 1);
             RayConst rc;
@@ -1391,6 +1424,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
     const bool inside = (Cx >= ep->bx_lo) && (Cx <= ep->bx_hi) && (Cy >= ep->by_lo) && (Cy <= ep->by_hi);
     if (inside)
         d = d + ep->bonus;
+// census: epilogue: pixel re-derivation, min_dist / argmin stores
     // The pixel's row / column / validity are RE-DERIVED here from a fresh lane id instead of being kept live across the
     // sample loop: at the forced six waves per SIMD (80 VGPRs) they were exactly what the register allocator spilled
     // (r, c and the 64-bit pixel index: 16-20 B of scratch per lane, stored before the loop and reloaded after it --
@@ -1410,6 +1444,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         ep->min_dist[o] = d;
         if (WANT_ARGMIN)
             ep->argmin[o] = besti;
+// census: epilogue: normals load / stencil call, normals_out store
         if (FUSE_SHADE) {
             float n[3];
             const float *normals = ep->normals;
@@ -1437,6 +1472,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
                     no[2 * P] = n[2];
                 }
             }
+// census: epilogue: shading call, composite, stores (T8:517-522)
             const Shaded sh = shade_pixel(x, y, zb, n[0], n[1], n[2], Cx, Cy, Cz, ep->ambient[bl], ep->intensity, d);
             float *shadow_w = ep->shadow_w, *full = ep->full, *final_shading = ep->final_shading;
             if (shadow_w)
@@ -1452,6 +1488,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
                 ren[ch * P] = alb[ch * P] * sh.fin;
         }
     }
+// census: counters (counting build only)
 #ifdef GCFR_COUNTERS
     if (a->counters && lane == 0 && !(KSPLIT && wave != 0)) {
         cnt[kCntVisitsAfterLastBody] += cnt_since_body;  // (tiles without any body: all their visits)
@@ -1474,6 +1511,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
     return false;
 }
 
+// census: kernel entry: grid mapping, instantiation choice (march_grid)
 // The __global__ entry points of the march.  Occupancy is forced (the register allocator would settle at
 // 95-99 VGPRs = 5 waves/SIMD): with the group body evaluated one sample at a time (GCFR_BODY_CHUNK = 1) the
 // inference variant fits six waves per SIMD, which beats the 119-VGPR / 4-wave build that kept four gathers in
@@ -1513,7 +1551,7 @@ __device__ __forceinline__ void march_grid(ArgPtr a)
         rough = march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, true, LDS, false, FULL>(a, bl, (int)blockIdx.y, tx, st);
     else
         rough = march_tile<TILE_W, EVEN_HALF, WANT_ARGMIN, DEPTH, FUSE_SHADE, 0, false, LDS, OWN, FULL>(a, bl, (int)blockIdx.y, tx, st);
-    if (FULL == kModeFull && __builtin_amdgcn_readfirstlane((int)rough) != 0) {  // the tile marches without the depth bounds
+    if (FULL == kModeFull && GCFR_M(15, false &&, ) __builtin_amdgcn_readfirstlane((int)rough) != 0) {  // the tile marches without the depth bounds
         // (the image statistics are reduced AGAIN, through a laundered pointer -- a dozen scalar loads: kept alive across the
         //  bounds variant for this call they were eleven more SGPRs than the kernel has, spilled into a VGPR's lanes for the
         //  whole kernel: one register less in the main loops and a v_readlane at every use, -1.2 % on the bench faces)

@@ -1,0 +1,88 @@
+// Mutation testing of the march's exactness machinery (round 5; tools/mutants.py, profiles/r05_mutants.md).
+//
+// The march skips samples on the strength of a dozen hand-derived safety margins, and every skipped sample is a claim about
+// the reference's minimum over ALL samples (train_raytracing_relighting_CelebAHQ_DSSIM_8x.py:510-514).  -DGCFR_MUT=<n>
+// builds the library with ONE of those margins removed or inverted; the -m gpu suite must then fail.  A margin whose removal
+// no test notices is a margin nobody is testing (round 3 shipped a hole that 3.4 G random soak pixels had not found).
+//
+//     GCFR_M(n, mutant tokens, product tokens)
+//
+// expands to the product tokens unless GCFR_MUT == n: pure token selection by the preprocessor, so the product build
+// (GCFR_MUT undefined) compiles exactly the token stream it had before the mutants were written -- tools/compare_device_code.py
+// against the build without them: every kernel identical.
+//
+//  n  margin (file: where)                                                          mutant
+//  1  mask bounding box inflated by 0.5 (rint) + 0.01 (gcfr_march.hpp, candidate range)   0.51 -> 0.49
+//  2  bounding octagon inflated by 1 + 0.02                                          1.02 -> 0.98
+//  3  Kerr: K1 (roundings proportional to |BCz|, |c1| t)                            = 0
+//  4  Kerr: K2 r (roundings proportional to |BA|)                                    = 0
+//  5  Kerr: plane-evaluation term n (1.2e-2 + 8e-6 max(H, W))                        = 0
+//  6  depth-bound skip: bound^2 * 0.998 > running minimum                            0.998 -> 1.002
+//  7  early termination, main loop: the same slack                                   0.998 -> 1.002
+//  8  early termination, trailing loop (horizon cap): the same slack                 0.998 -> 1.002
+//  9  safeS = 0.98e12 den^2 ("the distance is certainly below the masked 1e6")       0.98e12 -> 1.02e12
+// 10  gap0: the isolated sampled value z = 0 at integral coordinates                 dropped from the bound
+// 11  c1 > 0 ("the ray is still rising") in both termination tests                   dropped
+// 12  candidate range: one sample of slack either side                               removed
+// 13  horizon tables: wrap partners (prefix tables include the last column / row, suffix the first)   left out
+// 14  horizon tables: the dilation of the live cells wraps where the gathers do      no wrap
+// 15  march_grid: a tile that hands itself to the rough variant is re-run by it      not re-run
+// 16  tie predecessor (first index of the minimal DISTANCE, torch.min)               never re-marched
+// 17  pixels = mask: a lane outside the image counts as "own pixel off"              forgotten
+// 18  trailing loop entered / continued only when bestS < safeS                      condition dropped
+// 19  trailing loop: a lane past its last candidate sample records any_masked        not recorded
+// 20  horizon tables: live cells = the mask's non-zero cells dilated by one          no dilation
+// 21  horizon look-up: two / three cells of slack around the next sample's cell      none
+// 22  bounds grid stride: a group's footprint + 3 cells                              + 1
+// 23  Kerr as a whole                                                                = 0
+// 24  candidate range pruned some sample of the wave's range -> any_masked           not recorded
+// 25  termination cap without horizon tables: max(image depth maximum, 0)            without the 0
+// 26  "every remaining sample of the lane lies outside the mask's box" (lane_last < next group's first sample)   off by one
+// 27  trailing loop: "the lane has left the box" (lane_last < this group's first sample)   off by one
+// 29  bound evaluated at the group's first AND last sample (linear in t)             first sample only
+#pragma once
+
+#ifndef GCFR_MUT
+#define GCFR_MUT 0
+#endif
+
+#define GCFR_PP_CAT_(a, b, c) a##b##_##c
+#define GCFR_PP_CAT(a, b, c) GCFR_PP_CAT_(a, b, c)
+#define GCFR_PP_SECOND_(a, b, ...) b
+#define GCFR_PP_SECOND(...) GCFR_PP_SECOND_(__VA_ARGS__)
+#define GCFR_PP_IS_PAIR(x) GCFR_PP_SECOND(x, 0, ~)
+#define GCFR_PP_IF_0(mut, prod) prod
+#define GCFR_PP_IF_1(mut, prod) mut
+#define GCFR_PP_IF_(c) GCFR_PP_IF_##c
+#define GCFR_PP_IF(c) GCFR_PP_IF_(c)
+// GCFR_MUT_PAIR_<GCFR_MUT>_<n> is defined (as a two-element list whose second element is 1) only where both are equal
+#define GCFR_M(n, mut, prod) GCFR_PP_IF(GCFR_PP_IS_PAIR(GCFR_PP_CAT(GCFR_MUT_PAIR_, GCFR_MUT, n)))(mut, prod)
+
+#define GCFR_MUT_PAIR_1_1 ~, 1
+#define GCFR_MUT_PAIR_2_2 ~, 1
+#define GCFR_MUT_PAIR_3_3 ~, 1
+#define GCFR_MUT_PAIR_4_4 ~, 1
+#define GCFR_MUT_PAIR_5_5 ~, 1
+#define GCFR_MUT_PAIR_6_6 ~, 1
+#define GCFR_MUT_PAIR_7_7 ~, 1
+#define GCFR_MUT_PAIR_8_8 ~, 1
+#define GCFR_MUT_PAIR_9_9 ~, 1
+#define GCFR_MUT_PAIR_10_10 ~, 1
+#define GCFR_MUT_PAIR_11_11 ~, 1
+#define GCFR_MUT_PAIR_12_12 ~, 1
+#define GCFR_MUT_PAIR_13_13 ~, 1
+#define GCFR_MUT_PAIR_14_14 ~, 1
+#define GCFR_MUT_PAIR_15_15 ~, 1
+#define GCFR_MUT_PAIR_16_16 ~, 1
+#define GCFR_MUT_PAIR_17_17 ~, 1
+#define GCFR_MUT_PAIR_18_18 ~, 1
+#define GCFR_MUT_PAIR_19_19 ~, 1
+#define GCFR_MUT_PAIR_20_20 ~, 1
+#define GCFR_MUT_PAIR_21_21 ~, 1
+#define GCFR_MUT_PAIR_22_22 ~, 1
+#define GCFR_MUT_PAIR_23_23 ~, 1
+#define GCFR_MUT_PAIR_24_24 ~, 1
+#define GCFR_MUT_PAIR_25_25 ~, 1
+#define GCFR_MUT_PAIR_26_26 ~, 1
+#define GCFR_MUT_PAIR_27_27 ~, 1
+#define GCFR_MUT_PAIR_29_29 ~, 1

@@ -481,7 +481,7 @@ __device__ inline void build_horizon_block(int k, int b, const float *__restrict
         // image's edge.  So a non-zero mask cell in column 0 makes the last column live in its three rows, and one in row 0 makes
         // row H-1 live in its columns (round 4, advisor r03: a mask touching only the left / top edge left the wrap partner out
         // of the tables, and a large masked-out depth there was not covered by the trailing loop's cap).
-        const unsigned long long wrap_bit = segs > 1 ? 0ull : (1ull << last_lane);
+        const unsigned long long wrap_bit = GCFR_M(14, true ||, ) segs > 1 ? 0ull : (1ull << last_lane);
         float4 cm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // running maxima of this lane's four columns
         for (int r0 = r_lo; r0 < r_hi; r0 += RB) {
             uint32_t md[RB + 2];
@@ -498,13 +498,13 @@ __device__ inline void build_horizon_block(int k, int b, const float *__restrict
 #pragma unroll
             for (int j = 0; j < RB + 2; ++j) {
                 const int r = r0 - 1 + j;
-                bits[j] = __builtin_amdgcn_ballot_w64(in_w && r >= 0 && r <= H && md[j] != 0);
+                bits[j] = __builtin_amdgcn_ballot_w64(in_w && r >= 0 && r GCFR_M(14, <, <=) H && md[j] != 0);
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
                 const int r = r0 + j;
                 const unsigned long long v3 = bits[j] | bits[j + 1] | bits[j + 2];
-                const unsigned long long live = v3 | (v3 << 1) | (v3 >> 1) | edge | ((v3 & 1ull) ? wrap_bit : 0ull);
+                const unsigned long long live = GCFR_M(20, bits[j + 1] | edge, v3 | (v3 << 1) | (v3 >> 1) | edge | ((v3 & 1ull) ? wrap_bit : 0ull));
                 float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (in_w && r < r_hi && ((live >> lane) & 1ull))  // (fmaxf drops NaN)
                     v = make_float4(fmaxf(dv[j].x, 0.0f), fmaxf(dv[j].y, 0.0f), fmaxf(dv[j].z, 0.0f), fmaxf(dv[j].w, 0.0f));
@@ -564,7 +564,7 @@ __device__ inline void build_horizon_block(int k, int b, const float *__restrict
     constexpr int S = kHorizonDim;
     float *out = (float *)(zb + (size_t)b * zb_slot(H, W) + zb_stride(H, W)) + k;
     {   // columns: this band's column maxima over all W columns
-        const int add_pre = s_col[W - 1], add_suf = s_col[0];
+        const int add_pre = GCFR_M(13, 0, s_col[W - 1]), add_suf = GCFR_M(13, 0, s_col[0]);
         for (int i = tid; i < S; i += 256) {
             const int j = min(max(i - S / 2 + W / 2, 0), W - 1);
             out[(size_t)i * 4] = __builtin_bit_cast(float, max(s_cpre[j], add_pre));
@@ -573,8 +573,8 @@ __device__ inline void build_horizon_block(int k, int b, const float *__restrict
     }
     {   // rows: this band's own rows' maxima, zero elsewhere
         const int total = nr > 0 ? s_rpre[nr - 1] : 0;
-        const int add_pre = (nr > 0 && b_hi == H) ? s_row[nr - 1] : 0;  // the band that holds the image's last row
-        const int add_suf = (nr > 0 && b_lo == 0) ? s_row[0] : 0;       // ... its first row
+        const int add_pre = (GCFR_M(13, false &&, ) nr > 0 && b_hi == H) ? s_row[nr - 1] : 0;  // the band that holds the image's last row
+        const int add_suf = (GCFR_M(13, false &&, ) nr > 0 && b_lo == 0) ? s_row[0] : 0;       // ... its first row
         for (int i = tid; i < S; i += 256) {
             const int j = min(max(i - S / 2 + H / 2, 0), H - 1) - b_lo;  // position among this band's rows (may lie outside)
             const int pre = nr <= 0 ? 0 : (j < 0 ? 0 : (j >= nr ? total : s_rpre[j]));
@@ -691,9 +691,9 @@ static inline int launch_status()
 extern "C" const char *gcfr_version(void)
 {
 #if defined(GCFR_COUNTERS)
-    return "gcfr-hip 0.4.0 gfx950 +counters";
+    return "gcfr-hip 0.5.0 gfx950 +counters";
 #else
-    return "gcfr-hip 0.4.0 gfx950";
+    return "gcfr-hip 0.5.0 gfx950";
 #endif
 }
 
@@ -734,6 +734,7 @@ struct Knobs {
     int zbound = 1;      // depth-bound group skip (exact): 1 on, 0 off
     int lds_stage = -1;  // mask bitmap + bounds records of the workgroup's image in LDS: 0 off, 1 on (where the shape allows), -1 auto
     int pixels = 0;      // 1: pixels outside the mask are not marched (gcfr_options.pixels; the one knob that changes results)
+    int phase = 0;       // 0: prepass + march, 1: the prepass only, 2: the march only (gcfr_options.phase)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     unsigned long long *counters = nullptr;
 };
@@ -748,7 +749,7 @@ static int resolve_options(const gcfr_options *opt, Knobs &k)
     if ((tw != 0 && tw != 8 && tw != 16 && tw != 32 && tw != 64) || (g != 0 && g != 1 && g != 2 && g != 4) ||
         opt->ksplit < -1 || opt->ksplit > 1 || opt->depth_bound_skip < -1 || opt->depth_bound_skip > 1 ||
         opt->schedule < -1 || opt->schedule > 0 || opt->tile_order < -1 || opt->tile_order > 0 || opt->lds_stage < -1 ||
-        opt->lds_stage > 1 || opt->pixels < -1 || opt->pixels > 1)
+        opt->lds_stage > 1 || opt->pixels < -1 || opt->pixels > 1 || opt->phase < -1 || opt->phase > 2)
         return GCFR_ERR_INVALID_ARGUMENT;  // (schedule / tile_order: the grid is the only schedule; the fields keep the struct layout)
     k.tile_w = tw;
     k.group = g ? g : 4;
@@ -756,6 +757,7 @@ static int resolve_options(const gcfr_options *opt, Knobs &k)
     k.zbound = opt->depth_bound_skip < 0 ? 1 : opt->depth_bound_skip;
     k.lds_stage = opt->lds_stage;
     k.pixels = opt->pixels == 1 ? 1 : 0;
+    k.phase = opt->phase < 0 ? 0 : opt->phase;
     k.ev_start = (hipEvent_t)opt->event_start;
     k.ev_stop = (hipEvent_t)opt->event_stop;
     k.counters = (unsigned long long *)opt->counters;
@@ -769,6 +771,7 @@ extern "C" void gcfr_options_default(gcfr_options *opt)
     *opt = gcfr_options{};
     opt->struct_size = (uint32_t)sizeof(gcfr_options);
     opt->ksplit = opt->depth_bound_skip = opt->schedule = opt->tile_order = opt->lds_stage = -1;
+    opt->pixels = opt->phase = 0;
 }
 
 // workspace layout: [quad texels | partial boxes | per image: depth-bounds records, horizon tables | partial depth ranges | tflag | all-ones flags | mask bitmaps | partial diagonal extents]
@@ -839,7 +842,8 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
                            int32_t *argmin, void *workspace, size_t workspace_bytes, void *stream,
                            const FusedShade &fs, const gcfr_options *opt)
 {
-    if (!depth || !mask_u8 || !light_pt || !t_table || !min_dist)
+    const bool pre_only = opt && opt->phase == 1;  // (the prepass alone: the march's operands may still be missing)
+    if (!depth || !mask_u8 || !light_pt || !t_table || (!min_dist && !pre_only))
         return GCFR_ERR_INVALID_ARGUMENT;
     if (B <= 0 || L <= 0 || N <= 0 || N > 4096 || H < 2 || W < 2 || H > 4096 || W > 4096 ||
         (H & 1) || (W & 1) || (mask_batch != 1 && mask_batch != B))
@@ -851,8 +855,10 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
     Knobs kn;
     if (resolve_options(opt, kn) != GCFR_OK)
         return GCFR_ERR_INVALID_ARGUMENT;
-    if (kn.pixels == 1 && (!workspace || !argmin))
+    if (kn.pixels == 1 && (!workspace || (!argmin && !pre_only)))
         return GCFR_ERR_INVALID_ARGUMENT;  // pixels = mask lives in the workspace path's training (argmin) march
+    if (kn.phase != 0 && !workspace)
+        return GCFR_ERR_INVALID_ARGUMENT;  // the two halves only exist where there is a prepass
 
     // auto tile shape (measured): with the depth-bound skip compact tiles win (the lanes of a wave
     // agree more often).  16x4 everywhere: on the smooth bench faces it ties with 8x8 at 256 px (1690 vs 1688 G
@@ -914,9 +920,12 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
                              (((uintptr_t)mask_u8 & 3u) == 0);
         const int hz_blocks = horizon ? kHorizonBands : 0;
         const int vec_ok = ((W & 15) == 0) && (((uintptr_t)depth & 15u) == 0) && (((uintptr_t)mask_u8 & 15u) == 0);
-        hipLaunchKernelGGL(build_quad_kernel, dim3(hz_blocks + zb_blocks + (int)n_stat + bitmap_blocks + quad_blocks, B), dim3(256), 0, st,
-                           depth, (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox, zrange, mones, zb, zb_blocks,
-                           (int)n_stat, use_zb ? 1 : 0, vec_ok, N, t_table, kn.group, tflag, bitmap, bitmap_blocks, hz_blocks, diag);
+        if (kn.phase != 2)  // (phase 2: a phase-1 call with the same arguments has filled the workspace)
+            hipLaunchKernelGGL(build_quad_kernel, dim3(hz_blocks + zb_blocks + (int)n_stat + bitmap_blocks + quad_blocks, B), dim3(256), 0, st,
+                               depth, (float4 *)workspace, H, W, fs.lights, mask_u8, mask_batch, bbox, zrange, mones, zb, zb_blocks,
+                               (int)n_stat, use_zb ? 1 : 0, vec_ok, N, t_table, kn.group, tflag, bitmap, bitmap_blocks, hz_blocks, diag);
+        if (kn.phase == 1)
+            return launch_status();
         ShadowQuadArgs a = {};
         a.zb = use_zb ? zb : nullptr;
         a.zrange = zrange;
@@ -1017,8 +1026,8 @@ extern "C" int gcfr_render_fwd(const float *light_raw, int32_t clamp_z, float cl
                                float *rendered, void *workspace, size_t workspace_bytes, void *stream,
                                const gcfr_options *opt)
 {
-    if (!light_raw || !normals || !albedo || !ambient || !unit_out || !light_pt_out || !rendered ||
-        !workspace)
+    const bool pre_only = opt && opt->phase == 1;  // (gcfr_options.phase: the prepass reads depth, mask, light_raw and t_table only)
+    if (!light_raw || !unit_out || !light_pt_out || !workspace || (!pre_only && (!normals || !albedo || !ambient || !rendered)))
         return GCFR_ERR_INVALID_ARGUMENT;
     if (B <= 0 || L <= 0)
         return GCFR_ERR_INVALID_ARGUMENT;
@@ -1054,7 +1063,8 @@ extern "C" int gcfr_render_from_depth_fwd(const float *light_raw, int32_t clamp_
                                           float *final_shading, float *rendered, void *workspace,
                                           size_t workspace_bytes, void *stream, const gcfr_options *opt)
 {
-    if (!light_raw || !albedo || !ambient || !unit_out || !light_pt_out || !rendered || !workspace ||
+    const bool pre_only = opt && opt->phase == 1;
+    if (!light_raw || !unit_out || !light_pt_out || !workspace || (!pre_only && (!albedo || !ambient || !rendered)) ||
         B <= 0 || L <= 0 || fx == 0.0 || fy == 0.0)
         return GCFR_ERR_INVALID_ARGUMENT;
     FusedShade fs;
@@ -1081,4 +1091,25 @@ extern "C" int gcfr_render_from_depth_fwd(const float *light_raw, int32_t clamp_
     fs.intensity = intensity;
     return shadow_fwd_impl(depth, mask_u8, mask_batch, light_pt_out, B, L, H, W, N, t_table, bonus,
                            bonus_box, min_dist, argmin, workspace, workspace_bytes, stream, fs, opt);
+}
+
+// ----------------------------------------------------------------------------------------------
+// measurement aid: the achievable-HBM probe (bench.py)
+// ----------------------------------------------------------------------------------------------
+namespace gcfr {
+__global__ __launch_bounds__(256) void copy_probe_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = src[i];
+}
+}  // namespace gcfr
+
+extern "C" int gcfr_copy_probe(const void *src, void *dst, size_t bytes, void *stream)
+{
+    if (!src || !dst || bytes == 0 || (bytes & 15u) || ((uintptr_t)src & 15u) || ((uintptr_t)dst & 15u))
+        return GCFR_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(gcfr::copy_probe_kernel, dim3(8192), dim3(256), 0, (hipStream_t)stream, (const float4 *)src, (float4 *)dst,
+                       bytes / 16);
+    return launch_status();
 }

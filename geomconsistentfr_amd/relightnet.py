@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .block import RenderParams, render_from_depth
+from .block import RenderParams, render_from_depth, render_from_depth_prepass
 
 
 def _lrelu(x):
@@ -115,8 +115,12 @@ class _Hourglass(nn.Module):
     def _camera(self, intrinsic_matrix):
         return self._pinned_camera if self._pinned_camera is not None else intrinsic_matrix
 
-    def features(self, img_nhwc, epoch):
-        """-> (albedo (B,3,H,W) in (0,1), depth (B,1,H,W) x100, SL_lin2 (B,1,1,4)).  T8:197-350."""
+    def features(self, img_nhwc, epoch, on_depth=None):
+        """-> (albedo (B,3,H,W) in (0,1), depth (B,1,H,W) x100, SL_lin2 (B,1,1,4)).  T8:197-350.
+        The DEPTH decoder runs first (the reference runs the albedo decoder first, T8:290 then T8:350; the two are independent
+        sub-graphs off the same encoder features, so the order changes no value): `on_depth(depth, SL_lin2)`, if given, is called
+        as soon as both exist -- RelightNet.forward uses it to put the render block's prepass on a side stream, under the
+        albedo decoder's convolutions."""
         img = img_nhwc.permute(0, 3, 1, 2)
         c1_og = _lrelu(self._cb("c1_og", img))
         c1 = F.max_pool2d(c1_og, 2)
@@ -136,8 +140,10 @@ class _Hourglass(nn.Module):
         lf = self.AvgPool_LF(lighting).permute(0, 2, 3, 1)
         SL_lin2 = self.linear_SL2(_lrelu(self.linear_SL1(lf)))                          # (B,1,1,4)
         skips = [ogs["h3"], ogs["h2"], ogs["h1"], c1_og]
-        albedo = torch.sigmoid(self._decode("albedo", identity, skips, epoch))          # T8:290
         depth = 100.0 * self._decode("depth", identity, skips, epoch)                   # T8:350
+        if on_depth is not None:
+            on_depth(depth, SL_lin2)
+        albedo = torch.sigmoid(self._decode("albedo", identity, skips, epoch))          # T8:290
         return albedo, depth, SL_lin2
 
 
@@ -149,11 +155,20 @@ class RelightNet(_Hourglass):
         self.render_params = params or RenderParams.training()
         self.normal_z_offset = normal_z_offset                                          # T8:353
 
+    hoist_prepass = True   # the render block's prepass on a side stream, under the albedo decoder (block.render_prepass)
+
     def forward(self, img, epoch, intrinsic_matrix, masks):
-        albedo, depth, SL = self.features(img, epoch)
+        cam = self._camera(intrinsic_matrix)
+        m3 = masks.reshape(masks.shape[0], masks.shape[1], masks.shape[2])
+        early = []
+
+        def on_depth(depth, SL):  # depth, light and mask exist: everything the prepass reads (gcfr_options.phase = 1)
+            early.append(render_from_depth_prepass(depth, SL[:, 0, 0, 1:4], cam, m3, self.render_params))
+
+        albedo, depth, SL = self.features(img, epoch, on_depth if (self.hoist_prepass and img.is_cuda) else None)
         B = depth.shape[0]
-        r = render_from_depth(depth, albedo, SL[:, 0, 0, 1:4], SL[:, 0, 0, 0], self._camera(intrinsic_matrix), self.normal_z_offset,
-                              masks.reshape(B, masks.shape[1], masks.shape[2]), self.render_params)   # T8:353-522
+        r = render_from_depth(depth, albedo, SL[:, 0, 0, 1:4], SL[:, 0, 0, 0], cam, self.normal_z_offset,
+                              m3, self.render_params, prepared=early[0] if early else None)   # T8:353-522
         return (albedo, depth, r["shadow_mask_weights"], r["ambient_light"], r["full_shading"],
                 r["rendered_images"], r["unit_light_direction"], r["ambient_values"])   # T8:524
 

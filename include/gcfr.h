@@ -46,8 +46,9 @@ const char *gcfr_version(void);
  * to proceed on a mismatch (geomconsistentfr_amd/_lib.py does).
  *   3: round 3 -- gcfr_inference_images_u8 gained `mask_f32`; gcfr_abi_version itself; the metrics entry points.
  *   4: round 4 -- gcfr_options gained `pixels`.
+ *   5: round 5 -- gcfr_options gained `phase` (the prepass as its own enqueue); gcfr_copy_probe.
  */
-#define GCFR_ABI_VERSION 4
+#define GCFR_ABI_VERSION 5
 int32_t gcfr_abi_version(void);
 
 /*
@@ -95,6 +96,19 @@ typedef struct gcfr_options {
                                   only after multiplying by the mask as well, S8:603-608).  Honoured by the workspace path when
                                   `argmin` is requested (the training forward; halves its march on face-shaped masks);
                                   GCFR_ERR_INVALID_ARGUMENT without a workspace or without `argmin`. */
+    int32_t phase;             /* WHICH HALF of a workspace call is enqueued (gcfr_shadow_fwd, gcfr_render_fwd,
+                                  gcfr_render_from_depth_fwd).  0 (default; also -1): both -- the prepass launch (depth repack, mask
+                                  statistics, depth bounds, horizon tables, light preparation, sample-table check: everything that
+                                  depends on depth, mask, light_raw and t_table only) and the march launch behind it on `stream`.
+                                  1: the prepass only.  2: the march only, on a workspace that a phase-1 call WITH THE SAME ARGUMENTS
+                                  AND OPTIONS filled (the caller orders the two: same stream, or an event between two streams).
+                                  Bit-identical to phase 0 by construction: the same two launches with the same arguments, enqueued by
+                                  two calls.  Why: in RelightNet.forward the depth head, the light and the mask exist before the albedo
+                                  decoder has run (T8:226-350), so the prepass can run on a side stream under the decoder's
+                                  convolutions and the march then starts without a dependent launch in front of it.  A phase-1 call
+                                  reads only: depth, mask_u8, light_raw (where the entry point has it), t_table; writes: workspace,
+                                  unit_out / light_pt_out (where the entry point has them).  The remaining pointers are not touched
+                                  and may be NULL (the albedo does not exist yet).  GCFR_ERR_INVALID_ARGUMENT without a workspace. */
 } gcfr_options;
 
 /* Fills `opt` with the defaults (struct_size set, every knob "auto", no hooks). */
@@ -360,6 +374,13 @@ size_t gcfr_masked_metrics_workspace_bytes(int32_t B, int32_t H, int32_t W);
 int gcfr_masked_metrics_u8(const uint8_t *recon_u8, const uint8_t *gt_u8, const uint8_t *mask_u8, int32_t mask_batch,
                            int32_t B, int32_t H, int32_t W, double *mse_out, double *dssim_out, void *workspace,
                            size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Measurement aid (bench.py `roofline.hbm_measured_copy_GBs`): a float4 grid-stride device-to-device copy of `bytes` bytes
+ * (multiple of 16, both pointers 16-byte aligned), 8192 workgroups of 256 lanes -- the achievable-HBM probe the roofline's 8 TB/s
+ * spec peak is reported beside.  Not part of the render path.
+ * ------------------------------------------------------------------------------------------- */
+int gcfr_copy_probe(const void *src, void *dst, size_t bytes, void *stream);
 
 #ifdef __cplusplus
 }

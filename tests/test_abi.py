@@ -82,6 +82,15 @@ def test_options_struct_defaults_and_layout():
     assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(pixels=2))) == -1
     # pixels = mask lives in the workspace path's argmin march: refused (not ignored) without a workspace or without argmin
     assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(pixels=1))) == -1
+    # phase (round 5: the prepass as its own enqueue): off by default, range-checked, and the two halves only exist with a workspace
+    assert o.phase == 0
+    assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(phase=3))) == -1
+    assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(phase=1))) == -1      # no workspace in `args`
+    assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(phase=2))) == -1
+    assert _lib.with_phase(None, 2).phase == 2 and _lib.with_phase(_lib.options(tile_w=32, pixels=1), 1).tile_w == 32
+    # the copy probe validates alignment and size before launching
+    assert L.gcfr_copy_probe(ctypes.c_void_p(64), ctypes.c_void_p(128), ctypes.c_size_t(24), None) == -1
+    assert L.gcfr_copy_probe(ctypes.c_void_p(68), ctypes.c_void_p(128), ctypes.c_size_t(32), None) == -1
 
 
 def test_product_has_no_cpu_fallback():

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Mutation testing of the march's exactness machinery (csrc/gcfr_mutants.hpp).
+
+    tools/mutants.py build [n ...]     (CPU)  lib/mut_<n>.so for every mutant (or the ones named): -DGCFR_FAST_BUILD -DGCFR_MUT=<n>;
+                                              mut_0.so is the control (the fast build without a mutation: must pass everything)
+    tools/mutants.py run [n ...]       (GPU)  pytest -m gpu -x over the exactness tests with GCFR_HIP_LIB=<mutant>: the first failing
+                                              test (or SURVIVED) and the seconds it took -> gpurun_out/mutants/results.json + logs
+    tools/mutants.py table             (CPU)  gpurun_out/mutants/results.json -> profiles/r05_mutants.md
+
+A mutant that survives is a margin nobody tests: it gets a DIRECTED test built from the mechanism's own geometry
+(tests/test_gpu_margins.py), not a larger soak.
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_DIR = os.path.join(REPO, "geomconsistentfr_amd", "lib")
+OUT_DIR = os.path.join(REPO, "gpurun_out", "mutants")
+HEADER = os.path.join(REPO, "geomconsistentfr_amd", "csrc", "gcfr_mutants.hpp")
+# the tests that assert exactness of the march (bit equality against the oracle / the plain kernel)
+SELECT = "parity or configs or horizon or pixels or margins"
+
+
+def mutant_table():
+    """{n: (margin, mutant)} from the header's comment table"""
+    out = {}
+    for line in open(HEADER):
+        m = re.match(r"^// +(\d+)  (.+?)  +(\S.*)$", line.rstrip())
+        if m:
+            out[int(m.group(1))] = (m.group(2).strip(), m.group(3).strip())
+    return out
+
+
+def lib_of(n):
+    return os.path.join(LIB_DIR, "mut_%d.so" % n)
+
+
+def build(ns):
+    sys.path.insert(0, REPO)
+    from geomconsistentfr_amd import build as b
+    import concurrent.futures
+
+    def one(n):
+        t = time.time()
+        defs = ["-DGCFR_FAST_BUILD"] + (["-DGCFR_MUT=%d" % n] if n else [])
+        b.compile_and_link(lib_of(n), defines=defs, jobs=4)
+        return n, time.time() - t
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as ex:
+        for n, dt in ex.map(one, ns):
+            print("mut_%d.so  %.0f s" % (n, dt), flush=True)
+
+
+def run(ns, select=SELECT, extra=()):
+    os.makedirs(OUT_DIR, exist_ok=True)
+    res_path = os.path.join(OUT_DIR, "results.json")
+    results = json.load(open(res_path)) if os.path.exists(res_path) else {}
+    for n in ns:
+        lib = lib_of(n)
+        if not os.path.exists(lib):
+            results[str(n)] = {"status": "NOT BUILT"}
+            continue
+        env = dict(os.environ, GCFR_HIP_LIB=lib)
+        log = os.path.join(OUT_DIR, "mut_%d.log" % n)
+        t = time.time()
+        cmd = ["timeout", "600", sys.executable, "-m", "pytest", "tests", "-m", "gpu", "-x", "-q", "-k", select, "-p", "no:cacheprovider",
+               "--tb=line"] + list(extra)
+        r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True)
+        dt = time.time() - t
+        with open(log, "w") as f:
+            f.write(r.stdout[-20000:] + "\n--- stderr ---\n" + r.stderr[-4000:])
+        first = re.search(r"^FAILED (\S+)", r.stdout, re.M) or re.search(r"^(tests/\S+::\S+) FAILED", r.stdout, re.M)
+        passed = re.search(r"(\d+) passed", r.stdout)
+        if r.returncode == 0:
+            status, first_failing = "SURVIVED", None
+        elif r.returncode == 124:
+            status, first_failing = "TIMEOUT", None
+        elif first:
+            status, first_failing = "killed", first.group(1)
+        else:
+            status, first_failing = "ERROR rc=%d" % r.returncode, None
+        results[str(n)] = {"status": status, "first_failing_test": first_failing, "seconds": round(dt, 1),
+                           "passed_before": int(passed.group(1)) if passed else 0}
+        print(n, results[str(n)], flush=True)
+        with open(res_path, "w") as f:
+            json.dump(results, f, indent=1, sort_keys=True)
+
+
+def table():
+    results = json.load(open(os.path.join(OUT_DIR, "results.json")))
+    names = mutant_table()
+    lines = ["# Mutants of the march's exactness machinery (round 5)", "",
+             "`csrc/gcfr_mutants.hpp`: `-DGCFR_MUT=<n>` removes or inverts ONE safety margin; `tools/mutants.py run` runs",
+             "`pytest -m gpu -x -k \"%s\"` with `GCFR_HIP_LIB=lib/mut_<n>.so` (fast build: 16 x 4 tiles, groups of four -- the product's" % SELECT,
+             "default shape).  Mutant 0 is the control: the fast build without a mutation.  Product device code with the mutant macros",
+             "in place: identical to the build without them (`tools/compare_device_code.py`, 265 kernels).", "",
+             "| n | margin | mutant | result | first failing test | seconds |", "|---|---|---|---|---|---|"]
+    total = 0.0
+    for key in sorted(results, key=int):
+        n, r = int(key), results[key]
+        margin, mut = names.get(n, ("control: fast build, no mutation", "--")) if n else ("control: fast build, no mutation", "--")
+        status = r["status"]
+        if n == 0:
+            status = "passes (%d tests)" % r.get("passed_before", 0) if r["status"] == "SURVIVED" else "CONTROL FAILS: " + r["status"]
+        lines.append("| %d | %s | %s | %s | %s | %s |" % (n, margin, mut, status, ("`%s`" % r["first_failing_test"]) if r.get("first_failing_test") else "",
+                                                         r.get("seconds", "")))
+        total += r.get("seconds", 0.0) if n else 0.0
+    surv = [k for k in results if int(k) and results[k]["status"] != "killed"]
+    lines += ["", "%d mutants, %d not killed%s; %.0f s of GPU-box time for the mutants together." %
+              (len([k for k in results if int(k)]), len(surv), (" (" + ", ".join(sorted(surv, key=int)) + ")") if surv else "", total)]
+    path = os.path.join(REPO, "profiles", "r05_mutants.md")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print(path)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else ""
+    ns = [int(a) for a in sys.argv[2:] if a.lstrip("-").isdigit()] or [0] + sorted(mutant_table())
+    if what == "build":
+        build(ns)
+    elif what == "run":
+        run(ns)
+    elif what == "table":
+        table()
+    else:
+        sys.exit(__doc__)
