@@ -1141,10 +1141,15 @@ def run_dry(a, rk):
     check of `bench.py --gpus N` (tests/test_bench_launch.py); no kernels, no numbers."""
     layout = rk.describe()
     per_rank = rk.gather(rk.rank)
+    faces = (a.faces if a.faces != FACES_PER_GPU else 32) if a.workload == "train" else a.faces       # as run_train / run_render
+    seeds = rk.gather(rk.rank * 1_000_000)                       # seed0 of rank r's faces: RenderRig._device_batch / measure_train
+    faces_all = rk.gather(faces)
     if rk.rank != 0:
         return None
     return {"dry_run": True, "metric": "ray_steps_per_sec", "value": None, "unit": "ray-steps/s", **layout,
-            "ranks_seen": per_rank, "workload": a.workload}
+            "ranks_seen": per_rank, "workload": a.workload, "faces_per_rank": faces, "global_batch": int(sum(faces_all)),
+            "seed0_per_rank": [int(s_) for s_ in seeds], "parallelism": "dp%d" % rk.world,
+            "nominal_ray_steps_per_step": int(sum(faces_all)) * a.lights * a.size * a.size * a.samples}
 
 
 def main():

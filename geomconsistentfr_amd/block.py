@@ -269,6 +269,7 @@ def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParam
         depth, mask_u8, light = prepared.depth, prepared.mask_u8, prepared.light
         if prepared.key != _prepass_key(depth, mask_u8, light, params, options):
             raise _lib.GcfrError("render_fwd(prepared=...): params / options differ from the prepass call's")
+    ambient = _f32c(ambient).reshape(B, L)
     if normals is not None:
         _require_device(normals)
         normals = _f32c(normals).reshape(B, 3, H, W)

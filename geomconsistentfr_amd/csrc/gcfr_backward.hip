@@ -13,6 +13,42 @@
 // (exactly what autograd gives the reference).  Gradients reach: the 4 bilinear corners and the
 // pixel's own depth (f32 atomics into grad_depth), and the light point (block reduction, then one
 // f64 atomic per block and component).
+// Counting build (-DGCFR_BWD_COUNT; tools/bwd_requests.py, round 5): the fused backward's global f32 atomics by SOURCE --
+// per wave instruction: 1 instruction, the 64-B lines its active lanes touch (= requests at the memory side: each a
+// read-modify-write of a line), the elements (active lanes).  Compiled out of the product.
+#ifdef GCFR_BWD_COUNT
+#include <hip/hip_runtime.h>
+namespace gcfr {
+enum { kReqOwnPixel = 0, kReqWindowFlush = 1, kReqFallbackCorners = 2, kReqStencilHalo = 3, kReqSources = 4 };
+__device__ unsigned long long *g_bwd_count = nullptr;   // [source][instructions, lines, elements]
+__device__ inline void bwd_count_request(int src, const void *addr)
+{
+    if (!g_bwd_count)
+        return;
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+    const unsigned long long line = (unsigned long long)addr >> 6;
+    unsigned long long rem = act;
+    int lines = 0;
+    while (rem) {
+        const int l = __builtin_ctzll(rem);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)line, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(line >> 32), l);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(line == (((unsigned long long)hi << 32) | lo));
+        rem &= ~same;
+        ++lines;
+    }
+    if ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == __builtin_ctzll(act)) {
+        atomicAdd(g_bwd_count + 3 * src + 0, 1ull);
+        atomicAdd(g_bwd_count + 3 * src + 1, (unsigned long long)lines);
+        atomicAdd(g_bwd_count + 3 * src + 2, (unsigned long long)__builtin_popcountll(act));
+    }
+}
+}  // namespace gcfr
+#define GCFR_BWD_REQ(src, addr) gcfr::bwd_count_request(src, addr)
+#define GCFR_ATOMIC_HOOK(addr) gcfr::bwd_count_request(gcfr::kReqStencilHalo, addr)
+#else
+#define GCFR_BWD_REQ(src, addr) ((void)0)
+#endif
+
 #include "gcfr_device.hpp"
 
 #include <type_traits>
@@ -654,6 +690,7 @@ __attribute__((amdgpu_waves_per_eu(GCFR_BWD1_WAVES_PER_EU, GCFR_BWD1_WAVES_PER_E
             }
         }
         const double ax = ((double)c - a.nrm.cx) * a.nrm.inv_fx, ay = ((double)r - a.nrm.cy) * a.nrm.inv_fy;
+        GCFR_BWD_REQ(kReqOwnPixel, gz + p);
         atomicAdd(gz + p, (float)((ax * Sx + ay * Sy + Sz) + gzb));
     }
 #if GCFR_BWD_WINDOW
@@ -679,9 +716,14 @@ __attribute__((amdgpu_waves_per_eu(GCFR_BWD1_WAVES_PER_EU, GCFR_BWD1_WAVES_PER_E
             const int nrows = box_r1 - box_r0 + 1, ncols = box_c1 - box_c0 + 1;
             for (int rw = wave; rw < nrows; rw += 4) {
                 const float v = s_win[rw * kBwdWinW + lane];
-                if (lane < ncols && v != 0.0f) {
+                if (lane < ncols) {
+                    // (every cell read is zeroed, not only the ones flushed: a denormal sum compares equal to zero under
+                    //  flush-to-zero and would otherwise stay behind for the next tile's window -- advisor r04)
                     s_win[rw * kBwdWinW + lane] = 0.0f;
-                    atomicAdd(gz + (size_t)(box_r0 + rw) * W + (box_c0 + lane), v);
+                    if (v != 0.0f) {
+                        GCFR_BWD_REQ(kReqWindowFlush, gz + (size_t)(box_r0 + rw) * W + (box_c0 + lane));
+                        atomicAdd(gz + (size_t)(box_r0 + rw) * W + (box_c0 + lane), v);
+                    }
                 }
             }
         }
@@ -728,6 +770,10 @@ __attribute__((amdgpu_waves_per_eu(GCFR_BWD1_WAVES_PER_EU, GCFR_BWD1_WAVES_PER_E
         const int key_next = __builtin_amdgcn_update_dpp(0, key, 0x101, 0xf, 0xf, true);   // row_shl:1
         const bool last = ((lane & 7) == 7) || (key_next != key);
         if (last && key >= 0) {
+            GCFR_BWD_REQ(kReqFallbackCorners, gz + corners.idx[0]);
+            GCFR_BWD_REQ(kReqFallbackCorners, gz + corners.idx[1]);
+            GCFR_BWD_REQ(kReqFallbackCorners, gz + corners.idx[2]);
+            GCFR_BWD_REQ(kReqFallbackCorners, gz + corners.idx[3]);
             atomicAdd(gz + corners.idx[0], v0);
             atomicAdd(gz + corners.idx[1], v1);
             atomicAdd(gz + corners.idx[2], v2);
@@ -1086,6 +1132,14 @@ extern "C" int gcfr_render_bwd(const float *depth, const float *albedo, const fl
                            (hipStream_t)stream, a);
     return launch_status();
 }
+
+#ifdef GCFR_BWD_COUNT
+// counting build only: device buffer of 3 * 4 u64 (zeroed by the caller) the fused backward adds its request tallies to; NULL = off
+extern "C" int gcfr_debug_set_bwd_count(unsigned long long *device_buffer)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(gcfr::g_bwd_count), &device_buffer, sizeof(device_buffer)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 #ifdef GCFR_BWD_TRACE
 extern "C" int gcfr_debug_set_bwd_trace(unsigned long long *device_buffer)

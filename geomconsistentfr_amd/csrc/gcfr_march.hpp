@@ -582,7 +582,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
 
     // OWN: this lane's pixel is outside the mask (or outside the image): not marched.  Carried by `lane_last` = -1 from the
     // candidate range on (no register of its own): a lane without a candidate sample has only masked samples either way.
-    const bool own_off = OWN && (GCFR_M(17, false, !valid) || (buf_load_u8(mr, __mul24(r, W) + c) == 0));
+    const bool own_off = GCFR_M(17, false &&, ) OWN && (!valid || (buf_load_u8(mr, __mul24(r, W) + c) == 0));
 
     const ConstF32Ptr lp = (ConstF32Ptr)(unsigned long long)a->light_pt;
     const float Cx = lp[3 * bl + 0], Cy = lp[3 * bl + 1], Cz = lp[3 * bl + 2];
@@ -721,14 +721,16 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
                 const float inv_dt = __builtin_bit_cast(float, tfl[kTfInvDt]);   // (N - 1) / (tt[N-1] - tt[0]), v_rcp_f32
                 const float ka = (ta - t_first) * inv_dt, kb = (tb - t_first) * inv_dt;
                 // clamp in float first: ta / tb may be +-3e38
-                lane_lo = (int)fminf(fmaxf(floorf(ka) - GCFR_M(12, 0.0f, 1.0f), 0.0f), (float)a->N);
-                lane_hi = (int)fmaxf(fminf(ceilf(kb) + GCFR_M(12, 0.0f, 1.0f), (float)(a->N - 1)), -1.0f);
+                lane_lo = (int)fminf(fmaxf(floorf(ka) - 1.0f, 0.0f), (float)a->N);
+                lane_hi = (int)fmaxf(fminf(ceilf(kb) + 1.0f, (float)(a->N - 1)), -1.0f);
             }
         }
         // readfirstlane: the reductions are wave-uniform by construction, but only an SGPR tells the
         // compiler so -- with VGPR bounds the sample loop turns into a divergent loop (per-lane trip count,
         // vector loads of the sample table, +34 VGPRs: measured 20 % slower).
         lane_last = lane_hi;
+        // (round 5 tried both minima in one reduction -- signed 16-bit halves, v_pk_min_i16 behind each DPP move: more instructions, not
+        //  fewer -- v_min_i32 takes the DPP operand itself, the packed minimum needs a move in front of it)
         const int w_lo = __builtin_amdgcn_readfirstlane(wave_min_i32(lane_lo));
         const int w_hi = -__builtin_amdgcn_readfirstlane(wave_min_i32(-lane_hi));
         const int nb = max(k_begin, w_lo), ne = min(k_end, w_hi + 1);
@@ -1280,8 +1282,8 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         // here: zcur = the record of group k_trail, tc0 / tc3 = its first / last table value, tq = the table values of the group after it
         // Termination in this loop: the same test as finish_check(), with the cap taken from the horizon tables where the
         // prepass built them -- the maximum over the columns AND over the rows the rest of this lane's ray can still touch
-        // (running maxima from the next sample's cell towards the side the ray is heading for; two cells of slack cover the
-        // bilinear corners and the f32 position), instead of the image-wide maximum.
+        // (running maxima from the next sample's cell towards the side the ray is heading for; the slack that covers the bilinear
+        // corners and the f32 position is built into the tables: build_horizon_block), instead of the image-wide maximum.
         for (int k0 = k_trail; k0 < k_end; k0 += DEPTH) {
             const double ta64 = tc0, tb64 = tc3;
             tc0 = tq[0];
@@ -1297,7 +1299,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             const bool gone = lane_last < k0 GCFR_M(27, + 1, );
             GCFR_COUNT(kCntGroupsVisited, 1);
             if (__builtin_amdgcn_ballot_w64(!((cw && GCFR_M(18, true, (bestS < safeS))) || gone)) == 0ull) {
-                any_masked |= GCFR_M(19, false, gone);
+                any_masked |= gone;
                 GCFR_COUNT(kCntTrailSkips, 1);
 #ifdef GCFR_COUNTERS
                 ++cnt_since_body;
@@ -1309,8 +1311,8 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
                     dir_f32(dxl, dyl);
                     const int ci = (int)__builtin_floorf(__builtin_fmaf(tn, dxl, x)), ri = (int)__builtin_floorf(-__builtin_fmaf(tn, dyl, y));
                     constexpr int C = kHorizonDim / 2, M = kHorizonDim - 1;
-                    const int ic = (dxl >= 0.0f) ? kHorizonDim + min(max(ci + (C - GCFR_M(21, 0, 2)), 0), M) : min(max(ci + (C + GCFR_M(21, 1, 3)), 0), M);               // col_suf : col_pre
-                    const int ir = (dyl > 0.0f) ? 2 * kHorizonDim + min(max(ri + (C + GCFR_M(21, 1, 3)), 0), M) : 3 * kHorizonDim + min(max(ri + (C - GCFR_M(21, 0, 2)), 0), M);  // row_pre : row_suf
+                    const int ic = (dxl >= 0.0f) ? kHorizonDim + min(max(ci + C, 0), M) : min(max(ci + C, 0), M);               // col_suf : col_pre
+                    const int ir = (dyl > 0.0f) ? 2 * kHorizonDim + min(max(ri + C, 0), M) : 3 * kHorizonDim + min(max(ri + C, 0), M);  // row_pre : row_suf
                     const f32x4 zc4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, hz_off + (ic << 4), 0, 0));
                     const f32x4 zr4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, hz_off + (ir << 4), 0, 0));
                     const float zc = fmaxf(fmaxf(zc4.x, zc4.y), fmaxf(zc4.z, zc4.w)), zr_ = fmaxf(fmaxf(zr4.x, zr4.y), fmaxf(zr4.z, zr4.w));

@@ -561,14 +561,21 @@ __device__ inline void build_horizon_block(int k, int b, const float *__restrict
     // centred tables: entry kHorizonDim/2 + (j - N/2) belongs to column / row j of the N the image has; entries outside repeat
     // the nearest one.  Component k of the entry's float4 is this band's value.  The wrap partners: every prefix entry includes
     // the image's last column / row, every suffix entry its first (of THIS band's values).
+    // (Round 5) The SLACK of the march's look-up lives here, in the tables: the march asks with the cell its NEXT sample's f32
+    // position falls into; that sample's bilinear corners reach one cell back (u = s - 0.0001 floors to the cell before an integral
+    // s, T8:480-487) and one cell on, and the f32 position may be one cell off the f64 one -- so the suffix entry of cell c covers
+    // the columns >= c - kHzBack, the prefix entry the columns <= c + kHzAhead.  (Rounds 3-4 added the slack in the march's index
+    // arithmetic; as part of the table it is part of what tests/test_gpu_horizon.py pins, entry by entry.)
     constexpr int S = kHorizonDim;
+    constexpr int kHzBack = GCFR_M(21, 0, 2), kHzAhead = GCFR_M(21, 0, 3);
     float *out = (float *)(zb + (size_t)b * zb_slot(H, W) + zb_stride(H, W)) + k;
     {   // columns: this band's column maxima over all W columns
         const int add_pre = GCFR_M(13, 0, s_col[W - 1]), add_suf = GCFR_M(13, 0, s_col[0]);
         for (int i = tid; i < S; i += 256) {
-            const int j = min(max(i - S / 2 + W / 2, 0), W - 1);
-            out[(size_t)i * 4] = __builtin_bit_cast(float, max(s_cpre[j], add_pre));
-            out[(size_t)(S + i) * 4] = __builtin_bit_cast(float, max(s_csuf[j], add_suf));
+            const int c0 = i - S / 2 + W / 2;
+            const int jp = min(max(c0 + kHzAhead, 0), W - 1), js = min(max(c0 - kHzBack, 0), W - 1);
+            out[(size_t)i * 4] = __builtin_bit_cast(float, max(s_cpre[jp], add_pre));
+            out[(size_t)(S + i) * 4] = __builtin_bit_cast(float, max(s_csuf[js], add_suf));
         }
     }
     {   // rows: this band's own rows' maxima, zero elsewhere
@@ -576,9 +583,10 @@ __device__ inline void build_horizon_block(int k, int b, const float *__restrict
         const int add_pre = (GCFR_M(13, false &&, ) nr > 0 && b_hi == H) ? s_row[nr - 1] : 0;  // the band that holds the image's last row
         const int add_suf = (GCFR_M(13, false &&, ) nr > 0 && b_lo == 0) ? s_row[0] : 0;       // ... its first row
         for (int i = tid; i < S; i += 256) {
-            const int j = min(max(i - S / 2 + H / 2, 0), H - 1) - b_lo;  // position among this band's rows (may lie outside)
-            const int pre = nr <= 0 ? 0 : (j < 0 ? 0 : (j >= nr ? total : s_rpre[j]));
-            const int suf = nr <= 0 ? 0 : (j < 0 ? total : (j >= nr ? 0 : s_rsuf[j]));
+            const int r0 = i - S / 2 + H / 2;
+            const int jp = min(max(r0 + kHzAhead, 0), H - 1) - b_lo, js = min(max(r0 - kHzBack, 0), H - 1) - b_lo;  // positions among this band's rows (may lie outside)
+            const int pre = nr <= 0 ? 0 : (jp < 0 ? 0 : (jp >= nr ? total : s_rpre[jp]));
+            const int suf = nr <= 0 ? 0 : (js < 0 ? total : (js >= nr ? 0 : s_rsuf[js]));
             out[(size_t)(2 * S + i) * 4] = __builtin_bit_cast(float, max(pre, add_pre));
             out[(size_t)(3 * S + i) * 4] = __builtin_bit_cast(float, max(suf, add_suf));
         }

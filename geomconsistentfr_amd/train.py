@@ -177,6 +177,17 @@ def ddp_kwargs(cfg: "TrainConfig", device: torch.device, generator: bool, epoch:
     return kw
 
 
+def _canonical_grad_strides(module: nn.Module):
+    """Gradients of convolution weights with a size-1 dimension (the [1, 16, 1, 1] heads) come out of MIOpen's backward with
+    channels-last-looking strides ([16, 1, 16, 16]); DDP's reducer compares them with its bucket view's ([16, 1, 1, 1]) and warns
+    "Grad strides do not match bucket view strides" on every rank -- harmless at these sizes, but noise in the one path that
+    cannot be tested on hardware here.  A size-1 dimension's stride is free: re-viewing the gradient gives it the canonical
+    strides without a copy."""
+    for p_ in module.parameters():
+        if p_.dim() == 4 and 1 in p_.shape:
+            p_.register_hook(lambda g: g.reshape(-1).view(g.shape) if g.is_contiguous() else g.contiguous())
+
+
 class Trainer:
     """One process per GPU.  `step(batch, epoch, j)` = T8:617-656 for one batch of any size."""
 
@@ -185,8 +196,11 @@ class Trainer:
         self.cfg, self.device = cfg, torch.device(device)
         if cfg.miopen_find and self.device.type == "cuda":
             torch.backends.cudnn.benchmark = True
+        if cfg.render_pixels not in ("all", "mask"):
+            raise ValueError("TrainConfig.render_pixels must be 'all' or 'mask', got %r" % (cfg.render_pixels,))
         self.model = (model or RelightNet(cfg.shortcut)).float().to(self.device)
         if cfg.render_pixels != "all":
+            # NB: a `model` passed in by the caller is MUTATED here (its render_params are replaced): the Trainer owns the model
             import dataclasses
             self.model.render_params = dataclasses.replace(self.model.render_params, pixels=cfg.render_pixels)
         self.patchgan = (patchgan or PatchGAN()).float().to(self.device)
@@ -194,6 +208,8 @@ class Trainer:
         self.distributed, self._net_find_unused = distributed, None
         if distributed:
             from torch.nn.parallel import DistributedDataParallel as DDP
+            _canonical_grad_strides(self.model)
+            _canonical_grad_strides(self.patchgan)
             self._wrap_generator(0)
             self.disc = DDP(self.patchgan, **ddp_kwargs(cfg, self.device, generator=False))
         self.opt = torch.optim.Adam(self.model.parameters(), lr=cfg.lr)                  # T8:589
@@ -214,8 +230,11 @@ class Trainer:
             return
         # BatchNorm running statistics stay per GPU (module docstring).  DDP's constructor synchronises module state from
         # rank 0 (_sync_module_states); whether that includes BUFFERS under broadcast_buffers=False has differed between torch
-        # releases, so the buffers are snapshotted and put back around the (re-)wrap instead of trusting the installed one.
-        keep = [(b_, b_.detach().clone()) for b_ in self.model.buffers()]
+        # releases, so on a RE-wrap (training crosses epoch 14: every rank holds its own statistics by then) the buffers are
+        # snapshotted and put back instead of trusting the installed one.  The FIRST wrap is left to DDP: if rank 0 alone loaded a
+        # checkpoint before the Trainer was built, its buffers reach the other ranks with its parameters (advisor r04).
+        rewrap = self._net_find_unused is not None
+        keep = [(b_, b_.detach().clone()) for b_ in self.model.buffers()] if rewrap else []
         self.net = None                                                       # release the previous reducer's hooks
         self.net = DDP(self.model, **kw)                                      # (callers must not cache `trainer.net`: a
         with torch.no_grad():                                                 #  still-referenced old wrapper keeps its hooks)

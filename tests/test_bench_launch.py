@@ -32,6 +32,25 @@ def test_gpus2_self_launch_reaches_rank_startup_and_prints_one_json_line(workloa
     assert d["workload"] == workload
 
 
+@pytest.mark.parametrize("workload", ["render", "train"])
+def test_gpus8_dry_run_keeps_the_books_of_configs3(workload):
+    """BASELINE configs[3] (batch 256 over 8 GPUs) cannot run here; its BOOK-KEEPING can: eight self-launched ranks over gloo,
+    every rank joins the collective, per-rank seeds rank * 10^6 + index, 32 faces per rank in the training workload (8 in the render
+    workload), and the nominal ray-step accounting of one step x 8."""
+    p = _run(["--gpus", "8", "--dry-run", "--workload", workload], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks"] == 8 and d["self_launched"] is True
+    assert d["ranks_seen"] == [float(r) for r in range(8)]
+    faces = 32 if workload == "train" else 8
+    assert d["faces_per_rank"] == faces and d["global_batch"] == 8 * faces
+    assert d["seed0_per_rank"] == [r * 1_000_000 for r in range(8)]
+    assert d["nominal_ray_steps_per_step"] == 8 * faces * 256 * 256 * 160
+    assert d["parallelism"] == "dp8"
+
+
 def test_single_rank_needs_no_launcher():
     p = _run(["--dry-run"])
     assert p.returncode == 0, p.stderr[-2000:]

@@ -12,6 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 S = 1024  # kHorizonDim
+BACK, AHEAD = 2, 3   # cells of slack built into the suffix / prefix entries (gcfr_shadow.hip build_horizon_block)
 
 
 def _tables(depth, mask):
@@ -56,18 +57,24 @@ def _tables(depth, mask):
             tight |= sh
     assert (live | ~tight).all()                      # the kernel's live set contains the tight one
 
-    def scans(v):
+    def scans(v, back=BACK, ahead=AHEAD):
         v = v.copy()
         v[0] = v[-1] = max(v[0], v[-1])               # the corners' wrap partners, folded into both ends
         n = v.size
         pre, suf = np.maximum.accumulate(v), np.maximum.accumulate(v[::-1])[::-1]
-        j = np.clip(np.arange(S) - S // 2 + n // 2, 0, n - 1)
-        return pre[j], suf[j]
+        c0 = np.arange(S) - S // 2 + n // 2           # the cell entry i belongs to (outside the image: the nearest one)
+        # the look-up's slack is part of the table (round 5): the prefix entry of cell c covers the cells <= c + 3, the suffix
+        # entry the cells >= c - 2
+        return pre[np.clip(c0 + ahead, 0, n - 1)], suf[np.clip(c0 - back, 0, n - 1)]
     zl, zt = np.where(live, z, 0.0), np.where(tight, z, 0.0)
     cp, cs = scans(zl.max(axis=0))
     rp, rs = scans(zl.max(axis=1))
-    tcp, tcs = scans(zt.max(axis=0))
-    trp, trs = scans(zt.max(axis=1))
+    # WHAT THE MARCH NEEDS of the entry it looks up for a sample in cell c (its f32 position's floor): a bound on every cell that
+    # sample can read -- its bilinear corners floor(u), ceil(u) with u = s - 0.0001 lie in [c - 1, c + 1] (c - 1: an integral s),
+    # and the f64 position the corners come from may sit one cell beside the f32 one: cells c - 2 ... c + 2 -- and on everything
+    # further along the ray.  Stated on the TIGHT live set, without the kernel's construction.
+    tcp, tcs = scans(zt.max(axis=0), back=2, ahead=2)
+    trp, trs = scans(zt.max(axis=1), back=2, ahead=2)
     return (cp, cs, rp, rs), (tcp, tcs, trp, trs)
 
 
