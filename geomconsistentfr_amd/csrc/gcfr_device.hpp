@@ -102,8 +102,14 @@ __device__ inline void end_point(float x, float y, float Cx, float Cy, const Box
 // epilogue cannot produce -- the 2^32 pre-scaling of denormal-range arguments and its undoing, the 0 / inf class test: 9
 // instructions instead of 19.  The arguments there are S + 1e-4 and |BC|^2 + 1e-4 (T8:509, 508).  tests/test_gpu_sqrt_rn.py
 // compares it with __builtin_sqrtf over EVERY float of that domain.
+// (-DGCFR_R04_FIXED_COST: the A/B build of round 5's fixed-cost cuts -- the five trimmed stages in round 4's form: IEEE square roots
+//  and divisions in the distance finish, the give-up test, lambert_dot() and shadow_transfer(), the 3 x 3 f64 stencil of unit_normal();
+//  tools/build_variant.sh r04_fixed -DGCFR_R04_FIXED_COST, profiles/r05_fixed_cost_ab.txt)
 __device__ inline float sqrt_rn_normal(float x)
 {
+#ifdef GCFR_R04_FIXED_COST
+    return __builtin_sqrtf(x);
+#endif
     const float s = __builtin_amdgcn_sqrtf(x);
     const int si = __builtin_bit_cast(int, s);
     const float s_dn = __builtin_bit_cast(float, si - 1), s_up = __builtin_bit_cast(float, si + 1);
@@ -137,6 +143,13 @@ __device__ inline float exp_neg(float d)  // e^-d, d >= 0 (NaN in, NaN out; larg
 }
 __device__ inline float shadow_transfer(float d)
 {
+#ifdef GCFR_R04_FIXED_COST
+    {
+        const float e = expf(-d);
+        const float onepe = 1.0f + e;
+        return (-4.0f * e) / (onepe * onepe) + 1.0f;
+    }
+#endif
     const float e = exp_neg(d);
     const float onepe = 1.0f + e;
     const float q = onepe * onepe;
@@ -173,6 +186,17 @@ __device__ inline float lambert_dot(float x, float y, float zb, float nx, float 
 {
     // incident light direction, T8:364
     const float lx = Cx - x, ly = Cy - y, lz = Cz - zb;
+#ifdef GCFR_R04_FIXED_COST
+    {
+        float ln = norm3_torch(lx, ly, lz);
+        ln = ln > 1e-12f ? ln : 1e-12f;
+        const float ux = lx / ln, uy = ly / ln, uz = lz / ln;
+        float nn = norm3_torch(nx, ny, nz);
+        nn = nn > 1e-12f ? nn : 1e-12f;
+        const float n0 = nx / nn, n1 = ny / nn, n2 = nz / nn;
+        return (n0 * ux + n1 * uy) + n2 * uz;
+    }
+#endif
     const float rl = inv_norm3_clamped(lx, ly, lz);
     const float ux = lx * rl, uy = ly * rl, uz = lz * rl;
     // surface normal, re-normalised (T8:365)
@@ -326,6 +350,22 @@ __device__ inline double fast_rsqrt64(double x)
 // neighbour is part of a or of b, the centre of every e.
 __device__ inline void unit_normal(const NormalsArgs &a, const float *z, int r, int c, float (&n)[3])
 {
+#ifdef GCFR_R04_FIXED_COST
+    {
+        const Grad3 g = point_gradients(a, z, r, c);
+        const double nx = __builtin_fma(g.du[1], g.dv[2], -(g.du[2] * g.dv[1]));
+        const double ny = __builtin_fma(g.du[2], g.dv[0], -(g.du[0] * g.dv[2]));
+        const double nz = __builtin_fma(g.du[0], g.dv[1], -(g.du[1] * g.dv[0]));
+        const double n2sum = __builtin_fma(nz, nz, __builtin_fma(ny, ny, nx * nx));
+        double nn = n2sum > 1e-24 ? fast_sqrt64(n2sum) : 1e-12;
+        nn = nn > 1e-12 ? nn : 1e-12;
+        const double inv = fast_rcp64(nn);
+        n[0] = (float)(nx * inv);
+        n[1] = (float)(a.negate_y ? -(ny * inv) : (ny * inv));
+        n[2] = (float)(nz * inv);
+        return;
+    }
+#endif
     const int W = a.W;
     const bool has_l = c > 0, has_r = c < W - 1, has_u = r > 0, has_d = r < a.H - 1;
     const float *z1 = z + (size_t)r * W + c;

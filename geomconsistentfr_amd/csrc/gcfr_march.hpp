@@ -618,8 +618,13 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
     // (v_sqrt_f32 / v_rcp_f32, 1 ulp each: n and c1 only ever enter the BOUNDS -- the give-up heuristic, Kerr, the skip and the
     //  termination tests -- whose error terms K1 = ... + 1e-6 |c1| t and K2 r = (1e-6 n + ...) r budget sixteen ulp for each; the
     //  IEEE square root and division cost 27 instructions more per tile, round 5's census)
+#ifdef GCFR_R04_FIXED_COST
+    const float nrm = __builtin_sqrtf(BCx * BCx + BCy * BCy);
+    const float c1 = BCz * ((dxf * BCx + dyf * BCy) / nrm);
+#else
     const float nrm = __builtin_amdgcn_sqrtf(BCx * BCx + BCy * BCy);
     const float c1 = BCz * ((dxf * BCx + dyf * BCy) * __builtin_amdgcn_rcpf(nrm));
+#endif
     // (round 4: the give-up test sits in FRONT of the candidate-range computation -- a tile that hands itself to the rough
     //  variant has then paid for the end point and this test only, not for the box / octagon clipping it would do twice)
     const float t_abs = __builtin_bit_cast(float, tfl[kTfTabs]);  // max(|tt[0]|, |tt[N-1]|)
@@ -941,7 +946,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             //  (profiles/r04_pixels_mainhz_ab.txt).  The main loop rarely terminates, it hands over to the trailing loop.)
             const float gd = __builtin_fmaf(c1, tn, -(__builtin_fmaf(nrm_l, gz_cap, -(nrm_l * zb)) + Kerr));
             const float bS = bestS;
-            const bool finished = (GCFR_M(11, true, (c1 > 0.0f)) && (gd > 0.0f) && (gd * gd * GCFR_M(7, 1.002f, 0.998f) > bS) && (bS < safeS)) ||
+            const bool finished = (GCFR_M(11, true, (c1 > 0.0f)) && (gd > 0.0f) && (gd * gd * GCFR_M(7, GCFR_MUT_SLACK_VALUE, 0.998f) > bS) && (bS < safeS)) ||
                                   (lane_last < k0 + DEPTH GCFR_M(26, + 1, ));
             if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) {
                 any_masked |= (lane_last < k0 + DEPTH GCFR_M(26, + 1, ));
@@ -1321,7 +1326,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
                     const float Dc = __builtin_fmaf(nrm_l, fminf(zc, zr_), -(nrm_l * zb)) + Kerr;  // (Kerr = inf: never finished)
                     const float gd = __builtin_fmaf(c1, tn, -Dc);
                     const bool past = lane_last < k0 + DEPTH GCFR_M(26, + 1, );
-                    const bool finished = (GCFR_M(11, true, (c1 > 0.0f)) && (gd > 0.0f) && (gd * gd * GCFR_M(8, 1.002f, 0.998f) > bestS) && (bestS < safeS)) || past;
+                    const bool finished = (GCFR_M(11, true, (c1 > 0.0f)) && (gd > 0.0f) && (gd * gd * GCFR_M(8, GCFR_MUT_SLACK_VALUE, 0.998f) > bestS) && (bestS < safeS)) || past;
                     if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) {
                         any_masked |= past;
                         GCFR_COUNT(kCntEarlyExit, 1);

@@ -39,6 +39,13 @@
 // 27  trailing loop: "the lane has left the box" (lane_last < this group's first sample)   off by one
 // 29  bound evaluated at the group's first AND last sample (linear in t)             first sample only
 //
+// 3 and 5 are the two mutants no test kills (profiles/r05_mutants.md): K1, K2 r and the plane term budget for three different effects
+// -- the 1e-4 position offset times |BCz|, the f32 roundings of the distance's products, the offset times the surface's slope --
+// each ten times over, and they are ADDED: with one of them gone the other two and the 0.2 % slack still cover its effect wherever
+// a bound is tight enough to be decisive (K1's effect exceeds the rest only within 43 px of an overhead light's foot, where the
+// ray climbs 4000 t and no bounds tile is a thin band; the plane term's only on slopes near the plane fit's limit of 4, where the
+// depth range inflates K2 r).  Kerr as a whole (23) dies in five scene families, K2 r alone (4) far from zero.
+//
 // NOT in the list, because removing them cannot change a result (round 5 built them, they survived, and the reason is a proof, not
 // a missing test):
 //  * candidate range, "one sample of slack either side" (floor(ka) - 1, ceil(kb) + 1): floor / ceil already err on the safe side by
@@ -56,6 +63,9 @@
 #define GCFR_MUT 0
 #endif
 
+#ifndef GCFR_MUT_SLACK_VALUE   // (mutants 7 / 8: what replaces the termination tests' 0.998; tools/mutants.py builds 1.002)
+#define GCFR_MUT_SLACK_VALUE 1.002f
+#endif
 #define GCFR_PP_CAT_(a, b, c) a##b##_##c
 #define GCFR_PP_CAT(a, b, c) GCFR_PP_CAT_(a, b, c)
 #define GCFR_PP_SECOND_(a, b, ...) b

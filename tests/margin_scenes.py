@@ -61,28 +61,6 @@ def family_parallel(seed, H=128, W=128, B=8):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# B  pits in a flat plateau under a light whose (x, y) lies INSIDE the image: near the light's foot n = |BC_xy| is a few pixels,
-#    the ray climbs 4000 t per unit of t and G(t) = n (P - zb - BCz t) runs through zero -- the sample before and the sample after
-#    the crossing are a near-tie for some plateau heights P (swept over the images), the cap of the termination tests IS the
-#    plateau, and of Kerr only K1 = 4e-3 |BCz| is of any size.
-# ---------------------------------------------------------------------------------------------------------------------------
-def family_pits(seed, H=128, W=128, B=16):
-    rng = np.random.default_rng(2000 + seed)
-    Cx, Cy = rng.uniform(-0.3, 0.3) * W, rng.uniform(-0.3, 0.3) * H
-    Cz = float(rng.choice([4013.0, 1500.0, 600.0]))
-    P0 = Cz * rng.uniform(0.03, 0.3)
-    depth, lights = [], []
-    _, _, r, c = grids(H, W)
-    pit = ((r % 8) == rng.integers(0, 8)) & ((c % 8) == rng.integers(0, 8))
-    for b in range(B):
-        P = P0 + b * rng.uniform(0.002, 0.3)
-        depth.append(np.where(pit, 0.0, P).astype(f32))
-        lights.append([[Cx + 0.37, Cy - 0.21, Cz]])
-    return dict(depth=np.stack(depth), mask=np.ones((B, H, W), np.uint8), light_pt=np.array(lights, f32),
-                t_table=table(float(rng.choice([0.025, 0.004])), 0.005, 160), pixels_mask=False)
-
-
-# ---------------------------------------------------------------------------------------------------------------------------
 # C  distances around the masked value 1e6 (T8:512): a plateau so high above the pixels that sqrt(S) / |BC| lands within a few
 #    per cent of 1e6, under masks with holes -- `any_masked` decides the result exactly when the distance is not < 1e6, so every
 #    shortcut that stops looking at the mask ("bestS < safeS", the trailing loop, lanes that have left the box) is on the line.
@@ -193,32 +171,6 @@ def family_table(seed, H=128, W=128, B=8):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# G  a WALL one cell behind the ray.  With the light beside the image (x beyond the right edge, y inside) the rays of the LAST
-#    column end on that column: dx = 0 exactly, every sample has x = W/2 - 1 and reads column W - 2 with weight 1e-4 (the
-#    reference's - 0.0001, T8:480-487).  A wall of height 1e7 in column W - 2 therefore lifts every sampled depth by 1e3, far
-#    above the ground the horizon tables report for column W - 1 alone.  Likewise the last ROW with the light below the image.
-#    (Column 0 / row 0 read the wrap-around column / row: tests/test_gpu_horizon.py.)
-# ---------------------------------------------------------------------------------------------------------------------------
-def family_wall(seed, H=128, W=128, B=8):
-    rng = np.random.default_rng(7000 + seed)
-    X, Y, r, c = grids(H, W)
-    depth, lights = [], []
-    for b in range(B):
-        z = rng.uniform(0, 3) * rng.random((H, W))
-        wall = 10.0 ** rng.uniform(5.5, 7.5)
-        vertical = bool(rng.integers(0, 2))
-        if vertical:                                                  # rays along the last column
-            z[:, W - 2] = wall
-            C = np.array([W * rng.uniform(0.6, 3.0), rng.uniform(-0.45, 0.45) * H, rng.uniform(200, 6000)])
-        else:                                                         # rays along the last row
-            z[H - 2, :] = wall
-            C = np.array([rng.uniform(-0.45, 0.45) * W, -H * rng.uniform(0.6, 3.0), rng.uniform(200, 6000)])
-        depth.append(z.astype(f32))
-        lights.append([C])
-    return dict(depth=np.stack(depth), mask=np.ones((B, H, W), np.uint8), light_pt=np.array(lights, f32), t_table=table(), pixels_mask=False)
-
-
-# ---------------------------------------------------------------------------------------------------------------------------
 # I  cliffs under a COARSE table: 95 samples 0.0085 apart move a ray up to 6.5 cells per group of four at 256 px -- a footprint of
 #    ten cells with its bilinear corners, more than a depth-bounds tile of stride 8 covers from the cell that selects it.  The
 #    prepass picks the stride from the table (a group's reach + 3 cells); piecewise-constant terraces with tall cliffs make a
@@ -260,8 +212,8 @@ def family_negative(seed, H=128, W=130, B=8):
     return dict(depth=np.stack(depth), mask=np.stack(mask), light_pt=np.array(lights, f32), t_table=table(), pixels_mask=False)
 
 
-FAMILIES = {"parallel": family_parallel, "pits": family_pits, "million": family_million, "descending": family_descending,
-            "diamond": family_diamond, "table": family_table, "wall": family_wall, "cliffs": family_cliffs, "negative": family_negative}
+FAMILIES = {"parallel": family_parallel, "million": family_million, "descending": family_descending,
+            "diamond": family_diamond, "table": family_table, "cliffs": family_cliffs, "negative": family_negative}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -442,3 +394,143 @@ def family_parallel2(seed, H=128, W=128, B=8):
 
 
 FAMILIES["parallel2"] = family_parallel2
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# K2 level rays over ground that comes UP towards them by less than the termination tests' slack.  As family K (pixels on a masked-out
+#    plateau `top` above the ground, the light level with them), but the ground carries (a) a ramp that rises by 0.01 ... 0.09 % of
+#    `top` over the ray, or (b) a bump h1 behind the plateau's edge, a dip, and a far bump h2 = h1 + 0.01 ... 0.09 % of `top`:
+#    the far samples are CLOSER to the ray than the running minimum, by less than 0.2 % -- a termination bound without its slack
+#    (over the image-wide cap in the main loop, over the horizon tables' cap in the trailing loop the dip puts the wave into)
+#    calls the march off in front of them.
+# ---------------------------------------------------------------------------------------------------------------------------
+def family_level2(seed, H=128, W=128, B=8):
+    rng = np.random.default_rng(15000 + seed)
+    X, Y, r, c = grids(H, W)
+    depth, mask, lights = [], [], []
+    for b in range(B):
+        az = rng.uniform(0, 2 * np.pi)
+        u = np.array([np.cos(az), np.sin(az)])
+        s = X * u[0] + Y * u[1]
+        top = 10.0 ** rng.uniform(1.6, 3.0)
+        edge = rng.uniform(-0.35, -0.15) * W
+        high = s < edge
+        live = s > edge + 12
+        rise = top * rng.uniform(1e-4, 9e-4)
+        if (seed + b) % 2 == 0:                                       # (a) a ramp
+            ground = np.clip((s - edge - 12) / (0.6 * W), 0.0, 1.0) * rise
+        else:                                                         # (b) bump, dip, far bump
+            h1 = top * rng.uniform(0.003, 0.02)
+            s2 = edge + rng.uniform(45, 70)
+            ground = np.where(s < edge + 26, h1, np.where(s < s2, 0.0, h1 + rise))
+        z = np.where(high, top, ground)
+        dist = 10.0 ** rng.uniform(2.5, 4.5)
+        C = np.array([u[0] * dist, u[1] * dist, top * (1.0 + 10.0 ** rng.uniform(-6.5, -4))])
+        depth.append(z.astype(f32))
+        mask.append(live.astype(np.uint8))
+        lights.append([C])
+    return dict(depth=np.stack(depth), mask=np.stack(mask), light_pt=np.array(lights, f32), t_table=table(), pixels_mask=False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# L2 family L lifted far above zero.  Every bound also has to hold for the isolated sampled value z = 0 (integral coordinates), so
+#    near z = 0 no group is ever "certainly lost" and the wave never walks without its mask; with everything 3e6 ... 6e6 up, the two
+#    plateaus around the masked value do put it there.
+# ---------------------------------------------------------------------------------------------------------------------------
+def family_million3(seed, H=128, W=128, B=8):
+    sc = family_million2(seed, H, W, B)
+    rng = np.random.default_rng(16000 + seed)
+    base = rng.uniform(3e6, 6e6, (B, 1, 1))
+    sc["depth"] = (sc["depth"].astype(np.float64) + base).astype(f32)
+    sc["light_pt"] = sc["light_pt"].copy()
+    sc["light_pt"][:, :, 2] += base[:, :, 0].astype(f32)
+    return sc
+
+
+FAMILIES.update({"level2": family_level2, "million3": family_million3})
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# A3 the parallel-plane construction with the whole scene 1e6 ... 1e7 above zero: the f32 products of the distance (|BA| |BC| 1.2e-7)
+#    are then hundreds of units of G, far more than K1 and the plane term together -- K2 r, the term that grows with the depth
+#    range, is the only thing between that noise and a wrong skip.
+# ---------------------------------------------------------------------------------------------------------------------------
+def family_parallel3(seed, H=128, W=128, B=8):
+    rng = np.random.default_rng(17000 + seed)
+    X, Y, _, _ = grids(H, W)
+    depth, mask, lights = [], [], []
+    for b in range(B):
+        az = rng.uniform(0, 2 * np.pi)
+        el = rng.uniform(0.05, 1.0)
+        base = float(rng.choice([1.0e6, 3.0e6, 1.0e7]))
+        C = far_light(az, el, 4013.0)
+        C[2] += base
+        u = np.array([np.cos(az), np.sin(az)])
+        s = X * u[0] + Y * u[1]
+        v = -X * u[1] + Y * u[0]
+        plane = np.tan(el) * s + base
+        eps0 = 10.0 ** rng.uniform(-0.3, 2.2) * float(rng.choice([-1.0, 1.0]))
+        eps = eps0 * (1.0 + 0.25 * v / max(H, W))
+        s0 = rng.uniform(-0.25, 0.1) * min(H, W)
+        behind = s < s0
+        depth.append(np.where(behind, plane - eps, plane).astype(f32))
+        mask.append((~behind).astype(np.uint8))
+        lights.append([C])
+    return dict(depth=np.stack(depth), mask=np.stack(mask), light_pt=np.array(lights, f32), t_table=table(), pixels_mask=False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# N  steep planar FACETS under grazing light.  32 x 32-pixel facets, each an exact plane with slopes up to +-3.9 per axis (what the
+#    bounds tiles' plane fit represents exactly: thin bands, tight bounds); the light far away and almost level, so K1 ~ |BCz| is
+#    nothing.  The sample POSITION the reference evaluates is 1e-4 beside s(t) (T8:480-487): on a slope of 4 + 4 the sampled depth
+#    differs by 8e-4 from the plane's value at s(t) -- the plane-evaluation term of Kerr.  G runs through the facets linearly, five
+#    n per sample: among thousands of pixels some have a later group's closest sample within that 8e-4 n of their running minimum.
+# ---------------------------------------------------------------------------------------------------------------------------
+def family_facets(seed, H=128, W=128, B=8):
+    rng = np.random.default_rng(18000 + seed)
+    X, Y, r, c = grids(H, W)
+    depth, lights = [], []
+    for b in range(B):
+        cell = 32
+        ph_r, ph_c = 8 * rng.integers(0, 4), 8 * rng.integers(0, 4)
+        fi, fj = (r + ph_r) // cell, (c + ph_c) // cell
+        nf = (H // cell + 2, W // cell + 2)
+        a = rng.uniform(-3.9, 3.9, nf)[fi, fj]
+        bb = rng.uniform(-3.9, 3.9, nf)[fi, fj]
+        off = rng.uniform(-30, 30, nf)[fi, fj]
+        z = a * X + bb * Y + off
+        C = far_light(rng.uniform(0, 2 * np.pi), rng.uniform(1e-3, 0.1), float(rng.choice([4013.0, 1e5])))
+        depth.append(z.astype(f32))
+        lights.append([C])
+    return dict(depth=np.stack(depth), mask=np.ones((B, H, W), np.uint8), light_pt=np.array(lights, f32), t_table=table(), pixels_mask=False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# B2 pits in a plateau under an overhead light, the plateau's height SWEPT in steps of 0.004 through the value at which sample 7
+#    (below the plateau) and sample 8 (above it: the first sample of the group behind a termination check) are equally far from the
+#    ray.  Near the light's foot n is 5 ... 40 px and G = n (P - BCz t): the reference's 1e-4 position offset moves G by 1.4e-4 |BCz|
+#    = 0.56 there, more than the plane term (0.013 n) and K2 r together -- K1 = 4e-3 |BCz| is the term that covers it.  One pit per
+#    tile of the march (16 x 4), so that a tile's fate hangs on one lane.
+# ---------------------------------------------------------------------------------------------------------------------------
+def family_pits2(seed, H=128, W=128, B=24):
+    rng = np.random.default_rng(19000 + seed)
+    Cz = 4013.0
+    tt = table()
+    Cx, Cy = rng.uniform(-0.25, 0.25) * W, rng.uniform(-0.25, 0.25) * H
+    j = int(rng.choice([7, 15]))
+    mid = Cz * 0.5 * (tt[j] + tt[j + 1])
+    _, _, r, c = grids(H, W)
+    pit = ((r % 4) == rng.integers(0, 4)) & ((c % 16) == rng.integers(0, 16))
+    depth, lights = [], []
+    for b in range(B):
+        P = mid + (b - 0.7 * B) * 0.004
+        depth.append(np.where(pit, 0.0, P).astype(f32))
+        lights.append([[Cx + 0.37, Cy - 0.21, Cz]])
+    return dict(depth=np.stack(depth), mask=np.ones((B, H, W), np.uint8), light_pt=np.array(lights, f32), t_table=tt, pixels_mask=False)
+
+
+FAMILIES.update({"parallel3": family_parallel3, "facets": family_facets, "pits2": family_pits2})
+
+
+
+

@@ -32,6 +32,11 @@ KILLERS = [
     ("million", 1, [23, 24]), ("negative", 5, [23]), ("parallel", 36, [23]), ("parallel", 38, [23]),   # Kerr
     ("table", 1, [1]), ("table", 29, [1]),                                 # box inflation under an uneven table
     ("cliffs", 0, [29]), ("cliffs", 8, [16]),
+    ("level2", 0, [7, 8]), ("level2", 1, [7, 8]),                          # the termination tests' 0.2 % (main loop, trailing loop)
+    ("million3", 0, [9, 18]), ("million3", 10, [9]), ("million3", 4, [18]),   # safeS: "certainly below the masked 1e6"
+    ("cliffs2", 18, [22]), ("cliffs2", 63, [22]),                          # the bounds grid's stride: a group's reach + 3 cells
+    ("parallel3", 0, [4, 23]), ("parallel3", 1, [4]),                      # K2 r: the f32 noise of the distance far from zero
+    ("pits2", 0, [23]), ("level", 12, [23]),
 ]
 
 

@@ -107,14 +107,53 @@ def run_soak(n_cases, seed=0, options=None, sizes=None, want_argmin=True, pixels
             "seconds": time.time() - t0}
 
 
+def run_config5(n_faces, seed=0, want_argmin=True):
+    """The soak's leg at BASELINE configs[4]'s shape: `n_faces` random 512 x 512 faces, 18 random lights each
+    (all lights of a face in one launch, as the product shards them), 320 samples, the grid schedule forced (ksplit = 0: bounds
+    skip, trailing loop, horizon tables).  Bit equality of min_dist and argmin against the C oracle."""
+    from geomconsistentfr_amd import _lib
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    H = W = 512
+    N, L = 320, 18
+    prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
+    tt = c_oracle.sample_table(0.025, 0.8 / N, N)
+    n_pix = n_md_diff = n_arg_diff = 0
+    t0 = time.time()
+    for f in range(n_faces):
+        depth, mask, _ = random_case(rng, H, W)
+        lights = rng.standard_normal((L, 3)).astype(np.float32)
+        lights[:, 2] = np.abs(lights[:, 2]) * rng.choice([1.0, 0.1])
+        _, pt = light_prep(torch.from_numpy(lights).to(dev), prm)
+        md, am = shadow_min_distance(torch.from_numpy(depth[None]).to(dev), torch.from_numpy(mask[None]).to(dev), pt.reshape(1, L, 3), prm,
+                                     options=_lib.options(ksplit=0), want_argmin=want_argmin)
+        _, pt_o = c_oracle.light_prep(lights, clamp_z_min=0.0)
+        md_o, am_o = c_oracle.shadow_min_distance(depth[None], mask[None], pt_o[None], tt)
+        md = md.cpu().numpy()
+        n_pix += md.size
+        n_md_diff += int((md.view(np.int32) != md_o.view(np.int32)).sum())
+        if want_argmin:
+            lit = md_o < 1e5
+            n_arg_diff += int((am.cpu().numpy()[lit] != am_o[lit]).sum())
+    return {"leg": "config 5 shape: 512 x 512 x 320, 18 lights per face, grid schedule forced", "faces": n_faces, "seed": seed,
+            "pixels_compared": n_pix, "min_dist_bit_differences": n_md_diff, "argmin_differences": n_arg_diff, "argmin_kernel": want_argmin,
+            "seconds": time.time() - t0}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config5", type=int, default=0, help="N faces at configs[4]'s shape (512 x 512 x 320, 18 lights) instead of the mixed-size soak")
     ap.add_argument("--cases", type=int, default=240)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--tune", type=str, default="", help="comma list of gcfr_options knobs, e.g. schedule=0,tile_w=16")
     ap.add_argument("--no-argmin", action="store_true", help="the inference kernels (six waves / SIMD, no argmin output)")
     a = ap.parse_args()
     from geomconsistentfr_amd import _lib
+    if a.config5:
+        r = run_config5(a.config5, a.seed, want_argmin=not a.no_argmin)
+        r.update(library=_lib.load().gcfr_version().decode())
+        print(json.dumps(r))
+        return
     knobs = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)}
     r = run_soak(a.cases, a.seed, _lib.options(**knobs) if knobs else None, want_argmin=not a.no_argmin,
                  pixels_mask=knobs.get("pixels", 0) == 1)
