@@ -203,9 +203,9 @@ def cpu_baseline_c(sample_faces=8, seed0=0):
 
 def measured_copy_bandwidth_gbs(dev, mb=1024, iters=10):
     """Achievable HBM rate (read + write bytes) -- the denominator SURVEY.md 8d asks to report beside the 8 TB/s spec peak:
-    the library's float4 grid-stride copy kernel (gcfr_copy_probe: 16 B per lane and step, 8192 workgroups, the recipe
-    MI355X_MICROARCH.md quotes 6.29 TB/s for), 1 GiB in and 1 GiB out, HIP events on the launch stream.  Rounds 1-4 timed
-    torch's copy_ here, which reached 4.8 TB/s."""
+    the library's float4 grid-stride copy kernel (gcfr_copy_probe: one workgroup per CU, four 16-B loads in flight per lane,
+    non-temporal -- the best of tools/copy_probe_sweep.hip's sweep: 6.27 TB/s, MI355X_MICROARCH.md quotes 6.29), 1 GiB in and 1 GiB
+    out, HIP events on the launch stream.  Rounds 1-4 timed torch's copy_ here, which reached 4.8 TB/s."""
     import ctypes
     from geomconsistentfr_amd import _lib
     L = _lib.load()

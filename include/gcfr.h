@@ -377,8 +377,8 @@ int gcfr_masked_metrics_u8(const uint8_t *recon_u8, const uint8_t *gt_u8, const 
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement aid (bench.py `roofline.hbm_measured_copy_GBs`): a float4 grid-stride device-to-device copy of `bytes` bytes
- * (multiple of 16, both pointers 16-byte aligned), 8192 workgroups of 256 lanes -- the achievable-HBM probe the roofline's 8 TB/s
- * spec peak is reported beside.  Not part of the render path.
+ * (multiple of 16, both pointers 16-byte aligned), one workgroup of 256 lanes per CU, four loads in flight per lane, non-temporal --
+ * the achievable-HBM probe (6.3 TB/s, read + write) the roofline's 8 TB/s spec peak is reported beside.  Not part of the render path.
  * ------------------------------------------------------------------------------------------- */
 int gcfr_copy_probe(const void *src, void *dst, size_t bytes, void *stream);
 
