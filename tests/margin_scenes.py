@@ -530,7 +530,3 @@ def family_pits2(seed, H=128, W=128, B=24):
 
 
 FAMILIES.update({"parallel3": family_parallel3, "facets": family_facets, "pits2": family_pits2})
-
-
-
-

@@ -125,8 +125,10 @@ def table():
               "effect (1.4e-4 |BCz|) exceeds the rest only within 43 px of an overhead light's foot, where the ray climbs 4000 t per unit of t and no",
               "bounds tile is a thin band; the plane term's (8e-4 n on slopes 4 + 4) only where such slopes make the depth range -- and with it",
               "K2 r -- large.  Tried: families `pits2` (plateau height swept in steps of 0.004 through the tie of samples 7 / 8 under an overhead",
-              "light), `facets`, `facets2`, `sawtooth` (steep planar facets on the tiles' grid under level light), 300 seeds each: Kerr = 0 dies",
-              "there, the single terms do not.",
+              "light; a variant with the pits on the diagonals through the light's foot and steps of 0.001 fails for a structural reason: a pit",
+              "close enough to the foot for K1 to dominate, n < 15 px, has its first eight samples within a pixel of itself, inside its own",
+              "bilinear footprint, and later samples mean a higher plateau, a larger depth range and a larger K2 r), `facets`, `facets2`, `sawtooth`",
+              "(steep planar facets on the tiles' grid under level light), up to 300 seeds each: Kerr = 0 dies there, the single terms do not.",
               "",
               "**Removed from the list with a proof that they cannot change a result** (`csrc/gcfr_mutants.hpp`): the candidate range's extra",
               "sample of slack either side (floor / ceil already err by up to a step on the safe side; an accepted table deviates < 0.08 steps",
