@@ -368,13 +368,16 @@ __device__ inline void unit_normal(const NormalsArgs &a, const float *z, int r, 
 #endif
     const int W = a.W;
     const bool has_l = c > 0, has_r = c < W - 1, has_u = r > 0, has_d = r < a.H - 1;
-    const float *z1 = z + (size_t)r * W + c;
-    const int ol = has_l ? -1 : 0, orr = has_r ? 1 : 0, ou = has_u ? -W : 0, od = has_d ? W : 0;
+    // (raw buffer loads, byte offsets in 32 bits off one descriptor of the image's plane: no 64-bit address arithmetic per neighbour)
+    const __amdgpu_buffer_rsrc_t zr = make_rsrc(z, a.H * W * 4);
+    const int b11 = (r * W + c) << 2, W4 = W << 2;
+    const int bu = has_u ? b11 - W4 : b11, bd = has_d ? b11 + W4 : b11;
+    const int ol = has_l ? 4 : 0, orr = has_r ? 4 : 0;
     const float off = a.z_offset;
-    const float D11 = z1[0] + off;  // depth + 1610 in f32 (T8:353)
-    const float e00 = (z1[ou + ol] + off) - D11, e01 = (z1[ou] + off) - D11, e02 = (z1[ou + orr] + off) - D11;
-    const float e10 = (z1[ol] + off) - D11, e12 = (z1[orr] + off) - D11;
-    const float e20 = (z1[od + ol] + off) - D11, e21 = (z1[od] + off) - D11, e22 = (z1[od + orr] + off) - D11;
+    const float D11 = buf_load_f32(zr, b11) + off;  // depth + 1610 in f32 (T8:353)
+    const float e00 = (buf_load_f32(zr, bu - ol) + off) - D11, e01 = (buf_load_f32(zr, bu) + off) - D11, e02 = (buf_load_f32(zr, bu + orr) + off) - D11;
+    const float e10 = (buf_load_f32(zr, b11 - ol) + off) - D11, e12 = (buf_load_f32(zr, b11 + orr) + off) - D11;
+    const float e20 = (buf_load_f32(zr, bd - ol) + off) - D11, e21 = (buf_load_f32(zr, bd) + off) - D11, e22 = (buf_load_f32(zr, bd + orr) + off) - D11;
     const float h0 = e02 - e00, h1 = e12 - e10, h2 = e22 - e20;
     const float g0 = e20 - e00, g1 = e21 - e01, g2 = e22 - e02;
     const float a8 = __builtin_fmaf(2.0f, h1, h0 + h2), b8 = __builtin_fmaf(2.0f, g1, g0 + g2);  // (2 h exact: the fma rounds once, as the sum would)

@@ -675,51 +675,35 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         const int r_min = st.r_min, c_min = st.c_min, r_max = st.r_max, c_max = st.c_max;
         int lane_lo = a->N, lane_hi = -1;  // empty
         if (r_min != kBBoxInit && !(OWN && own_off)) {
-            const float X0 = (float)c_min - halfWf - GCFR_M(1, 0.49f, 0.51f), X1 = (float)c_max - halfWf + GCFR_M(1, 0.49f, 0.51f);
-            const float Y0 = halfHf - (float)r_max - GCFR_M(1, 0.49f, 0.51f), Y1 = halfHf - (float)r_min + GCFR_M(1, 0.49f, 0.51f);
+            // (wave-uniform, and gfx950 has no scalar float unit: the integer part on the scalar unit, then one conversion and one fma
+            //  each -- 0.5 (2 c - W) is exactly c - W/2)
+            const float X0 = __builtin_fmaf(0.5f, (float)(2 * c_min - W), -GCFR_M(1, 0.49f, 0.51f)), X1 = __builtin_fmaf(0.5f, (float)(2 * c_max - W), GCFR_M(1, 0.49f, 0.51f));
+            const float Y0 = __builtin_fmaf(0.5f, (float)(H - 2 * r_max), -GCFR_M(1, 0.49f, 0.51f)), Y1 = __builtin_fmaf(0.5f, (float)(H - 2 * r_min), GCFR_M(1, 0.49f, 0.51f));
             float ta = -3.0e38f, tb = 3.0e38f;
             bool empty = !finite_ray;
-            // (v_rcp_f32, 1 ulp: the 0.01-pixel margin dwarfs it; four IEEE divisions cost ~50 VALU per wave)
-            if (dxf != 0.0f) {
-                const float inv = __builtin_amdgcn_rcpf(dxf);
-                const float t1 = (X0 - x) * inv, t2 = (X1 - x) * inv;
-                ta = fmaxf(ta, fminf(t1, t2));
-                tb = fminf(tb, fmaxf(t1, t2));
-            } else {
-                empty = empty || (x < X0) || (x > X1);
-            }
-            if (dyf != 0.0f) {
-                const float inv = __builtin_amdgcn_rcpf(dyf);
-                const float t1 = (Y0 - y) * inv, t2 = (Y1 - y) * inv;
-                ta = fmaxf(ta, fminf(t1, t2));
-                tb = fminf(tb, fmaxf(t1, t2));
-            } else {
-                empty = empty || (y < Y0) || (y > Y1);
-            }
+            // One slab: p + t dp inside [lo, hi].  dp == 0: no constraint on t if p is inside, no t at all if it is not.  Branch-free (round 5: as
+            // `if (dp != 0) ... else ...` each of the four slabs was a divergent region of its own, ~19 VALU and ~18 scalar
+            // instructions and branches apiece).  (v_rcp_f32, 1 ulp: the 0.01-pixel margin dwarfs it; four IEEE divisions cost ~50
+            // VALU per wave)
+            auto slab = [&](float p, float dp, float lo, float hi) {
+                const bool still = dp == 0.0f;
+                const float inv = __builtin_amdgcn_rcpf(dp);
+                const float t1 = (lo - p) * inv, t2 = (hi - p) * inv;
+                const float whole = ((p < lo) || (p > hi)) ? 3.0e38f : -3.0e38f;  // dp == 0: t in [-big, big], or the empty [big, -big]
+                ta = fmaxf(ta, still ? whole : fminf(t1, t2));
+                tb = fminf(tb, still ? -whole : fmaxf(t1, t2));
+            };
+            slab(x, dxf, X0, X1);
+            slab(y, dyf, Y0, Y1);
             // ... and inside the mask's bounding OCTAGON (round 3): the cell's column + row and column - row lie within the
             // extents the prepass found, i.e. (s_x + W/2) +- (H/2 - s_y) does to within 1 (two roundings of 0.5) + 0.02.  For
             // an elliptical mask the octagon cuts four fifths of the box's corners: -18 % visited groups (tools/sim_octagon.py).
             if (st.mask_all_ones == 0) {  // (wave-uniform; an all-ones mask's octagon is its box)
-                const float hs = 0.5f * (float)(W + H), hd = 0.5f * (float)(W - H);
-                const float U0 = (float)st.s_min - hs - GCFR_M(2, 0.98f, 1.02f), U1 = (float)st.s_max - hs + GCFR_M(2, 0.98f, 1.02f);
-                const float V0 = (float)st.d_min - hd - GCFR_M(2, 0.98f, 1.02f), V1 = (float)st.d_max - hd + GCFR_M(2, 0.98f, 1.02f);
-                const float u = x - y, du = dxf - dyf, v = x + y, dv = dxf + dyf;
-                if (du != 0.0f) {
-                    const float inv = __builtin_amdgcn_rcpf(du);
-                    const float t1 = (U0 - u) * inv, t2 = (U1 - u) * inv;
-                    ta = fmaxf(ta, fminf(t1, t2));
-                    tb = fminf(tb, fmaxf(t1, t2));
-                } else {
-                    empty = empty || (u < U0) || (u > U1);
-                }
-                if (dv != 0.0f) {
-                    const float inv = __builtin_amdgcn_rcpf(dv);
-                    const float t1 = (V0 - v) * inv, t2 = (V1 - v) * inv;
-                    ta = fmaxf(ta, fminf(t1, t2));
-                    tb = fminf(tb, fmaxf(t1, t2));
-                } else {
-                    empty = empty || (v < V0) || (v > V1);
-                }
+                const int ws = W + H, wd = W - H;
+                const float U0 = __builtin_fmaf(0.5f, (float)(2 * st.s_min - ws), -GCFR_M(2, 0.98f, 1.02f)), U1 = __builtin_fmaf(0.5f, (float)(2 * st.s_max - ws), GCFR_M(2, 0.98f, 1.02f));
+                const float V0 = __builtin_fmaf(0.5f, (float)(2 * st.d_min - wd), -GCFR_M(2, 0.98f, 1.02f)), V1 = __builtin_fmaf(0.5f, (float)(2 * st.d_max - wd), GCFR_M(2, 0.98f, 1.02f));
+                slab(x - y, dxf - dyf, U0, U1);
+                slab(x + y, dxf + dyf, V0, V1);
             }
             if (!empty && ta <= tb) {
                 const float t_first = __builtin_bit_cast(float, tfl[kTfTfirst]);  // (float)tt[0]
@@ -1055,7 +1039,12 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         // whole group in the k-split variant, whose launches are tiny and latency-bound
         // (the argmin variant runs at five waves per SIMD and has the registers for two gathers in flight: +5 % on smooth and on
         //  rough depth, round 3; the six-wave inference variant at five waves with two in flight: -2 ... -3 %)
-        constexpr int GCFR_BODY_CHUNK = KSPLIT ? DEPTH : (WANT_ARGMIN && DEPTH >= 2 ? 2 : 1);  // (KSPLIT here: SPLIT == 1 only)
+#ifndef GCFR_INFER_BODY_CHUNK
+#define GCFR_INFER_BODY_CHUNK 1   // (-DGCFR_MARCH_WAVES_PER_EU=5 -DGCFR_INFER_BODY_CHUNK=2, re-measured in round 5 on the bench faces: one batch at a
+                                  //  time +1.8 % (1.100 against 1.080 T), four in flight -0.8 % (2.180 against 2.197 T); four waves with two or
+                                  //  four in flight lose both ways: profiles/r05_body_chunk_ab.txt)
+#endif
+        constexpr int GCFR_BODY_CHUNK = KSPLIT ? DEPTH : (WANT_ARGMIN && DEPTH >= 2 ? 2 : GCFR_INFER_BODY_CHUNK);  // (KSPLIT here: SPLIT == 1 only)
         if (run_body) {
           GCFR_COUNT(kCntBodies, 1);
 #ifdef GCFR_COUNTERS

@@ -607,26 +607,38 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float *__restrict
 {
     const int Wp = W + 1, Hp = H + 1;
     const int b = blockIdx.y;
+    // (-DGCFR_PREPASS_JOBS=<bit mask>: which jobs run -- horizon 1, bounds 2, statistics 4, bitmap 8, repack 16; timing experiments
+    //  only, tools/prepass_jobs.py: the workspace is garbage without all of them)
+#ifdef GCFR_PREPASS_JOBS
+#define GCFR_JOB(bit) (((GCFR_PREPASS_JOBS) >> (bit)) & 1)
+#else
+#define GCFR_JOB(bit) 1
+#endif
     if ((int)blockIdx.x < hz_blocks) {  // (head of the grid: the longest job of the prepass; one block per image and row band)
-        build_horizon_block((int)blockIdx.x, b, depth, mask, mask_batch, H, W, zb);
+        if (GCFR_JOB(0))
+            build_horizon_block((int)blockIdx.x, b, depth, mask, mask_batch, H, W, zb);
         return;
     }
     const int bx = (int)blockIdx.x - hz_blocks;
     if (bx < zb_blocks) {
-        build_zbounds_block(bx, b, depth, zb, H, W, N, t_table, group);
+        if (GCFR_JOB(1))
+            build_zbounds_block(bx, b, depth, zb, H, W, N, t_table, group);
         return;
     }
     if (bx < zb_blocks + stat_blocks) {
-        build_stats_block(bx - zb_blocks, b, depth, mask, mask_batch, H, W, bbox, zrange, mones, diag,
-                          want_z != 0, vec_ok != 0);
+        if (GCFR_JOB(2))
+            build_stats_block(bx - zb_blocks, b, depth, mask, mask_batch, H, W, bbox, zrange, mones, diag,
+                              want_z != 0, vec_ok != 0);
         return;
     }
     if (bx < zb_blocks + stat_blocks + bitmap_blocks) {
-        if (b < mask_batch)
+        if (GCFR_JOB(3) && b < mask_batch)
             build_bitmap_block(bx - zb_blocks - stat_blocks, b, mask, H, W, bitmap);
         return;
     }
     const int qb = bx - zb_blocks - stat_blocks - bitmap_blocks;
+    if (!GCFR_JOB(4))
+        return;
 #ifndef GCFR_QUAD_PER_THREAD
 #define GCFR_QUAD_PER_THREAD 4
 #endif
