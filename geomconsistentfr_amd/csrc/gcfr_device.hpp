@@ -19,7 +19,7 @@ constexpr float kMaskedDistance = 1000000.0f;  // T8:512
 // drop writes, so a corrupted index can never fault the GPU.
 constexpr int kBufferRsrcWord3 = 0x00020000;
 
-// census: tile set-up: lane, pixel, descriptors, light, own depth
+// census: @caller
 __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void *p, int bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, kBufferRsrcWord3);

@@ -7,7 +7,8 @@ How: csrc/gcfr_march_unit.hip is compiled for gfx950 with -gline-tables-only (de
 instruction the source line it came from (inlined callees keep THEIR lines: end_point(), unit_normal(), lambert_dot() ...), and the
 DWARF inlined-subroutine tree says which instantiation of march_tile() an instruction belongs to -- a grid kernel holds four
 (all-ones mask or not) x (bounds variant or rough variant), and a tile executes one (a rough tile: two prologues).  A source line
-belongs to the stage named by the last `// census: <stage>` marker above it in its file.
+belongs to the stage named by the last `// census: <stage>` marker above it in its file (`// census: @caller`: the lines below are
+helpers that count where they are called from -- the buffer-load wrappers).
 
 The fixed stages (tile set-up, end point, candidate range, bounds set-up, epilogue ...) are straight-line code executed once per
 tile, so their static counts ARE the per-tile dynamic counts (both arms of a wave-uniform branch are listed; which one a
@@ -202,6 +203,9 @@ def main():
             dump = args.pop(0)
         elif a == "--co":         # a code object compiled earlier with -gline-tables-only (skips the compilation)
             prebuilt = args.pop(0)
+        elif a == "--csrc":       # another copy of csrc/ (an earlier commit's, for a like-for-like table)
+            global CSRC
+            CSRC = os.path.abspath(args.pop(0))
         else:
             defines.append(a)
     tw = next((d.split("=")[1] for d in defines if d.startswith("-DGCFR_UNIT_TILE_W=")), "16")
@@ -256,11 +260,13 @@ def main():
     def caller_in_sources(addr, f, ln):
         """an instruction whose own line lies in a header outside csrc/ (fminf, floor, expf, __mul24 ...): the line of the innermost
         call site that does lie in csrc/, through the inlined-subroutine chain"""
-        if f and os.path.basename(f) in maps:
+        def ours(ff, ll):  # a line of csrc/ whose stage is not "@caller" (tiny helpers -- buffer loads -- count where they are called)
+            return bool(ff) and os.path.basename(ff) in maps and stage_of(maps, ff, ll) != "@caller"
+        if ours(f, ln):
             return f, ln
         chain = sorted((d for d in tree if any(lo <= addr < hi for lo, hi in d[2])), key=lambda d: -d[0])
         for _, _, _, cfile, cline in chain:
-            if cfile and os.path.basename(cfile) in maps:
+            if ours(cfile, cline):
                 return cfile, cline
         return f, ln
 
