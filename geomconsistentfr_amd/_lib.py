@@ -20,10 +20,13 @@ _ERRORS = {-1: "GCFR_ERR_INVALID_ARGUMENT", -2: "GCFR_ERR_LAUNCH"}
 
 _p, _i, _f, _d = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_double
 
-N_COUNTERS = 20      # GCFR_N_COUNTERS
+N_COUNTERS = 28      # GCFR_N_COUNTERS
 COUNTER_NAMES = ("tiles", "groups_nominal", "groups_visited", "bound_tests", "bodies", "lane_samples", "early_exits",
                  "tie_remarches", "samples_in_range", "bounds_given_up", "visits_after_last_body", "visits_before_first_body",
-                 "trail_enter", "trail_skips", "trail_leave", "rough_samples", "wave_samples", "wave_samples_taken", "lane_takes")
+                 "trail_enter", "trail_skips", "trail_leave", "rough_samples", "wave_samples", "wave_samples_taken", "lane_takes",
+                 # the audit build (-DGCFR_AUDIT, csrc/gcfr_march.hpp): claims checked / contradicted; audit_max_use is a maximum (1/1000 of Kerr)
+                 "audit_bound_checks", "audit_bound_violations", "audit_term_checks", "audit_term_violations",
+                 "audit_masked_checks", "audit_masked_violations", "audit_safe_violations", "audit_max_use")
 
 
 class Options(ctypes.Structure):

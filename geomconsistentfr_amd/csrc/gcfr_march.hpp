@@ -333,8 +333,26 @@ __device__ inline int lo32(double v)
 // gcfr_options.counters once per tile.  Compiled out of the product build.
 enum { kCntTiles, kCntGroupsNominal, kCntGroupsVisited, kCntBoundTests, kCntBodies, kCntLaneSamples, kCntEarlyExit,
        kCntTieRemarch, kCntSamplesInRange, kCntBoundsGivenUp, kCntVisitsAfterLastBody, kCntVisitsBeforeFirstBody,
-       kCntTrailEnter, kCntTrailSkips, kCntTrailLeave, kCntRoughSamples, kCntWaveSamples, kCntWaveSamplesTaken, kCntLaneTakes, kCntUsed };
+       kCntTrailEnter, kCntTrailSkips, kCntTrailLeave, kCntRoughSamples, kCntWaveSamples, kCntWaveSamplesTaken, kCntLaneTakes,
+       // (-DGCFR_AUDIT, see below) lane-samples a claim spoke for / samples that contradict it; the last one is a maximum, not a sum
+       kCntAuditBoundChecks, kCntAuditBoundViol, kCntAuditTermChecks, kCntAuditTermViol, kCntAuditMaskedChecks, kCntAuditMaskedViol,
+       kCntAuditSafeViol, kCntAuditMaxUse, kCntUsed };
 static_assert(kCntUsed <= GCFR_N_COUNTERS, "gcfr_options.counters holds GCFR_N_COUNTERS tallies");
+// The AUDIT build (-DGCFR_COUNTERS -DGCFR_AUDIT; tools/audit.py, tests/test_gpu_audit.py; round 5).  Every claim the march makes
+// about samples it does NOT evaluate is checked against the plain evaluation of exactly those samples (ray_sample(): the depth plane
+// and the mask, no workspace, no bounds), whether or not the claim was decisive for a result:
+//   * the depth-bound test: "g > 0  =>  S_k >= 0.998 g^2 for every unmasked sample k of the group" -- at EVERY evaluation of the
+//     bound, not only where it skipped something (kCntAuditBound*); and how much of the error budget Kerr the evaluation used up,
+//     (raw bound - sqrt(S_k)) / Kerr, as a maximum in 1/1000 (kCntAuditMaxUse: 1000 would be a bound without any margin left);
+//   * early termination, main and trailing loop: the same for every later sample of a lane that is finished by the bound (kCntAuditTerm*);
+//   * "this sample is masked": the candidate range (every sample outside [lane_lo, lane_hi]), lane_last at terminations and in the
+//     trailing loop's skips (kCntAuditMasked*);
+//   * "this lane's distance is certainly below the masked value" wherever bestS < safeS lets a lane ignore its any_masked (kCntAuditSafeViol).
+// An end-to-end comparison only sees a wrong claim when it changes a minimum; the audit sees it whenever it is made -- which is what
+// kills the mutants whose margin is shadowed by its neighbours in every decisive case (csrc/gcfr_mutants.hpp: 3 and 5).
+#if defined(GCFR_AUDIT) && !defined(GCFR_COUNTERS)
+#error "-DGCFR_AUDIT needs -DGCFR_COUNTERS"
+#endif
 #ifdef GCFR_COUNTERS
 #define GCFR_COUNT(i, n) (cnt[i] += (unsigned)(n))
 #else
@@ -606,6 +624,41 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
     const double Mx = EVEN_HALF ? kRintMagic + halfW : kRintMagic;
     const double My = EVEN_HALF ? kRintMagic + halfH : kRintMagic;
     const int quad_origin = (Wp + 1) << 4;  // byte offset of texel (r=0, c=0)
+#ifdef GCFR_AUDIT   // (see the counters: every claim about samples that are not evaluated, checked against their plain evaluation)
+    RayConst arc;
+    arc.H = H;
+    arc.W = W;
+    arc.halfW = halfW;
+    arc.halfH = halfH;
+    arc.x = x;
+    arc.y = y;
+    arc.zb = zb;
+    arc.dx = dxf;
+    arc.dy = dyf;
+    arc.BCx = BCx;
+    arc.BCy = BCy;
+    arc.BCz = BCz;
+    arc.x64 = x64;
+    arc.y64 = y64;
+    arc.dx64 = dx64;
+    arc.dy64 = dy64;
+    const __amdgpu_buffer_rsrc_t azr = make_rsrc(a->depth + (size_t)b * P, (int)(P * 4));
+    bool audit_dead = false;  // pixels = mask: a lane that is not marched sees every sample as masked (by the option's definition)
+    auto audit_S = [&](int k, bool &masked) -> float {  // sample k of this lane's ray, from the depth plane and the mask
+        const float S = ray_sample(arc, (double)tt[k], azr, mr, masked);
+        masked = masked || audit_dead;
+        return S;
+    };
+    auto audit_count = [&](int slot, bool pred) { cnt[slot] += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pred)); };
+    auto audit_masked = [&](int k_from, int k_to, bool claim) {  // "samples [k_from, k_to) of the lanes in `claim` are masked"
+        for (int k = k_from; k < k_to; ++k) {
+            bool m;
+            (void)audit_S(k, m);
+            audit_count(kCntAuditMaskedChecks, claim && finite_ray);
+            audit_count(kCntAuditMaskedViol, claim && finite_ray && !m);
+        }
+    };
+#endif
 // census: give-up test (incl. nrm, c1)
     const ConstI32Ptr tfl = (ConstI32Ptr)(unsigned long long)a->tflag;  // the prepass' record about the sample table (scalar loads)
     const bool t_increasing = (a->N >= 2) && (tfl[kTfOk] != 0);  // checked by the prepass (see its table check)
@@ -718,6 +771,16 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         // compiler so -- with VGPR bounds the sample loop turns into a divergent loop (per-lane trip count,
         // vector loads of the sample table, +34 VGPRs: measured 20 % slower).
         lane_last = lane_hi;
+#ifdef GCFR_AUDIT
+        audit_dead = OWN && own_off;
+        for (int k = 0; k < a->N; ++k) {  // the candidate range: every sample outside [lane_lo, lane_hi] is masked
+            bool m;
+            (void)audit_S(k, m);
+            const bool claim = finite_ray && ((k < lane_lo) || (k > lane_hi));
+            audit_count(kCntAuditMaskedChecks, claim);
+            audit_count(kCntAuditMaskedViol, claim && !m);
+        }
+#endif
         // (round 5 tried both minima in one reduction -- signed 16-bit halves, v_pk_min_i16 behind each DPP move: more instructions, not
         //  fewer -- v_min_i32 takes the DPP operand itself, the packed minimum needs a move in front of it)
         const int w_lo = __builtin_amdgcn_readfirstlane(wave_min_i32(lane_lo));
@@ -861,6 +924,27 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
     // past N-1 are clamped to N-1: re-evaluating the last sample changes neither the minimum nor the
     // (first) argmin, so the tail needs no branch.
     auto clampk = [&](int k) { return k < k_end ? k : k_end - 1; };
+#ifdef GCFR_AUDIT
+    // "this lane's distance is certainly below the masked value 1e6" (where bestS < safeS lets a lane ignore its any_masked)
+    auto audit_safe = [&](bool claim) {
+        const float den_a = sqrt_rn_normal(((BCx * BCx + BCy * BCy) + BCz * BCz) + kEps4);
+        const float d_a = sqrt_rn_normal(bestS) / den_a;
+        audit_count(kCntAuditSafeViol, claim && finite_ray && !(d_a < kMaskedDistance));
+    };
+    // the wave stops in front of sample k_from: a lane finished by the bound (`by_bound`, its gd, the slack of the test) claims
+    // S_k >= slack gd^2 for each of its later unmasked samples, a lane finished by its range (`by_last`) that they are all masked
+    auto audit_finish = [&](int k_from, bool by_bound, float gd, float slack, bool by_last) {
+        for (int k = k_from; k < k_end; ++k) {
+            bool m;
+            const float S = audit_S(k, m);
+            audit_count(kCntAuditTermChecks, by_bound && !m);
+            audit_count(kCntAuditTermViol, by_bound && !m && (S < gd * gd * slack));
+            audit_count(kCntAuditMaskedChecks, !by_bound && by_last && finite_ray);
+            audit_count(kCntAuditMaskedViol, !by_bound && by_last && finite_ray && !m);
+        }
+        audit_safe(by_bound);
+    };
+#endif
     struct Prefetched {  // what is gathered one group ahead: the group's mask bytes and its depth bounds
         uint32_t m[DEPTH];
         f32x4 z;  // {a, b, c_lo, c_hi}
@@ -935,6 +1019,10 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) {
                 any_masked |= (lane_last < k0 + DEPTH GCFR_M(26, + 1, ));
                 GCFR_COUNT(kCntEarlyExit, 1);
+#ifdef GCFR_AUDIT
+                audit_finish(k0 + DEPTH, GCFR_M(11, true, (c1 > 0.0f)) && (gd > 0.0f) && (gd * gd * GCFR_M(7, GCFR_MUT_SLACK_VALUE, 0.998f) > bS) && (bS < safeS),
+                             gd, GCFR_M(7, GCFR_MUT_SLACK_VALUE, 0.998f), lane_last < k0 + DEPTH GCFR_M(26, + 1, ));
+#endif
                 return false;
             }
         }
@@ -943,7 +1031,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
 // census: loop: depth-bound test
     // bound_cw(): the depth-bound test of one group for this lane -- true: no sample of the group can lower (or tie) the
     // lane's running minimum.  cz: the group's bounds record, ta64 / tb64: its first / last table value.
-    auto bound_cw = [&](const f32x4 &cz, double ta64, double tb64) -> bool {
+    auto bound_cw = [&](const f32x4 &cz, double ta64, double tb64, int k0) -> bool {
             GCFR_COUNT(kCntBoundTests, 1);
             const float ta = (float)ta64, tb = (float)tb64;  // tt[k0], tt[clampk(k0 + DEPTH - 1)]
             // (n zb re-multiplied per test from a laundered zb: hoisted out of the loops it is one more live register than the
@@ -965,6 +1053,21 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             const float gap = fmaxf(Flo + fminf(eA, eB), -(Fhi + fmaxf(eA, eB)));  // > 0 iff the band stays clear of the ray
             const float gap0 = fmaxf(-Qz - Thi, Tlo + Qz);     // the same for the isolated value z = 0
             const float g = GCFR_M(10, gap, fminf(gap, gap0)) - Kerr;
+#ifdef GCFR_AUDIT
+            for (int j = 0; j < DEPTH; ++j) {  // g > 0: every unmasked sample of the group has S >= 0.998 g^2 (what a skip relies on)
+                bool m;
+                const float S = audit_S(clampk(k0 + j), m);
+                const bool claim = (g > 0.0f) && !m;
+                audit_count(kCntAuditBoundChecks, claim);
+                audit_count(kCntAuditBoundViol, claim && (S < g * g * GCFR_M(6, 1.002f, 0.998f)));
+                // how much of the budget the evaluation used: (the bound before Kerr - the true sqrt(S)) / Kerr, in 1/1000
+                const float use = claim ? ((g + Kerr) - __builtin_sqrtf(S)) / Kerr : 0.0f;
+                const int use_m = (int)fminf(fmaxf(use * 1000.0f, 0.0f), 1.0e6f);
+                cnt[kCntAuditMaxUse] = max(cnt[kCntAuditMaxUse], (unsigned)(-wave_min_i32(-use_m)));
+            }
+#else
+            (void)k0;
+#endif
             return (g > 0.0f) && (g * g * GCFR_M(6, 1.002f, 0.998f) > bestS);
     };
 // census: loop: sample body (bilinear, distance, minimum)
@@ -1029,7 +1132,7 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         if (LAZY) {
             run_body = __builtin_amdgcn_ballot_w64(!none && !cw_in) != 0ull;
         } else if (run_body && use_zb) {
-            const bool cannot_win = bound_cw(cz, ta64, tb64);
+            const bool cannot_win = bound_cw(cz, ta64, tb64, k0);
             run_body = __builtin_amdgcn_ballot_w64(!none && !cannot_win) != 0ull;
             if (TRAIL)  // (see the trailing loop below) nothing of this group mattered to any lane, masked or not
                 all_lazy = !run_body && __builtin_amdgcn_ballot_w64(!((cannot_win && GCFR_M(18, true, (bestS < safeS))) || (lane_last < k0))) == 0ull;
@@ -1128,8 +1231,11 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             pos_tq(DEPTH - 1, px, py);
             cell[DEPTH - 1] = mask_offset(px, py, cj[DEPTH - 1], rj[DEPTH - 1]);
             const f32x4 cz = lds_zb_fetch(cj[0], rj[0], cj[DEPTH - 1], rj[DEPTH - 1]);
-            cw = bound_cw(cz, ta64, tb64);
+            cw = bound_cw(cz, ta64, tb64, k0);
             if (__builtin_amdgcn_ballot_w64(!(cw && (bestS < safeS))) == 0ull) {
+#ifdef GCFR_AUDIT
+                audit_safe(cw);
+#endif
                 load_tq(k0 + DEPTH);
                 return finish_check(k0, tq[0], check_finished);
             }
@@ -1289,12 +1395,16 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
             const int hz_off = (GCFR_HORIZON != 0) && check && (k0 + DEPTH < k_end) ? launder(a)->hz_off : -1;
             const bool check_hz = hz_off >= 0;
             const float tn = (float)tc0;  // the next group's first table value
-            const bool cw = bound_cw(zcur, ta64, tb64);
+            const bool cw = bound_cw(zcur, ta64, tb64, k0);
             const bool gone = lane_last < k0 GCFR_M(27, + 1, );
             GCFR_COUNT(kCntGroupsVisited, 1);
             if (__builtin_amdgcn_ballot_w64(!((cw && GCFR_M(18, true, (bestS < safeS))) || gone)) == 0ull) {
                 any_masked |= gone;
                 GCFR_COUNT(kCntTrailSkips, 1);
+#ifdef GCFR_AUDIT
+                audit_safe(cw && !gone);                              // (the lane's any_masked is not updated: it must not matter)
+                audit_masked(k0, min(k0 + DEPTH, k_end), gone);      // (a lane that is gone: its samples from here on are masked)
+#endif
 #ifdef GCFR_COUNTERS
                 ++cnt_since_body;
 #endif
@@ -1319,6 +1429,10 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
                     if (__builtin_amdgcn_ballot_w64(!finished) == 0ull) {
                         any_masked |= past;
                         GCFR_COUNT(kCntEarlyExit, 1);
+#ifdef GCFR_AUDIT
+                        audit_finish(k0 + DEPTH, GCFR_M(11, true, (c1 > 0.0f)) && (gd > 0.0f) && (gd * gd * GCFR_M(8, GCFR_MUT_SLACK_VALUE, 0.998f) > bestS) && (bestS < safeS),
+                                     gd, GCFR_M(8, GCFR_MUT_SLACK_VALUE, 0.998f), past);
+#endif
                         break;
                     }
                 } else if (!finish_check(k0, tc0, check)) {
@@ -1490,8 +1604,12 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
         cnt[kCntVisitsAfterLastBody] += cnt_since_body;  // (tiles without any body: all their visits)
 #ifndef GCFR_TRACE_ONLY   // (ten same-address atomics per tile cost ~20 ns each: they distort the timeline)
 #pragma unroll
-        for (int i = 0; i < kCntUsed; ++i)
-            atomicAdd(a->counters + i, (unsigned long long)cnt[i]);
+        for (int i = 0; i < kCntUsed; ++i) {
+            if (i == kCntAuditMaxUse)
+                atomicMax(a->counters + i, (unsigned long long)cnt[i]);
+            else
+                atomicAdd(a->counters + i, (unsigned long long)cnt[i]);
+        }
 #endif
         // per-tile record after the GCFR_N_COUNTERS tallies: {t0, t1 (100 MHz), shader cycles, hw ids | work}
         unsigned long long *rec = a->counters + GCFR_N_COUNTERS + 4 * ((size_t)(bl * a->tiles_y + qy) * a->tiles_x + tx);

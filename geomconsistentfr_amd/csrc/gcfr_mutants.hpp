@@ -39,12 +39,15 @@
 // 27  trailing loop: "the lane has left the box" (lane_last < this group's first sample)   off by one
 // 29  bound evaluated at the group's first AND last sample (linear in t)             first sample only
 //
-// 3 and 5 are the two mutants no test kills (profiles/r05_mutants.md): K1, K2 r and the plane term budget for three different effects
-// -- the 1e-4 position offset times |BCz|, the f32 roundings of the distance's products, the offset times the surface's slope --
-// each ten times over, and they are ADDED: with one of them gone the other two and the 0.2 % slack still cover its effect wherever
-// a bound is tight enough to be decisive (K1's effect exceeds the rest only within 43 px of an overhead light's foot, where the
-// ray climbs 4000 t and no bounds tile is a thin band; the plane term's only on slopes near the plane fit's limit of 4, where the
-// depth range inflates K2 r).  Kerr as a whole (23) dies in five scene families, K2 r alone (4) far from zero.
+// 3 and 5 are the two mutants no END-TO-END test kills (profiles/r05_mutants.md): K1, K2 r and the plane term budget for three different
+// effects -- the 1e-4 position offset times |BCz|, the f32 roundings of the distance's products, the offset times the surface's slope --
+// each ten times over, and they are ADDED: with one of them gone the other two and the 0.2 % slack still cover its effect wherever a bound
+// is tight enough to DECIDE a minimum (K1's effect exceeds the rest only within 43 px of an overhead light's foot, where the ray climbs
+// 4000 t and no bounds tile is a thin band; the plane term's only on slopes near the plane fit's limit of 4, where the depth range
+// inflates K2 r).  Kerr as a whole (23) dies in five scene families, K2 r alone (4) far from zero.  The AUDIT build kills both
+// (-DGCFR_COUNTERS -DGCFR_AUDIT, gcfr_march.hpp; tools/audit.py, tests/test_gpu_audit.py): it checks the claim the margins were derived
+// for -- g > 0 => S_k >= 0.998 g^2 for every unmasked sample of the group -- at every evaluation of the bound, decisive or not, and
+// without K1 (on `pits2`) or without the plane term (on `facets`) hundreds of evaluations contradict it.
 //
 // NOT in the list, because removing them cannot change a result (round 5 built them, they survived, and the reason is a proof, not
 // a missing test):

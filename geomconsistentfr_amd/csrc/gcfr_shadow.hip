@@ -710,7 +710,9 @@ static inline int launch_status()
 
 extern "C" const char *gcfr_version(void)
 {
-#if defined(GCFR_COUNTERS)
+#if defined(GCFR_AUDIT)
+    return "gcfr-hip 0.5.0 gfx950 +counters +audit";
+#elif defined(GCFR_COUNTERS)
     return "gcfr-hip 0.5.0 gfx950 +counters";
 #else
     return "gcfr-hip 0.5.0 gfx950";

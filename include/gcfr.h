@@ -56,7 +56,7 @@ int32_t gcfr_abi_version(void);
  * With ONE exception (`pixels`, off by default) nothing here changes a result bit: the knobs select among kernels /
  * schedules that are bit-identical (tests/test_gpu_parity.py asserts it for every combination), the hooks only observe.
  */
-#define GCFR_N_COUNTERS 20
+#define GCFR_N_COUNTERS 28
 typedef struct gcfr_options {
     uint32_t struct_size;      /* sizeof(gcfr_options) of the caller's build; a mismatch is GCFR_ERR_INVALID_ARGUMENT */
     int32_t tile_w;            /* pixels per tile row: 8, 16, 32 or 64 (a wave marches a tile_w x 64/tile_w tile); 0 = auto */
