@@ -530,3 +530,39 @@ def family_pits2(seed, H=128, W=128, B=24):
 
 
 FAMILIES.update({"parallel3": family_parallel3, "facets": family_facets, "pits2": family_pits2})
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# W  a mask that touches column 0 (row 0) only, an extreme masked-OUT depth in the opposite column (row): samples whose rounded cell
+#    lies in column 0 read column W-1 as their left bilinear corner (index -1 wraps, T8:488-491), so the horizon tables' entries must
+#    hold those cells or the trailing loop's cap is too low (advisor r03; tests/test_gpu_horizon.py pins the product end to end with
+#    these scenes, tools/audit.py audits the terminations' claims on them: mutants 13 / 14).  seed % 3: left / top / corner.
+# ---------------------------------------------------------------------------------------------------------------------------
+def family_wrap_edge(seed, H=256, W=256, B=12):
+    edge = ("left", "top", "corner")[seed % 3]
+    rng = np.random.default_rng(23000 + seed)
+    _, _, r, c = grids(H, W)
+    raw = np.array([[-0.9, 0.05, 0.3], [-0.6, 0.6, 0.5], [-0.3, -0.8, 0.4], [0.05, 0.9, 0.3], [0.4, 0.8, 0.4], [-0.7, 0.7, 0.1],
+                    [-0.2, 0.3, 0.9], [0.0, 0.95, 0.2], [-0.95, 0.0, 0.2], [-0.5, 0.5, 0.7], [0.3, -0.2, 0.9], [-0.8, 0.5, 0.05]], np.float64)
+    raw = raw + 0.02 * rng.standard_normal(raw.shape)
+    raw[:, 2] = np.abs(raw[:, 2])
+    pts = (4013.0 * raw / np.linalg.norm(raw, axis=1, keepdims=True)).astype(f32)[:B]
+    base = 60.0 * np.exp(-((c / 90.0) ** 2 if edge != "top" else (r / 90.0) ** 2)) + 2.0 * np.sin(c / 9.0) * np.cos(r / 7.0)
+    depth = (base[None] + 0.3 * rng.random((B, H, W))).astype(f32)
+    mask = np.zeros((B, H, W), np.uint8)
+    for b in range(B):
+        spike = (1e6, 3e4, 5e3)[(b + seed // 3) % 3]
+        if edge in ("left", "corner"):
+            lo = 0 if edge == "corner" else 40 + 5 * b
+            mask[b, lo:lo + 120, 0:60 + 3 * b] = 1
+            depth[b, max(lo - 2, 0):lo + 122, W - 1] = spike
+        if edge in ("top", "corner"):
+            lo = 0 if edge == "corner" else 30 + 6 * b
+            mask[b, 0:50 + 2 * b, lo:lo + 130] = 1
+            depth[b, H - 1, max(lo - 2, 0):lo + 132] = spike
+        if edge == "corner":
+            depth[b, H - 1, W - 1] = 1e6
+    return dict(depth=depth, mask=mask, light_pt=pts[:, None, :], t_table=table(), pixels_mask=False)
+
+
+FAMILIES["wrap_edge"] = family_wrap_edge

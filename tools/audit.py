@@ -33,8 +33,9 @@ AUDIT_KEYS = ("audit_bound_checks", "audit_bound_violations", "audit_term_checks
 
 
 class Auditor:
-    def __init__(self):
+    def __init__(self, knobs=None):
         from geomconsistentfr_amd import _lib
+        self.knobs = dict(knobs or {})
         self._lib, self.L_ = _lib, _lib.load()
         self.version = self.L_.gcfr_version().decode()
         if "+audit" not in self.version:
@@ -55,9 +56,10 @@ class Auditor:
         am = torch.empty((B, L, H, W), dtype=torch.int32, device=dev) if want_argmin else None
         nb = int(L_.gcfr_shadow_workspace_bytes(B, H, W))
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-        n_tiles = B * L * ((W + 15) // 16) * ((H + 3) // 4)
+        tw = self.knobs.get("tile_w", 0) or 16
+        n_tiles = B * L * ((W + tw - 1) // tw) * ((H + 64 // tw - 1) // (64 // tw))
         counters = torch.zeros(_lib.N_COUNTERS + 4 * n_tiles, dtype=torch.int64, device=dev)
-        opt = _lib.options(ksplit=0, pixels=pixels, counters=counters.data_ptr())
+        opt = _lib.options(**dict(dict(ksplit=0), **self.knobs), pixels=pixels, counters=counters.data_ptr())
         _lib.check(L_.gcfr_shadow_fwd(d_depth.data_ptr(), d_mask.data_ptr(), d_mask.shape[0], d_pt.data_ptr(), B, L, H, W, d_tt.numel(),
                                       d_tt.data_ptr(), 0.0, None, md.data_ptr(), am.data_ptr() if am is not None else None, ws.data_ptr(), nb,
                                       None, ctypes.byref(opt)), "gcfr_shadow_fwd")
@@ -126,10 +128,13 @@ def main():
     ap.add_argument("--more", type=str, default="facets=60,pits2=24",
                     help="families that get more seeds: the ones on which the single terms of Kerr are needed for a claim to hold "
                          "(mutant 5, the plane term: steep planar facets under level light; mutant 3, K1: plateaus with pits under an overhead light)")
+    ap.add_argument("--tune", type=str, default="", help="gcfr_options knobs, e.g. tile_w=8,group=2 or lds_stage=1 (needs an audit build "
+                                                          "of every march unit: without -DGCFR_FAST_BUILD)")
     ap.add_argument("--out", type=str, default="")
     a = ap.parse_args()
     import margin_scenes as MS
-    au = Auditor()
+    knobs = {k: int(v) for k, v in (kv.split("=") for kv in a.tune.split(",") if kv)}
+    au = Auditor(knobs)
     t0 = time.time()
     if a.random:
         au.random_cases(a.random, a.seed)
@@ -137,7 +142,7 @@ def main():
     more = {k: int(v) for k, v in (kv.split("=") for kv in a.more.split(",") if kv)}
     au.families(names, a.family_seeds, {k: v for k, v in more.items() if k in names})
     r = au.report()
-    r.update(random_cases=(a.random // 8) * 8, seed=a.seed, families=names, family_seeds=a.family_seeds, more_seeds=more,
+    r.update(knobs=knobs, random_cases=(a.random // 8) * 8, seed=a.seed, families=names, family_seeds=a.family_seeds, more_seeds=more,
              seconds=round(time.time() - t0, 1))
     print(json.dumps(r))
     if a.out:
