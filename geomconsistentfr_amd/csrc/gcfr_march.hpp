@@ -524,7 +524,9 @@ enum { kModeInline = 0, kModeFull = 1, kModeRough = 2 };
 #define GCFR_ROUGH 1
 #endif
 #ifndef GCFR_ROUGH_CHUNK
-#define GCFR_ROUGH_CHUNK 2      // samples in flight per iteration of the rough loop: six-wave inference march
+#define GCFR_ROUGH_CHUNK 3      // samples in flight per iteration of the rough loop: six-wave inference march (round 4: 2 -- 3 spilled
+                                // then; since round 5's trims 3 and 4 fit the 80 registers: noise-400 faces +2.2 % / +0.7 %, the bench
+                                // faces, the FFHQ fixtures and all-ones masks unchanged, profiles/r05_rough_chunk_ab.txt)
 #endif
 #ifndef GCFR_ROUGH_CHUNK_ARGMIN
 #define GCFR_ROUGH_CHUNK_ARGMIN 3   // ... five-wave training march
@@ -826,6 +828,11 @@ __device__ GCFR_TILE_INLINE bool march_tile(ArgPtr a, const int bl, const int qy
     // the trailing loop in place, when the allocator spilled an f64 ray constant into the bodies instead.  (Laundered: or the
     // loop-invariant conversion is hoisted straight back into a register.)
     auto dir_f32 = [&](float &dxl, float &dyl) {
+        if (WANT_ARGMIN) {  // (the five-wave training kernels have the two registers: round 5)
+            dxl = finite_ray ? dxf : 0.0f;
+            dyl = finite_ray ? dyf : 0.0f;
+            return;
+        }
         double dx_l = dx64, dy_l = dy64;
         asm volatile("" : "+v"(dx_l), "+v"(dy_l));
         dxl = (float)dx_l;
