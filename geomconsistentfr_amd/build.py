@@ -143,6 +143,7 @@ def compile_and_link(out: str, defines=(), verbose: bool = False, jobs=None) -> 
     """Every translation unit to an object (in parallel), then one link.  -DGCFR_FAST_BUILD: the default march shape only."""
     hipcc = _hipcc()
     defines = list(defines)
+    hashes = source_hash() + "\n" + full_bytes_hash() + "\n" + " ".join(defines) + "\n"   # (of the sources as they are NOW)
     cflags = [f for f in FLAGS if f != "-shared"] + defines
     units = MARCH_UNITS[:1] if "-DGCFR_FAST_BUILD" in defines else MARCH_UNITS
     os.makedirs(os.path.dirname(out), exist_ok=True)
@@ -165,7 +166,20 @@ def compile_and_link(out: str, defines=(), verbose: bool = False, jobs=None) -> 
         with concurrent.futures.ThreadPoolExecutor(max_workers=jobs or min(len(jobs_list), os.cpu_count() or 4)) as ex:
             objs = list(ex.map(run, jobs_list))
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+    # beside every build: what it was built from (line 1 the code-only hash, 2 the raw-bytes hash, 3 the -D flags); tests that run a
+    # variant (tests/test_gpu_audit.py) refuse one that no longer matches the sources
+    with open(os.path.splitext(out)[0] + ".srchash", "w") as f:
+        f.write(hashes)
     return out
+
+
+def variant_is_current(path: str) -> bool:
+    """a variant library built by compile_and_link() from the sources as they are now (its .srchash beside it says so)"""
+    try:
+        with open(os.path.splitext(path)[0] + ".srchash") as f:
+            return f.read().split("\n")[0] == source_hash()
+    except OSError:
+        return False
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -79,7 +79,9 @@ typedef struct gcfr_options {
                                   counts (executed groups, bound tests, ...; tools/count_work.py) to the first
                                   GCFR_N_COUNTERS and writes a 4-word timeline record per tile behind them
                                   (tools/trace_timeline.py); only a library built with -DGCFR_COUNTERS touches it
-                                  (gcfr_version() then ends in "+counters"), else ignored */
+                                  (gcfr_version() then ends in "+counters"), else ignored.  With -DGCFR_AUDIT as well ("+audit")
+                                  the last eight tallies count the claims the march makes about samples it does not evaluate and
+                                  the ones a plain evaluation of those samples contradicts (tools/audit.py) */
     int32_t pixels;            /* WHICH PIXELS are marched.  0 (default; also -1): every pixel, as the reference does
                                   (T8:371-515 computes minimum_distance for all H x W pixels).
                                   1 ("mask"; DEVIATES from the reference's returned tensors, opt-in): pixels whose OWN mask cell

@@ -23,6 +23,8 @@ pytestmark = pytest.mark.gpu
 def _audit(*args):
     if not os.path.exists(AUDIT_LIB):
         pytest.skip("no audit build: tools/build_variant.sh audit -DGCFR_FAST_BUILD -DGCFR_COUNTERS -DGCFR_AUDIT (or __graft_entry__.build())")
+    from geomconsistentfr_amd import build as hip_build
+    assert hip_build.variant_is_current(AUDIT_LIB), "lib/audit.so was built from other sources than csrc/ holds now: rebuild it (see above)"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit.py")] + list(args), env=dict(os.environ, GCFR_HIP_LIB=AUDIT_LIB),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-400:], r.stderr[-1500:])

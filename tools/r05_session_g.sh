@@ -3,10 +3,11 @@
 # columns of the mutant table, profiles (kernel trace + PMC passes), work counts, soaks, the audit (product + every march unit), the
 # interleaved A/B against round 4's fixed-cost form, bench lines.  The driver's command runs afterwards (session H), when
 # profiles/pmc_summary.json has been rebuilt from this session's counters.
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r05g; mkdir -p $O gpurun_out/mutants; rm -f gpurun_out/mutants/results.json gpurun_out/mutants/audit.json
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r05g; mkdir -p $O gpurun_out/mutants; [ -z "$SKIP_MUTANTS" ] && rm -f gpurun_out/mutants/results.json gpurun_out/mutants/audit.json
+# (SKIP_MUTANTS=1: everything but the mutant table, which needs its 54 libraries built -- tools/mutants.py build, build-audit)
 timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_full.log 2>&1; grep -n "passed\|failed" $O/pytest_full.log | tail -2
-timeout 1500 python tools/mutants.py run > $O/mutants_run.log 2>&1; grep -c killed $O/mutants_run.log; grep SURVIVED $O/mutants_run.log | cut -c1-80
-timeout 900 python tools/mutants.py run-audit > $O/mutants_audit.log 2>&1; grep -c '"violations": 0,' $O/mutants_audit.log
+[ -z "$SKIP_MUTANTS" ] && timeout 1500 python tools/mutants.py run > $O/mutants_run.log 2>&1; grep -c killed $O/mutants_run.log; grep SURVIVED $O/mutants_run.log | cut -c1-80
+[ -z "$SKIP_MUTANTS" ] && timeout 900 python tools/mutants.py run-audit > $O/mutants_audit.log 2>&1; grep -c '"violations": 0,' $O/mutants_audit.log
 tools/prof.sh r05_fwd fwd > $O/prof_fwd.log 2>&1
 tools/prof.sh r05_fwd128 fwd --faces 128 > $O/prof_fwd128.log 2>&1
 tools/prof.sh r05_bwd bwd > $O/prof_bwd.log 2>&1
