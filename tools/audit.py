@@ -96,6 +96,20 @@ class Auditor:
             for want in (True, False):
                 self.march(depth, mask, pt[:, None, :].astype(np.float32), tt, want, tag="random")
 
+    def config5(self, n_faces, seed):
+        """random faces at BASELINE configs[4]'s shape: 512 x 512, 320 samples, 18 lights per face in one launch"""
+        import soak_parity as SP
+        import c_oracle
+        rng = np.random.default_rng(seed)
+        tt = c_oracle.sample_table(0.025, 0.8 / 320, 320)
+        for _ in range(n_faces):
+            depth, mask, _l = SP.random_case(rng, 512, 512)
+            lights = rng.standard_normal((18, 3)).astype(np.float32)
+            lights[:, 2] = np.abs(lights[:, 2]) * rng.choice([1.0, 0.1])
+            _, pt = c_oracle.light_prep(lights, clamp_z_min=0.0)
+            for want in (True, False):
+                self.march(depth[None], mask[None], pt[None].astype(np.float32), tt, want, tag="config5")
+
     def families(self, names, n_seeds, more=None):
         import margin_scenes as MS
         for name in names:
@@ -128,6 +142,7 @@ def main():
     ap.add_argument("--more", type=str, default="facets=60,pits2=24",
                     help="families that get more seeds: the ones on which the single terms of Kerr are needed for a claim to hold "
                          "(mutant 5, the plane term: steep planar facets under level light; mutant 3, K1: plateaus with pits under an overhead light)")
+    ap.add_argument("--config5", type=int, default=0, help="N random faces at configs[4]'s shape (512 x 512 x 320, 18 lights)")
     ap.add_argument("--tune", type=str, default="", help="gcfr_options knobs, e.g. tile_w=8,group=2 or lds_stage=1 (needs an audit build "
                                                           "of every march unit: without -DGCFR_FAST_BUILD)")
     ap.add_argument("--out", type=str, default="")
@@ -138,11 +153,13 @@ def main():
     t0 = time.time()
     if a.random:
         au.random_cases(a.random, a.seed)
+    if a.config5:
+        au.config5(a.config5, a.seed)
     names = [] if a.families == "none" else (sorted(MS.FAMILIES) if a.families == "all" else a.families.split(","))
     more = {k: int(v) for k, v in (kv.split("=") for kv in a.more.split(",") if kv)}
     au.families(names, a.family_seeds, {k: v for k, v in more.items() if k in names})
     r = au.report()
-    r.update(knobs=knobs, random_cases=(a.random // 8) * 8, seed=a.seed, families=names, family_seeds=a.family_seeds, more_seeds=more,
+    r.update(knobs=knobs, random_cases=(a.random // 8) * 8, config5_faces=a.config5, seed=a.seed, families=names, family_seeds=a.family_seeds, more_seeds=more,
              seconds=round(time.time() - t0, 1))
     print(json.dumps(r))
     if a.out:
