@@ -93,3 +93,33 @@ def test_census_markers_cover_the_tile_function_in_order():
     assert pos == sorted(pos), list(zip(order, pos))
     assert census.classify("v_fma_f64")[1:] == ("f64", 4) and census.classify("v_rcp_f32_e32")[1:] == ("trans_f32", 8)
     assert census.classify("buffer_load_dwordx4")[0] == "vmem" and census.classify("s_cbranch_scc1")[0] == "branch"
+
+
+def test_every_scene_family_is_well_formed_and_deterministic():
+    """what tools/audit.py and tools/mutant_hunt.py iterate over: depth (B,H,W) f32, mask (B,H,W) u8, light points (B,L,3) f32, an
+    increasing f64 sample table -- and the same arrays for the same seed"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import margin_scenes as MS
+    assert {"facets", "pits2", "wrap_edge", "integral", "million3", "level2"} <= set(MS.FAMILIES)
+    for name, fam in sorted(MS.FAMILIES.items()):
+        a, b = fam(1), fam(1)
+        B, H, W = a["depth"].shape
+        assert a["depth"].dtype == np.float32 and a["mask"].dtype == np.uint8 and a["mask"].shape == (B, H, W), name
+        assert a["light_pt"].dtype == np.float32 and a["light_pt"].shape[0] == B and a["light_pt"].shape[2] == 3, name
+        tt = a["t_table"]
+        assert tt.dtype == np.float64 and tt.ndim == 1 and np.all(np.diff(tt) > 0), name
+        for k in ("depth", "mask", "light_pt", "t_table"):
+            assert np.array_equal(a[k], b[k]), (name, k)
+
+
+def test_a_variant_library_is_current_only_with_the_hash_of_todays_sources(tmp_path):
+    """geomconsistentfr_amd/build.py: every compile_and_link() leaves <name>.srchash beside the library; tests that run a variant
+    (tests/test_gpu_audit.py) refuse one built from other sources"""
+    from geomconsistentfr_amd import build as hip_build
+    lib = tmp_path / "variant.so"
+    lib.write_bytes(b"")
+    assert not hip_build.variant_is_current(str(lib))                     # no hash beside it
+    (tmp_path / "variant.srchash").write_text("0" * 64 + "\n" + "0" * 64 + "\n-DX\n")
+    assert not hip_build.variant_is_current(str(lib))                     # another source
+    (tmp_path / "variant.srchash").write_text(hip_build.source_hash() + "\n" + hip_build.full_bytes_hash() + "\n-DX\n")
+    assert hip_build.variant_is_current(str(lib))
