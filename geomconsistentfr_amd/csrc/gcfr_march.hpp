@@ -251,13 +251,27 @@ __device__ inline float lane_value(float v, int lane)
 // Per-image statistics the march needs before it starts: the bounding box of the mask's non-zero cells and the
 // depth range.  One 256-thread block per chunk of kStatChunk pixels writes ONE partial record (four + two minima:
 // {r_min, c_min, -r_max, -c_max}, {z_min, -z_max} as sortable ints; kBBoxInit / INT_MAX where the chunk has
-// nothing to report), so an image has only P/16384 partials (4 at 256x256) and every march wave reduces them
+// nothing to report), so an image has only P/16384 partials (4 at 256x256, 8 at 512x512) and every march wave reduces them
 // itself with one load and six DPP minima -- no atomics to initialise, no workgroup barrier in the march (round 1
 // kept 256 partials per image and reduced them through LDS in every march workgroup's prologue).
 constexpr int kQueueSlot = 64;  // (workspace layout: the table record keeps a 256-B line to itself)
 enum { kTfOk = 0, kTfStride = 1, kTfTabs = 2, kTfTfirst = 3, kTfInvDt = 4 };  // tflag[]: per-launch facts about the sample table (prepass)
 constexpr int kStatChunk = 16384;
-__host__ __device__ inline int n_stat_chunks(int H, int W) { return (H * W + kStatChunk - 1) / kStatChunk; }
+// Pixels per statistics chunk: kStatChunk -- doubled for images of 9 ... 16 plain chunks (up to 512 x 512, BASELINE
+// configs[4]'s size), so that those too have at most 8 records and every march wave folds them on the scalar unit
+// (reduce_image_stats; sixteen records there cost the march its registers: the scalar loads spill into VGPRs).
+__host__ __device__ inline int stat_chunk_shift(int H, int W)
+{
+    const int raw = (H * W + kStatChunk - 1) >> 14;
+    return (raw > 8 && raw <= 16) ? 15 : 14;
+}
+__host__ __device__ inline int stat_chunk_px(int H, int W) { return 1 << stat_chunk_shift(H, W); }
+__host__ __device__ inline int n_stat_chunks(int H, int W)
+{
+    const int sh = stat_chunk_shift(H, W);
+    return (H * W + (1 << sh) - 1) >> sh;
+}
+static_assert(kStatChunk == 1 << 14, "stat_chunk_shift() spells kStatChunk as a shift");
 
 
 // Operands of the per-pixel epilogue (distance finish, optional fused shading).  They live in the kernel-argument

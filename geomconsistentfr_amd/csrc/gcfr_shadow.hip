@@ -298,7 +298,8 @@ __device__ inline void build_stats_block(int chunk, int b, const float *__restri
                                          int *__restrict__ diag_out, bool want_z, bool vec_ok)
 {
     const int P = H * W;
-    const int p0 = chunk * kStatChunk;
+    const int chunk_px = stat_chunk_px(H, W);  // kStatChunk or twice that
+    const int p0 = chunk * chunk_px;
     const bool want_box = b < mask_batch;
     int rmin = kBBoxInit, cmin = kBBoxInit, nrmax = kBBoxInit, ncmax = kBBoxInit;
     int all_set = 1;  // every mask cell this lane saw is non-zero
@@ -307,9 +308,10 @@ __device__ inline void build_stats_block(int chunk, int b, const float *__restri
     const float *z = depth + (size_t)b * P;
     const uint8_t *m = mask + (size_t)b * P;  // only dereferenced when want_box
     if (vec_ok) {  // W % 16 == 0 and 16-byte aligned planes: 16 pixels of one row per lane and step
+        for (int part0 = 0; part0 < chunk_px; part0 += kStatChunk)
 #pragma unroll
         for (int it = 0; it < kStatChunk / 4096; ++it) {
-            const int i = p0 + it * 4096 + (int)threadIdx.x * 16;
+            const int i = p0 + part0 + it * 4096 + (int)threadIdx.x * 16;
             if (i < P) {
                 if (want_z) {
                     const float4 *zp = (const float4 *)(z + i);
@@ -331,7 +333,7 @@ __device__ inline void build_stats_block(int chunk, int b, const float *__restri
             }
         }
     } else {  // any width / alignment: one pixel per lane and step
-        for (int e = threadIdx.x; e < kStatChunk; e += 256) {
+        for (int e = threadIdx.x; e < chunk_px; e += 256) {
             const int i = p0 + e;
             if (i >= P)
                 break;

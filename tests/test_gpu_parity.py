@@ -592,3 +592,52 @@ def test_rough_depth_marches_bit_identically_through_the_rough_loop(knobs):
         np.testing.assert_array_equal(md.cpu().numpy(), md_o)
         if want_argmin:
             np.testing.assert_array_equal(am.cpu().numpy()[lit], am_o[lit])
+
+
+@pytest.mark.parametrize("Hs,Ws", [(362, 362), (362, 364), (368, 400), (500, 500), (512, 512), (514, 512)])
+def test_statistics_chunks_around_the_doubled_size_class_are_bit_identical(Hs, Ws):
+    """The prepass' per-image statistics (mask box / octagon, all-ones flag, depth range) are partial records per chunk of
+    16,384 pixels -- 32,768 for images of 9 ... 16 plain chunks, so that a 512 x 512 image has eight records the march folds on
+    the scalar unit (csrc/gcfr_march.hpp stat_chunk_px).  Sizes on both sides of both class borders, widths with and without
+    the 16-pixel vector path, and masks / depths whose deciding cells lie in the SECOND half of a doubled chunk or in the last,
+    partial one: a record that misses them gives a wrong box (samples skipped), a wrong all-ones flag or a depth range that
+    is too narrow (bounds that are none) -- the direct kernel uses none of them."""
+    from geomconsistentfr_amd import RenderParams, shadow_min_distance, light_prep
+    rng = np.random.default_rng(Hs * 7 + Ws)
+    P = Hs * Ws
+    r, c = np.mgrid[0:Hs, 0:Ws]
+    base = (0.25 * Hs * np.exp(-(((c - 0.5 * Ws) / (0.3 * Ws)) ** 2 + ((r - 0.5 * Hs) / (0.3 * Hs)) ** 2))).astype(np.float32)
+    masks, depths = [], []
+    def flat_cells(lo, hi):
+        m = np.zeros(P, np.uint8)
+        m[lo:hi] = 1
+        return m.reshape(Hs, Ws)
+    masks.append(flat_cells(16384 + 40, 32768 - 40))                 # only cells of the second 16,384 pixels
+    masks.append(flat_cells(P - 3 * Ws - 7, P))                      # only cells of the last (partial) chunk
+    m = np.ones(P, np.uint8); m[16384 + 5] = 0; masks.append(m.reshape(Hs, Ws))      # all ones but one cell, second half
+    m = np.ones(P, np.uint8); m[P - 1] = 0; masks.append(m.reshape(Hs, Ws))          # ... but the very last cell
+    masks.append(np.ones((Hs, Ws), np.uint8))                        # all ones
+    masks.append((((c - 0.55 * Ws) / (0.3 * Ws)) ** 2 + ((r - 0.6 * Hs) / (0.35 * Hs)) ** 2 < 1).astype(np.uint8))
+    B = len(masks)
+    for b in range(B):
+        d = (base + rng.random((Hs, Ws)).astype(np.float32)).reshape(P)
+        if b % 2 == 0:
+            d[16384 + 9 * (b + 1)] = 4000.0 + b                      # the image's depth maximum / minimum live in the second half
+            d[32768 - 11 * (b + 1)] = -3000.0 - b
+        else:
+            d[P - 2 - b] = 2500.0                                    # ... or in the last chunk
+        depths.append(d.reshape(Hs, Ws))
+    mask, depth = np.stack(masks), np.stack(depths)
+    lights = np.array([[0.3, 0.5, 0.8], [-0.9, 0.1, 0.2], [0.7, -0.7, 0.05]], np.float32)
+    lights = np.stack([np.roll(lights, b, axis=0) for b in range(B)])
+    prm = RenderParams(n_samples=40, t0=0.025, dt=0.02)
+    _, pt = light_prep(to_dev(lights), prm)
+    ref_md, ref_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=False)
+    for want in (True, False):
+        md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, want_argmin=want, use_workspace=True)
+        assert torch.equal(md, ref_md), (want, (md != ref_md).nonzero()[:5].tolist())
+        if want:
+            assert torch.equal(am, ref_am)
+    import c_oracle
+    md_o, _ = c_oracle.shadow_min_distance(depth[:2], mask[:2], pt[:2].cpu().numpy(), c_oracle.sample_table(0.025, 0.02, 40))
+    np.testing.assert_array_equal(ref_md[:2].cpu().numpy(), md_o)
