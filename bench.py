@@ -469,7 +469,7 @@ class RenderRig:
 
     def __init__(self, rk, B, size=256, lights=1, samples=160, mask="ellipse", depth_noise=0.0, data="synthetic",
                  streams=4, from_depth=False, want_argmin=False, knobs=None, graph=True, mode="plan", pixels="all",
-                 normals_stage="fused"):
+                 normals_stage="auto"):
         from geomconsistentfr_amd import RenderParams, _lib
         from geomconsistentfr_amd import block as R
         self.rk, self.R, self._lib = rk, R, _lib
@@ -685,7 +685,7 @@ def run_render(a, rk):
     from_depth = (not a.normals_in) and mode in ("plan", "eager")      # (the direct / unfused A/B forms take normals as input)
     headline = (a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse" and a.depth_noise == 0.0
                 and a.data == "synthetic" and B == FACES_PER_GPU and not knobs and mode == "plan" and from_depth
-                and not a.argmin and a.pixels == "all" and a.normals_stage == "fused")
+                and not a.argmin and a.pixels == "all" and a.normals_stage in ("auto", "fused"))
     rig = RenderRig(rk, B, a.size, a.lights, a.samples, a.mask, a.depth_noise, a.data, a.streams, from_depth,
                     a.argmin, knobs, graph=not a.no_graph, mode=mode, pixels=a.pixels, normals_stage=a.normals_stage)
     n_streams, world, rank = rig.n_streams, rk.world, rk.rank
@@ -796,8 +796,10 @@ def run_render(a, rk):
             aux["config5"] = {"ray_steps_per_sec": r5.ray_steps_per_step * steps5 / sec, "ms_per_step": 1e3 * sec / steps5,
                               "faces_lights_per_sec": 18 * steps5 / sec, "march_kernel_ms": r5.kernel_launch_ms(ev, 30)[0],
                               "steps": steps5, "regions": reg["n"], "batches_in_flight": r5.n_streams,
+                              "normals_stage": (r5.plans[0].normals_stage if r5.plans else None),
                               "workload": "BASELINE configs[4], per-GPU shape: 1 face x 18 lights x 512x512 x 320 march steps, "
-                                          "normals from depth, forward-only shadow+shade"}
+                                          "normals from depth (18 lights per face: the stencil once, in its own launch -- "
+                                          "block.normals_stage_for), forward-only shadow+shade"}
             del r5
         except Exception as e:
             aux["config5"] = {"error": repr(e)}
@@ -1182,9 +1184,10 @@ def main():
     ap.add_argument("--normals-in", action="store_true",
                     help="SURVEY 8d's accounting form instead: normals handed in as a 12 B/pixel input (gcfr_render_fwd; rounds "
                          "1-3's headline step -- the default line carries it as normals_in_*)")
-    ap.add_argument("--normals-stage", choices=["fused", "kernel"], default="fused",
-                    help="A/B: 'kernel' = the normals stage as its own launch (gcfr_normals_fwd) in front of gcfr_render_fwd instead of "
-                         "fused into the march epilogue (three launches per step, the same bits)")
+    ap.add_argument("--normals-stage", choices=["auto", "fused", "kernel"], default="auto",
+                    help="'kernel' = the normals stage as its own launch (gcfr_normals_fwd) in front of gcfr_render_fwd instead of "
+                         "fused into the march epilogue (three launches per step, the same bits); 'auto' = the product's rule: by "
+                         "the number of lights per face (block.normals_stage_for: fused below 8)")
     ap.add_argument("--verbose-json", action="store_true", help="print the line with every note / sample description (default: compact)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the configs[2] training-step leg of the headline line")
     ap.add_argument("--pixels", choices=["all", "mask"], default="all",

@@ -166,6 +166,23 @@ def shade(normals, depth, albedo, light_pt, ambient, min_dist, params: RenderPar
     return dict(shadow_mask_weights=w, full_shading=full, final_shading=fin, rendered_images=ren)
 
 
+# Lights per face from which the normals stage runs as its own launch (gcfr_normals_fwd, then gcfr_render_fwd reads its
+# output) instead of inside the march's epilogue (gcfr_render_from_depth_fwd): the stencil does not depend on the light, the
+# fused epilogue evaluates it once per (pixel, light).  Measured: one light per face -- fused wins (one launch fewer, no
+# normals re-read: profiles/r04_normals_stage_ab.txt); 18 lights per 512 x 512 face (BASELINE configs[4]) -- the own launch
+# wins by 2.1 % (profiles/r05_config5_normals_stage_ab.txt).  Bit-identical either way (tests/test_gpu_normals.py).
+NORMALS_KERNEL_MIN_LIGHTS = 8
+
+
+def normals_stage_for(n_lights: int, normals_stage: str = "auto") -> str:
+    """'fused' | 'kernel' for a render of `n_lights` lights per face ('auto': by NORMALS_KERNEL_MIN_LIGHTS)"""
+    if normals_stage == "auto":
+        return "kernel" if n_lights >= NORMALS_KERNEL_MIN_LIGHTS else "fused"
+    if normals_stage not in ("fused", "kernel"):
+        raise _lib.GcfrError("normals_stage must be 'auto', 'fused' or 'kernel'")
+    return normals_stage
+
+
 _SIDE_STREAMS = {}
 
 
@@ -304,6 +321,21 @@ def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParam
                 float(params.directional_intensity), unit.data_ptr(), pt.data_ptr(), md.data_ptr(), _opt_ptr(am),
                 w.data_ptr(), full.data_ptr(), fin.data_ptr(), ren.data_ptr(), ws.data_ptr(), ws_bytes,
                 _stream_ptr(dev), _lib.opt_ref(options)), "gcfr_render_fwd")
+        elif normals_stage_for(L) == "kernel":
+            # many lights per face: the light-independent stencil once, in its own launch, instead of once per light in the
+            # march's epilogue (the same bits; NORMALS_KERNEL_MIN_LIGHTS)
+            fx, fy, cx, cy, z_off = [float(v) for v in camera]
+            nout = torch.empty((B, 3, H, W), **f32)
+            _lib.check(L_.gcfr_normals_fwd(depth.data_ptr(), B, H, W, fx, fy, cx, cy, z_off, 1, nout.data_ptr(), _stream_ptr(dev)),
+                       "gcfr_normals_fwd")
+            _lib.check(L_.gcfr_render_fwd(
+                light.data_ptr(), int(clamp), float(params.clamp_light_z_min or 0.0), float(params.light_distance),
+                depth.data_ptr(), mask_u8.data_ptr(), mask_u8.shape[0], nout.data_ptr(), albedo.data_ptr(),
+                ambient.data_ptr(), B, L, H, W, params.n_samples, tt.data_ptr(), float(params.inside_bonus), box,
+                float(params.directional_intensity), unit.data_ptr(), pt.data_ptr(), md.data_ptr(), _opt_ptr(am),
+                w.data_ptr(), full.data_ptr(), fin.data_ptr(), ren.data_ptr(), ws.data_ptr(), ws_bytes,
+                _stream_ptr(dev), _lib.opt_ref(options)), "gcfr_render_fwd")
+            out["surface_normals"] = nout
         else:
             fx, fy, cx, cy, z_off = [float(v) for v in camera]
             nout = torch.empty((B, 3, H, W), **f32)
@@ -439,7 +471,7 @@ class RenderFwdPlan:
     Inputs must already be device tensors of the planned shapes and dtypes (f32, mask u8)."""
 
     def __init__(self, B, L, H, W, params: RenderParams = RenderParams(), device="cuda", want_argmin=False,
-                 mask_batch=None, camera=None, options=None, normals_stage="fused"):
+                 mask_batch=None, camera=None, options=None, normals_stage="auto"):
         self.L_ = _lib.load()
         want_argmin, options = _pixels_options(params, want_argmin, options)
         self.options = options          # _lib.Options or None; kept alive here, read by the library at every call
@@ -450,10 +482,9 @@ class RenderFwdPlan:
             dev = torch.device("cuda", torch.cuda.current_device())
         self.dev, self.params, self.shape, self.camera = dev, params, (B, L, H, W), camera
         # "fused": the march epilogue evaluates the normals stencil (gcfr_render_from_depth_fwd, two launches);
-        # "kernel": gcfr_normals_fwd first, then gcfr_render_fwd reads its output (three launches; the same bits -- A/B knob)
-        if normals_stage not in ("fused", "kernel"):
-            raise _lib.GcfrError("normals_stage must be 'fused' or 'kernel'")
-        self.normals_stage = normals_stage
+        # "kernel": gcfr_normals_fwd first, then gcfr_render_fwd reads its output (three launches; the same bits);
+        # "auto": by the number of lights per face (normals_stage_for)
+        self.normals_stage = normals_stage_for(L, normals_stage)
         f32 = dict(dtype=torch.float32, device=dev)
         self.tt = sample_table(params, dev)
         o = dict(unit_light_direction=torch.empty((B, L, 3), **f32), light_pt=torch.empty((B, L, 3), **f32),

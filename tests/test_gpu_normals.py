@@ -85,6 +85,43 @@ def test_fused_normals_forward_is_bit_identical_to_the_three_stage_path():
     assert torch.equal(r["surface_normals"], n)
 
 
+def test_many_lights_per_face_run_the_normals_stage_as_its_own_launch_with_the_same_bits(monkeypatch):
+    """block.normals_stage_for: from NORMALS_KERNEL_MIN_LIGHTS lights per face on, render_fwd(camera=...) and RenderFwdPlan run
+    gcfr_normals_fwd once and hand its output to gcfr_render_fwd, instead of evaluating the light-independent stencil in every
+    light's epilogue (config 5: 18 lights per face).  Every output equals the fused form's bit for bit; a hipGraph of the plan
+    and the two-phase form (prepass hoisted) as well."""
+    from geomconsistentfr_amd import RenderParams
+    from geomconsistentfr_amd import block as R
+    rng = np.random.default_rng(12)
+    B, L, H, W = 2, 9, 96, 128
+    assert L >= R.NORMALS_KERNEL_MIN_LIGHTS and R.normals_stage_for(L) == "kernel" and R.normals_stage_for(1) == "fused"
+    dev = torch.device(DEV)
+    depth = torch.from_numpy((30 * rng.random((B, H, W))).astype(np.float32)).to(dev)
+    mask = torch.from_numpy((rng.random((B, H, W)) > 0.3).astype(np.uint8)).to(dev)
+    albedo = torch.from_numpy(rng.random((B, 3, H, W), dtype=np.float32)).to(dev)
+    light = torch.from_numpy(rng.standard_normal((B, L, 3)).astype(np.float32)).to(dev)
+    amb = torch.from_numpy(rng.random((B, L), dtype=np.float32)).to(dev)
+    cam = (1570.0, 1570.0, W / 2.0, H / 2.0, 1610.0)
+    prm = RenderParams(n_samples=48, dt=0.016)
+    keys = ("minimum_distance", "argmin", "shadow_mask_weights", "full_shading", "final_shading", "rendered_images", "surface_normals")
+    own = R.render_fwd(depth, mask, light, amb, None, albedo, prm, want_argmin=True, camera=cam)
+    pre = R.render_prepass(depth, mask, light, prm, want_argmin=True)
+    own2 = R.render_fwd(depth, mask, light, amb, None, albedo, prm, want_argmin=True, camera=cam, prepared=pre)
+    plan = R.RenderFwdPlan(B, L, H, W, prm, dev, want_argmin=True, camera=cam)
+    assert plan.normals_stage == "kernel"
+    args = (depth, mask, light, amb, None, albedo)
+    planned = {k: v.clone() for k, v in plan(*args).items() if k in keys}
+    graphed = {k: v.clone() for k, v in R.RenderFwdPlan(B, L, H, W, prm, dev, want_argmin=True, camera=cam).capture(*args).replay().items()
+               if k in keys}
+    monkeypatch.setattr(R, "NORMALS_KERNEL_MIN_LIGHTS", 1 << 30)
+    assert R.normals_stage_for(L) == "fused"
+    fused = R.render_fwd(depth, mask, light, amb, None, albedo, prm, want_argmin=True, camera=cam)
+    assert R.RenderFwdPlan(B, L, H, W, prm, dev, want_argmin=True, camera=cam).normals_stage == "fused"
+    for k in keys:
+        for name, got in (("own launch", own), ("own launch, prepass hoisted", own2), ("plan", planned), ("hipGraph", graphed)):
+            assert torch.equal(got[k], fused[k]), (name, k)
+
+
 def test_forward_normals_tolerance_contract_and_non_finite_cells():
     """include/gcfr.h: forward normals are NOT bit-pinned (kornia's summation order is unspecified and the kernel uses
     reciprocals / rsq + Newton steps instead of IEEE divisions, round-2 advisor note): the contract is `within 4 f32 ulp of
