@@ -1187,7 +1187,7 @@ def main():
     ap.add_argument("--normals-stage", choices=["auto", "fused", "kernel"], default="auto",
                     help="'kernel' = the normals stage as its own launch (gcfr_normals_fwd) in front of gcfr_render_fwd instead of "
                          "fused into the march epilogue (three launches per step, the same bits); 'auto' = the product's rule: by "
-                         "the number of lights per face (block.normals_stage_for: fused below 8)")
+                         "the number of lights per face (block.normals_stage_for: fused below 16)")
     ap.add_argument("--verbose-json", action="store_true", help="print the line with every note / sample description (default: compact)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the configs[2] training-step leg of the headline line")
     ap.add_argument("--pixels", choices=["all", "mask"], default="all",

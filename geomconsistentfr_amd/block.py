@@ -168,10 +168,11 @@ def shade(normals, depth, albedo, light_pt, ambient, min_dist, params: RenderPar
 
 # Lights per face from which the normals stage runs as its own launch (gcfr_normals_fwd, then gcfr_render_fwd reads its
 # output) instead of inside the march's epilogue (gcfr_render_from_depth_fwd): the stencil does not depend on the light, the
-# fused epilogue evaluates it once per (pixel, light).  Measured: one light per face -- fused wins (one launch fewer, no
-# normals re-read: profiles/r04_normals_stage_ab.txt); 18 lights per 512 x 512 face (BASELINE configs[4]) -- the own launch
-# wins by 2.1 % (profiles/r05_config5_normals_stage_ab.txt).  Bit-identical either way (tests/test_gpu_normals.py).
-NORMALS_KERNEL_MIN_LIGHTS = 8
+# fused epilogue evaluates it once per (pixel, light).  Measured, own launch against fused (512 x 512 x 320, interleaved,
+# profiles/r05_normals_stage_crossover.txt): four batches in flight +0.5 % at 4 lights per face, +1.3 % at 8, +2.1 % at 18
+# (BASELINE configs[4]); one batch at a time -1.9 % at 4, -0.8 % at 8, +0.6 % at 18; one light per face: fused wins both ways
+# (profiles/r04_normals_stage_ab.txt).  16: where both rates gain.  Bit-identical either way (tests/test_gpu_normals.py).
+NORMALS_KERNEL_MIN_LIGHTS = 16
 
 
 def normals_stage_for(n_lights: int, normals_stage: str = "auto") -> str:

@@ -93,7 +93,7 @@ def test_many_lights_per_face_run_the_normals_stage_as_its_own_launch_with_the_s
     from geomconsistentfr_amd import RenderParams
     from geomconsistentfr_amd import block as R
     rng = np.random.default_rng(12)
-    B, L, H, W = 2, 9, 96, 128
+    B, L, H, W = 2, 17, 96, 128
     assert L >= R.NORMALS_KERNEL_MIN_LIGHTS and R.normals_stage_for(L) == "kernel" and R.normals_stage_for(1) == "fused"
     dev = torch.device(DEV)
     depth = torch.from_numpy((30 * rng.random((B, H, W))).astype(np.float32)).to(dev)
