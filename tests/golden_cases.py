@@ -30,10 +30,19 @@ def _inputs():
     return inp["depths"], inp["masks"], alb
 
 
+SMOOTH_T8 = ("t8_a", "t8_b", "t8_c", "t8_d", "t8_e")
+# oracle/make_golden_rough.py: untrained-network / noise-40 / noise-400 depth, sparse masks, lights on the nine-way
+# branch's boundaries (t8_f exactly on them, t8_h one ulp outside), (1,0,0) / (0,0,1) / z<0 (t8_g).  t8_f stores the RGB
+# of face 0 only (`rendered_images_face0`) and the gradients of the `full` loss; t8_h the march's values/indices only.
+ROUGH_T8 = ("t8_f", "t8_g", "t8_h")
+
+
 def t8_batches():
-    """Yield (name, dict) per T8 batch of 3 faces (training form)."""
-    depths, masks, alb = _inputs()
-    for name in ("t8_a", "t8_b", "t8_c", "t8_d", "t8_e"):
+    """Yield (name, dict) per T8 batch of 3 faces (training form): the smooth batches, then the rough ones."""
+    depths_s, masks_s, alb = _inputs()
+    rough = np.load(os.path.join(GOLDEN, "inputs_rough.npz"))
+    for name in SMOOTH_T8 + ROUGH_T8:
+        depths, masks = (depths_s, masks_s) if name in SMOOTH_T8 else (rough["depths"], rough["masks"])
         z = np.load(os.path.join(GOLDEN, name + ".npz"))
         di, mi = z["depth_idx"], z["mask_idx"]
         yield name, dict(

@@ -1,5 +1,5 @@
 """GPU parity of the backward kernels (through the C ABI and the autograd glue) against
-  (1) the reference's own autograd gradients stored in tests/golden/t8_a.npz, t8_b.npz,
+  (1) the reference's own autograd gradients stored in tests/golden/t8_a.npz, t8_b.npz and (rough depth) t8_f.npz,
   (2) autograd through the materialised oracle port at small sizes with random cotangents.
 Gates (BASELINE.json states none for gradients): depth/albedo grads
 max|diff| <= 1e-3 * max|g|; light/ambient grads rel <= 1e-4.
@@ -114,6 +114,21 @@ def test_backward_matches_reference_autograd_shadow_loss(idx):
     l4 = exp["grad_shadow_light4"]
     np.testing.assert_allclose(gl, l4[:, 1:4], rtol=1e-4, atol=1e-4 * np.abs(l4[:, 1:4]).max())
     assert np.abs(gamb).max() <= 1e-6 * max(1.0, np.abs(l4[:, 0]).max()) + np.abs(l4[:, 0]).max() * 1e-5
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["three_kernel", "fused"])
+def test_backward_matches_reference_autograd_on_rough_depth(fused):
+    """tests/golden/t8_f.npz (oracle/make_golden_rough.py): 100 x the depth head of a freshly initialised reference
+    network -- what epoch 0 marches, argmin near-ties included -- sparse masks, lights ON the nine-way branch's
+    boundaries (C_x == -W/2, C_y == H/2) and one inside the image; the reference's own autograd gradients of the
+    `full` loss (RGB + shadow terms), same gates as the smooth batches."""
+    case = dict(t8_batches())["t8_f"]
+    exp = case["expect"]
+    gd, _, gl, gamb = (_run_fused if fused else _run_hip)(case, "full", int(exp["grad_full_seed"]))
+    _check_depth_grad(gd, exp["grad_full_depth"])
+    l4 = exp["grad_full_light4"]
+    np.testing.assert_allclose(gl, l4[:, 1:4], rtol=1e-4, atol=1e-4 * np.abs(l4[:, 1:4]).max())
+    np.testing.assert_allclose(gamb, l4[:, 0], rtol=1e-5)
 
 
 @pytest.mark.parametrize("light", [(0.3, 0.5, 0.8), (-0.9, 0.1, 0.2), (0.004, -0.003, 1.0), (0.7, -0.7, 0.05),

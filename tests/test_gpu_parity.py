@@ -66,15 +66,20 @@ def test_render_matches_reference_golden(name, case):
     out = render(to_dev(case["depth"])[:, None], to_dev(case["albedo"]), to_dev(case["light"]),
                  to_dev(case["ambient"]), n.float().to(dev()), to_dev(case["mask"]), params_from(prm))
     w = out["shadow_mask_weights"].cpu().numpy()
-    e_w = np.abs(w - exp["shadow_mask_weights"]).max()
-    assert e_w <= W_GATE, e_w
-    assert e_w <= 2e-5, "inside the gate but worse than the expected fp32 noise: %g" % e_w
+    if "shadow_mask_weights" in exp:                     # (t8_h pins the march's values / indices only: test_gpu_configs)
+        e_w = np.abs(w - exp["shadow_mask_weights"]).max()
+        assert e_w <= W_GATE, e_w
+        assert e_w <= 2e-5, "inside the gate but worse than the expected fp32 noise: %g" % e_w
     np.testing.assert_allclose(out["unit_light_direction"].cpu().numpy().reshape(-1, 3),
                                exp["unit_light_direction"].reshape(-1, 3), atol=1e-7)
     if "full_shading" in exp:
         assert np.abs(out["full_shading"].cpu().numpy() - exp["full_shading"]).max() <= 1e-5
     if "rendered_images" in exp:
         e = np.abs(out["rendered_images"].cpu().numpy() - exp["rendered_images"]).max()
+        assert e <= RGB_GATE, e
+        assert e <= 2e-5, e
+    if "rendered_images_face0" in exp:                   # the rough batch t8_f stores face 0's RGB only
+        e = np.abs(out["rendered_images"].cpu().numpy()[:1] - exp["rendered_images_face0"]).max()
         assert e <= RGB_GATE, e
         assert e <= 2e-5, e
 

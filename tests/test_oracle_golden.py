@@ -51,7 +51,8 @@ def test_c_oracle_matches_reference_golden(name, case):
     nrm = normals_for(case["depth"], prm).numpy()
     o = c_oracle.shade(nrm, case["depth"], case["albedo"], pt[:, None, :], case["ambient"][:, None], md,
                        intensity=prm["intensity"])
-    assert np.abs(o["shadow_w"][:, 0] - exp["shadow_mask_weights"]).max() <= 2e-6
+    if "shadow_mask_weights" in exp:
+        assert np.abs(o["shadow_w"][:, 0] - exp["shadow_mask_weights"]).max() <= 2e-6
     # minimum_distance and argmin as the reference's own torch.min returned them (T8:514), before the +5 bonus
     md_raw, am = c_oracle.shadow_min_distance(case["depth"], case["mask"], pt[:, None, :], tt)
     md_ref, am_ref = exp["minimum_distance"], exp["argmin"].astype(np.int32)
@@ -70,6 +71,8 @@ def test_c_oracle_matches_reference_golden(name, case):
         assert np.abs(o["full_shading"][:, 0] - exp["full_shading"]).max() <= 1e-6
     if "rendered_images" in exp:
         assert np.abs(o["rendered"][:, 0] - exp["rendered_images"]).max() <= 1e-6
+    if "rendered_images_face0" in exp:
+        assert np.abs(o["rendered"][:1, 0] - exp["rendered_images_face0"]).max() <= 1e-6
 
 
 def test_sample_table_is_numpy_arange():
