@@ -15,7 +15,7 @@ from . import build as _build
 _LIB = None
 
 GCFR_OK = 0
-ABI_VERSION = 5      # include/gcfr.h GCFR_ABI_VERSION this binding was written against
+ABI_VERSION = 6      # include/gcfr.h GCFR_ABI_VERSION this binding was written against
 _ERRORS = {-1: "GCFR_ERR_INVALID_ARGUMENT", -2: "GCFR_ERR_LAUNCH"}
 
 _p, _i, _f, _d = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_double
@@ -34,16 +34,16 @@ class Options(ctypes.Structure):
     except `pixels`, see the header).  Build one with `options(...)`; pass it as `options=` to the block functions /
     RenderFwdPlan."""
     _fields_ = [("struct_size", ctypes.c_uint32), ("tile_w", _i), ("group", _i), ("ksplit", _i),
-                ("depth_bound_skip", _i), ("schedule", _i), ("tile_order", _i), ("lds_stage", _i),
+                ("depth_bound_skip", _i), ("lds_stage", _i),
                 ("event_start", _p), ("event_stop", _p), ("counters", _p), ("pixels", _i), ("phase", _i)]
 
 
-def options(tile_w=0, group=0, ksplit=-1, depth_bound_skip=-1, schedule=-1, tile_order=-1, event_start=None,
+def options(tile_w=0, group=0, ksplit=-1, depth_bound_skip=-1, event_start=None,
             event_stop=None, counters=None, lds_stage=-1, pixels=0, phase=0) -> Options:
     o = Options()
     load().gcfr_options_default(ctypes.byref(o))
     o.tile_w, o.group, o.ksplit, o.depth_bound_skip = tile_w, group, ksplit, depth_bound_skip
-    o.schedule, o.tile_order, o.lds_stage = schedule, tile_order, lds_stage
+    o.lds_stage = lds_stage
     o.event_start, o.event_stop, o.counters = event_start, event_stop, counters
     o.pixels = pixels
     o.phase = phase
@@ -97,7 +97,7 @@ _SIGNATURES = {
     "gcfr_render_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _d, _d, _d, _d, _f, _i, _f, _p, _p, _p, _p, _p,
                              _p, _p, _p, _p, _p]),
     "gcfr_light_prep_bwd": (_i, [_p, _i, _i, _f, _f, _p, _p, _p, _p]),
-    "gcfr_inference_images_u8": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "gcfr_inference_images_u8": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p]),
     "gcfr_fix_border_u8": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "gcfr_assemble_batch_u8": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "gcfr_masked_metrics_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i]),

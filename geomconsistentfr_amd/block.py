@@ -201,32 +201,43 @@ class Prepared:
     """What `render_prepass()` leaves behind for the `render_fwd(..., prepared=...)` / `render_from_depth(..., prepared=...)`
     that follows: the workspace the prepass filled, the light outputs it wrote, the event that marks its end on the side
     stream, and the arguments it was issued with (the march must be issued with the same ones)."""
-    __slots__ = ("ws", "ws_bytes", "unit", "pt", "event", "key", "depth", "mask_u8", "light")
+    __slots__ = ("ws", "ws_bytes", "unit", "pt", "event", "key", "depth", "mask_u8", "light", "src")
 
 
-def _prepass_key(depth, mask_u8, light, params, options):
+def source_signature(*tensors):
+    """What identifies the CALLER's depth / mask / light between a prepass and its march: storage address, in-place version
+    counter (shared by every view of a tensor, bumped by every in-place write), shape, strides and dtype of the tensors AS THE
+    CALLER HANDED THEM OVER -- before any f32 / u8 / contiguous conversion, whose copies have fresh addresses every time."""
+    return tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype) for t in tensors)
+
+
+def _prepass_key(shapes, params, options):
     import ctypes
     knobs = None
     if options is not None:
         o = _lib.with_phase(options, 0)
         o.event_start = o.event_stop = None
         knobs = bytes(ctypes.string_at(ctypes.byref(o), ctypes.sizeof(o)))
-    return (depth.data_ptr(), tuple(depth.shape), mask_u8.data_ptr(), tuple(mask_u8.shape), light.data_ptr(), tuple(light.shape),
-            params, knobs)
+    return (shapes, params, knobs)
 
 
 def render_prepass(depth, mask, light, params: RenderParams = RenderParams(), want_argmin: bool = True, options=None,
-                   stream: Optional[torch.cuda.Stream] = None) -> Prepared:
+                   stream: Optional[torch.cuda.Stream] = None, src=None) -> Prepared:
     """The FIRST of the forward's two launches on its own (gcfr_options.phase = 1): depth repack, mask statistics, depth
     bounds, horizon tables, light preparation, sample-table check -- everything that depends on depth (B,H,W), mask (B|1,H,W)
     and light (B,L,3) only.  Enqueued on `stream` (default: the device's side stream) behind whatever the CURRENT stream
     has enqueued so far, so that it runs under the work the caller enqueues next on the current stream (RelightNet.forward:
     the albedo decoder's convolutions, T8:226-290).  Pass the result as `prepared=` to render_fwd / render_from_depth with the
     same depth, mask, light, params, want_argmin and options: that call waits for the prepass and enqueues the march alone.
-    Bit-identical to the one-call form (the same two launches with the same arguments)."""
+    Bit-identical to the one-call form (the same two launches with the same arguments).
+    `src`: the `source_signature()` of the caller's own tensors where a wrapper reshaped them before this call (default: of
+    depth, mask, light as given); the march call must present the same signature -- a different tensor, or the same one written
+    in place in between, is an error there, not a render of stale data."""
     _require_device(depth, mask, light)
     want_argmin, options = _pixels_options(params, want_argmin, options)
     L_ = _lib.load()
+    if src is None:
+        src = source_signature(depth, mask, light)
     depth = _f32c(depth)
     B, H, W = depth.shape
     dev = depth.device
@@ -240,11 +251,14 @@ def render_prepass(depth, mask, light, params: RenderParams = RenderParams(), wa
     p.pt = torch.empty((B, L, 3), dtype=torch.float32, device=dev)
     p.ws_bytes = int(L_.gcfr_shadow_workspace_bytes(B, H, W))
     p.ws = torch.empty(p.ws_bytes, dtype=torch.uint8, device=dev)
-    p.key = _prepass_key(depth, mask_u8, light, params, options)
+    p.src = src
+    p.key = _prepass_key((tuple(depth.shape), tuple(mask_u8.shape), tuple(light.shape)), params, options)
     box = ctypes_float4(params.bonus_box) if params.bonus_box is not None else None
     clamp = params.clamp_light_z_min is not None
     side = stream if stream is not None else side_stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))              # depth / light are produced on the current stream
+    for t in (depth, mask_u8, light, p.unit, p.pt, p.ws):         # allocated on the current stream, used on `side`: the
+        t.record_stream(side)                                     # caching allocator must not recycle them under the prepass
     opt1 = _lib.with_phase(options, 1)
     with torch.cuda.device(dev), torch.cuda.stream(side):
         _lib.check(L_.gcfr_render_fwd(
@@ -259,7 +273,7 @@ def render_prepass(depth, mask, light, params: RenderParams = RenderParams(), wa
 
 
 def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParams = RenderParams(),
-               want_argmin: bool = True, camera=None, options=None, prepared: Optional[Prepared] = None):
+               want_argmin: bool = True, camera=None, options=None, prepared: Optional[Prepared] = None, src=None):
     """One enqueue for the whole forward block (gcfr_render_fwd): light prep, depth repack, ray march with
     the shading fused into its epilogue.  depth (B,H,W), mask (B|1,H,W), light (B,L,3) raw/target,
     ambient (B,L), normals/albedo (B,3,H,W).  Returns a dict of f32 tensors (B,L,...).
@@ -267,26 +281,33 @@ def render_fwd(depth, mask, light, ambient, normals, albedo, params: RenderParam
     epilogue as well (gcfr_render_from_depth_fwd); the dict then also carries "surface_normals".
     `options`: a `_lib.Options`; only `pixels` changes a result bit, and `params.pixels = "mask"` forces the argmin plane (see
     shadow_min_distance).  `prepared`: the result of `render_prepass()` on the same depth / mask / light / params / options --
-    the prepass has been enqueued already (side stream), this call waits for it and enqueues the march only."""
+    the prepass has been enqueued already (side stream), this call waits for it and enqueues the march only.  The caller's
+    depth / mask / light are compared with what the prepass was given (`source_signature`: address, in-place version, shape,
+    strides, dtype; `src` = the signature of the caller's own tensors where a wrapper reshaped them): a mismatch raises."""
     _require_device(depth, mask, light, ambient, albedo)
     if normals is None and camera is None:
         raise _lib.GcfrError("render_fwd needs either normals or camera=(fx, fy, cx, cy, z_offset)")
     want_argmin, options = _pixels_options(params, want_argmin, options)
     L_ = _lib.load()
-    depth = _f32c(depth)
-    B, H, W = depth.shape
-    dev = depth.device
-    mask_u8 = mask_to_u8(mask).reshape(-1, H, W)
-    light = _f32c(light).reshape(B, -1, 3)
-    L = light.shape[1]
     if prepared is not None:
-        # the march reads the very tensors the prepass read (its f32 / u8 copies where the caller's were converted)
-        if tuple(prepared.depth.shape) != (B, H, W) or tuple(prepared.light.shape) != (B, L, 3) or \
-                tuple(prepared.mask_u8.shape) != tuple(mask_u8.shape):
-            raise _lib.GcfrError("render_fwd(prepared=...): shapes differ from the prepass call's")
+        # the march reads the very tensors the prepass read (its f32 / u8 copies where the caller's were converted): what the
+        # caller hands over NOW must be what it handed to the prepass, unmodified
+        if (src if src is not None else source_signature(depth, mask, light)) != prepared.src:
+            raise _lib.GcfrError("render_fwd(prepared=...): depth / mask / light are not the tensors the prepass was issued with "
+                                 "(a different tensor, another view, or written in place since)")
         depth, mask_u8, light = prepared.depth, prepared.mask_u8, prepared.light
-        if prepared.key != _prepass_key(depth, mask_u8, light, params, options):
+        B, H, W = depth.shape
+        dev = depth.device
+        L = light.shape[1]
+        if prepared.key != _prepass_key((tuple(depth.shape), tuple(mask_u8.shape), tuple(light.shape)), params, options):
             raise _lib.GcfrError("render_fwd(prepared=...): params / options differ from the prepass call's")
+    else:
+        depth = _f32c(depth)
+        B, H, W = depth.shape
+        dev = depth.device
+        mask_u8 = mask_to_u8(mask).reshape(-1, H, W)
+        light = _f32c(light).reshape(B, -1, 3)
+        L = light.shape[1]
     ambient = _f32c(ambient).reshape(B, L)
     if normals is not None:
         _require_device(normals)
@@ -369,99 +390,118 @@ def _opt_ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-class _RenderFunction(torch.autograd.Function):
-    """autograd glue around the HIP forward/backward kernels (one light per image).
+def _light_shapes(B, light, ambient):
+    """The caller's light / ambient as (B,L,3) / (B,L) views and whether the call was the reference's one-light form
+    (light (B,3), ambient (B,): outputs without the light axis) or the many-lights form (light (B,L,3), ambient (B,L))."""
+    if light.dim() == 3 and light.shape[0] == B and light.shape[2] == 3:
+        L = light.shape[1]
+        if ambient.numel() != B * L:
+            raise _lib.GcfrError("light is (B,L,3) = %s: ambient must hold B*L = %d values, got %s"
+                                 % (tuple(light.shape), B * L, tuple(ambient.shape)))
+        return light, ambient.reshape(B, L), L, True
+    if light.numel() != B * 3:
+        raise _lib.GcfrError("light must be (B,3) or (B,L,3); got %s for B = %d" % (tuple(light.shape), B))
+    return light.reshape(B, 1, 3), ambient.reshape(B, 1), 1, False
 
-    Differentiable inputs: depth, albedo, light, ambient, normals -- the leaves autograd reaches in the
+
+def _result_dict(B, H, W, multi, ambient, w, full, fin, ren, unit, md, normals=None):
+    """The reference's tensors by name (T8:524 / S1:505).  One-light form: the reference's shapes.  Many-lights form: a light
+    axis after the batch axis (w / full / final / minimum_distance (B,L,H,W), rendered_images (B,L,3,H,W),
+    unit_light_direction (B,L,3,1,1), ambient_values (B,L,1,1), ambient_light (B,L,H,W))."""
+    if multi:
+        L = w.shape[1]
+        amb = ambient.to(torch.float32).reshape(B, L, 1, 1)
+        r = dict(shadow_mask_weights=w, ambient_light=amb.expand(B, L, H, W), full_shading=full, rendered_images=ren,
+                 unit_light_direction=unit.reshape(B, L, 3, 1, 1), ambient_values=amb, final_shading=fin, minimum_distance=md)
+    else:
+        amb = ambient.to(torch.float32).reshape(B, 1, 1)
+        r = dict(shadow_mask_weights=w[:, 0], ambient_light=amb.expand(B, H, W), full_shading=full[:, 0],
+                 rendered_images=ren[:, 0], unit_light_direction=unit.reshape(B, 3, 1, 1), ambient_values=amb,
+                 final_shading=fin[:, 0], minimum_distance=md[:, 0])
+    if normals is not None:
+        r["surface_normals"] = normals
+    return r
+
+
+class _RenderFunction(torch.autograd.Function):
+    """autograd glue around the HIP forward/backward kernels, L >= 1 lights per image.
+
+    Differentiable inputs: depth, albedo, light (B,L,3), ambient (B,L), normals -- the leaves autograd reaches in the
     reference (T8:352-524).  The mask and the constants are not differentiable."""
 
     @staticmethod
     def forward(ctx, depth, albedo, light, ambient, normals, mask_u8, params):
         B, _, H, W = depth.shape
+        L = light.shape[1]
         depth3 = _f32c(depth).reshape(B, H, W)
-        light2 = _f32c(light).reshape(B, 3)
-        amb = _f32c(ambient).reshape(B, 1)
+        light3 = _f32c(light).reshape(B, L, 3)
+        amb = _f32c(ambient).reshape(B, L)
         albedo_c = _f32c(albedo)
         normals_c = _f32c(normals)
         need_grad = any(ctx.needs_input_grad[:5])
-        out = render_fwd(depth3, mask_u8, light2.reshape(B, 1, 3), amb, normals_c, albedo_c, params,
-                         want_argmin=need_grad)
-        unit, pt, md, am = (out["unit_light_direction"].reshape(B, 3), out["light_pt"].reshape(B, 3),
-                            out["minimum_distance"], out["argmin"])
+        out = render_fwd(depth3, mask_u8, light3, amb, normals_c, albedo_c, params, want_argmin=need_grad)
+        unit, pt, md, am = out["unit_light_direction"], out["light_pt"], out["minimum_distance"], out["argmin"]
         ctx.params = params
         if need_grad:
-            ctx.save_for_backward(depth3, albedo_c, light2, amb, normals_c, pt, md, am)
-        w, full, fin, ren = (out["shadow_mask_weights"][:, 0], out["full_shading"][:, 0],
-                             out["final_shading"][:, 0], out["rendered_images"][:, 0])
-        md0 = md[:, 0]
-        ctx.mark_non_differentiable(md0)
-        return w, full, fin, ren, unit, md0
+            ctx.save_for_backward(depth3, albedo_c, light3, amb, normals_c, pt, md, am)
+        ctx.mark_non_differentiable(md)
+        return (out["shadow_mask_weights"], out["full_shading"], out["final_shading"], out["rendered_images"], unit, md)
 
     @staticmethod
     def backward(ctx, g_w, g_full, g_fin, g_ren, g_unit, _g_md):
-        depth3, albedo, light2, amb, normals, pt, md, am = ctx.saved_tensors
+        depth3, albedo, light3, amb, normals, pt, md, am = ctx.saved_tensors
         prm = ctx.params
         L_ = _lib.load()
         B, H, W = depth3.shape
+        L = light3.shape[1]
         dev = depth3.device
         gw, gfull, gfin, gren = [None if g is None else _f32c(g) for g in (g_w, g_full, g_fin, g_ren)]
         grad_normals = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
         grad_albedo = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
         grad_depth = _zeros((B, H, W), torch.float32, dev)
-        grad_pt = _zeros((B, 1, 3), torch.float64, dev)
-        grad_amb = _zeros((B, 1), torch.float64, dev)
-        grad_md = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        grad_pt = _zeros((B, L, 3), torch.float64, dev)
+        grad_amb = _zeros((B, L), torch.float64, dev)
+        grad_md = torch.empty((B, L, H, W), dtype=torch.float32, device=dev)
         tt = sample_table(prm, dev)
         with torch.cuda.device(dev):
             st = _stream_ptr(dev)
             _lib.check(L_.gcfr_shade_bwd(normals.data_ptr(), depth3.data_ptr(), albedo.data_ptr(), pt.data_ptr(),
-                                         amb.data_ptr(), md.data_ptr(), B, 1, H, W, float(prm.directional_intensity),
+                                         amb.data_ptr(), md.data_ptr(), B, L, H, W, float(prm.directional_intensity),
                                          _opt_ptr(gw), _opt_ptr(gfull), _opt_ptr(gfin), _opt_ptr(gren),
                                          grad_normals.data_ptr(), grad_albedo.data_ptr(), grad_depth.data_ptr(),
                                          grad_pt.data_ptr(), grad_amb.data_ptr(), grad_md.data_ptr(), st),
                        "gcfr_shade_bwd")
             _lib.check(L_.gcfr_shadow_bwd(grad_md.data_ptr(), depth3.data_ptr(), pt.data_ptr(), am.data_ptr(),
-                                          B, 1, H, W, prm.n_samples, tt.data_ptr(), grad_depth.data_ptr(),
+                                          B, L, H, W, prm.n_samples, tt.data_ptr(), grad_depth.data_ptr(),
                                           grad_pt.data_ptr(), st), "gcfr_shadow_bwd")
-            grad_light = torch.empty((B, 3), dtype=torch.float32, device=dev)
-            gu = None if g_unit is None else _f32c(g_unit).reshape(B, 3)
+            grad_light = torch.empty((B, L, 3), dtype=torch.float32, device=dev)
+            gu = None if g_unit is None else _f32c(g_unit).reshape(B * L, 3)
             clamp = prm.clamp_light_z_min is not None
-            _lib.check(L_.gcfr_light_prep_bwd(light2.data_ptr(), B, int(clamp), float(prm.clamp_light_z_min or 0.0),
+            _lib.check(L_.gcfr_light_prep_bwd(light3.data_ptr(), B * L, int(clamp), float(prm.clamp_light_z_min or 0.0),
                                               float(prm.light_distance), _opt_ptr(gu), grad_pt.data_ptr(),
                                               grad_light.data_ptr(), st), "gcfr_light_prep_bwd")
-        return (grad_depth.reshape(B, 1, H, W), grad_albedo, grad_light, grad_amb.reshape(B).float(),
-                grad_normals, None, None)
+        return (grad_depth.reshape(B, 1, H, W), grad_albedo, grad_light, grad_amb.float(), grad_normals, None, None)
 
 
 def render(depth, albedo, light, ambient, normals, mask, params: RenderParams = RenderParams()):
-    """Render block for a batch with one light per image (the reference's call shape), differentiable.
+    """Render block for a batch, differentiable; one light per image (the reference's call shape) or many.
 
       depth (B,1,H,W) f32      c2_o_depth (x100 already applied, T8:350)
       albedo (B,3,H,W) f32     c2_o_albedo
-      light (B,3)              SL_lin2[...,1:4] (T8:357) or target_lighting (S1:332)
-      ambient (B,)             SL_lin2[...,0] (T8:367) / target ambient
+      light (B,3)              SL_lin2[...,1:4] (T8:357) or target_lighting (S1:332)   | (B,L,3): L lights per face
+      ambient (B,)             SL_lin2[...,0] (T8:367) / target ambient                | (B,L)
       normals (B,3,H,W)        depth_to_normals(depth+offset, K), y negated (T8:353-354)
       mask (B,H,W) or (1,H,W)  0 = outside the face (T8:510)
 
-    Returns the reference's tensors by name (T8:524 / S1:505), all f32.  Gradients flow to depth, albedo,
-    light, ambient and normals through the HIP backward kernels."""
+    Returns the reference's tensors by name (T8:524 / S1:505), all f32; with (B,L,3) lights every per-light tensor carries a
+    light axis after the batch axis (`_result_dict`).  Gradients flow to depth, albedo, light, ambient and normals through
+    the HIP backward kernels (for L lights: summed over the lights where the input has no light axis)."""
     _require_device(depth, albedo, light, ambient, normals, mask)
     B, _, H, W = depth.shape
     mask_u8 = mask_to_u8(mask).reshape(-1, H, W)
-    light = light.reshape(B, 3)
-    ambient = ambient.reshape(B)
-    w, full, fin, ren, unit, md = _RenderFunction.apply(depth, albedo, light, ambient, normals, mask_u8, params)
-    amb = ambient.to(torch.float32).reshape(B, 1, 1)
-    return dict(
-        shadow_mask_weights=w,
-        ambient_light=amb.expand(B, H, W),
-        full_shading=full,
-        rendered_images=ren,
-        unit_light_direction=unit.reshape(B, 3, 1, 1),
-        ambient_values=amb,
-        final_shading=fin,
-        minimum_distance=md,
-    )
+    light3, amb2, L, multi = _light_shapes(B, light, ambient)
+    w, full, fin, ren, unit, md = _RenderFunction.apply(depth, albedo, light3, amb2, normals, mask_u8, params)
+    return _result_dict(B, H, W, multi, amb2, w, full, fin, ren, unit, md)
 
 
 class RenderFwdPlan:
@@ -606,61 +646,66 @@ class RenderFwdPlan:
 
 
 class _RenderFromDepthFunction(torch.autograd.Function):
-    """Whole T8:353-522 seam, one light per image, differentiable w.r.t. depth, albedo, light, ambient.
-    Forward: gcfr_render_from_depth_fwd (two launches).  Backward: gcfr_render_bwd (one launch: shading,
-    ray-march and normals-stencil backward fused per pixel) + gcfr_light_prep_bwd."""
+    """Whole T8:353-522 seam, L >= 1 lights per image, differentiable w.r.t. depth, albedo, light (B,L,3), ambient (B,L).
+    Forward: gcfr_render_from_depth_fwd (two launches; from NORMALS_KERNEL_MIN_LIGHTS lights per face on the normals stage
+    as its own launch in front of gcfr_render_fwd).  Backward: gcfr_render_bwd (one launch: shading, ray-march and
+    normals-stencil backward fused per pixel, every light of a pixel in the same thread) + gcfr_light_prep_bwd."""
 
     @staticmethod
-    def forward(ctx, depth, albedo, light, ambient, mask_u8, cam, params, prepared=None):
+    def forward(ctx, depth, albedo, light, ambient, mask, cam, params, prepared=None, src=None):
         B, _, H, W = depth.shape
-        depth3 = _f32c(depth).reshape(B, H, W)
-        light2 = _f32c(light).reshape(B, 3)
-        amb = _f32c(ambient).reshape(B, 1)
+        L = light.shape[1]
+        amb = _f32c(ambient).reshape(B, L)
         albedo_c = _f32c(albedo)
         need_grad = any(ctx.needs_input_grad[:4])
-        o = render_fwd(depth3, mask_u8, light2.reshape(B, 1, 3), amb, None, albedo_c, params,
-                       want_argmin=need_grad, camera=cam, prepared=prepared)
-        if prepared is not None:
-            depth3, light2 = prepared.depth, prepared.light.reshape(B, 3)     # (what the kernels read: saved for the backward)
+        if prepared is None:
+            depth3 = _f32c(depth).reshape(B, H, W)
+            light3 = _f32c(light).reshape(B, L, 3)
+            o = render_fwd(depth3, mask, light3, amb, None, albedo_c, params, want_argmin=need_grad, camera=cam)
+        else:       # the march reads the prepass's own copies; the caller's tensors are only compared with its record
+            o = render_fwd(depth.reshape(B, H, W), mask, light, amb, None, albedo_c, params, want_argmin=need_grad, camera=cam,
+                           prepared=prepared, src=src)
+            depth3, light3 = prepared.depth, prepared.light     # (what the kernels read: saved for the backward)
         ctx.params, ctx.cam = params, cam
         if need_grad:
-            ctx.save_for_backward(depth3, albedo_c, light2, amb, o["light_pt"].reshape(B, 3), o["minimum_distance"],
-                                  o["argmin"], o["surface_normals"])
-        md0 = o["minimum_distance"][:, 0]
-        ctx.mark_non_differentiable(md0)
-        return (o["shadow_mask_weights"][:, 0], o["full_shading"][:, 0], o["final_shading"][:, 0],
-                o["rendered_images"][:, 0], o["unit_light_direction"].reshape(B, 3), o["surface_normals"], md0)
+            ctx.save_for_backward(depth3, albedo_c, light3, amb, o["light_pt"], o["minimum_distance"], o["argmin"],
+                                  o["surface_normals"])
+        md = o["minimum_distance"]
+        ctx.mark_non_differentiable(md)
+        return (o["shadow_mask_weights"], o["full_shading"], o["final_shading"], o["rendered_images"],
+                o["unit_light_direction"], o["surface_normals"], md)
 
     @staticmethod
     def backward(ctx, g_w, g_full, g_fin, g_ren, g_unit, g_nrm, _g_md):
-        depth3, albedo, light2, amb, pt, md, am, nrm_fwd = ctx.saved_tensors
+        depth3, albedo, light3, amb, pt, md, am, nrm_fwd = ctx.saved_tensors
         prm, cam = ctx.params, ctx.cam
         L_ = _lib.load()
         B, H, W = depth3.shape
+        L = light3.shape[1]
         dev = depth3.device
         gw, gfull, gfin, gren, gnrm = [None if g is None else _f32c(g) for g in (g_w, g_full, g_fin, g_ren, g_nrm)]
         grad_albedo = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
         grad_depth = _zeros((B, H, W), torch.float32, dev)
-        grad_pt = _zeros((B, 1, 3), torch.float64, dev)
-        grad_amb = _zeros((B, 1), torch.float64, dev)
-        grad_light = torch.empty((B, 3), dtype=torch.float32, device=dev)
+        grad_pt = _zeros((B, L, 3), torch.float64, dev)
+        grad_amb = _zeros((B, L), torch.float64, dev)
+        grad_light = torch.empty((B, L, 3), dtype=torch.float32, device=dev)
         tt = sample_table(prm, dev)
         fx, fy, cx, cy, z_off = cam
         with torch.cuda.device(dev):
             st = _stream_ptr(dev)
             _lib.check(L_.gcfr_render_bwd(depth3.data_ptr(), albedo.data_ptr(), pt.data_ptr(), amb.data_ptr(),
-                                          md.data_ptr(), am.data_ptr(), nrm_fwd.data_ptr(), B, 1, H, W, prm.n_samples,
+                                          md.data_ptr(), am.data_ptr(), nrm_fwd.data_ptr(), B, L, H, W, prm.n_samples,
                                           tt.data_ptr(),
                                           fx, fy, cx, cy, z_off, 1, float(prm.directional_intensity),
                                           _opt_ptr(gw), _opt_ptr(gfull), _opt_ptr(gfin), _opt_ptr(gren), _opt_ptr(gnrm),
                                           grad_albedo.data_ptr(), grad_depth.data_ptr(), grad_pt.data_ptr(),
                                           grad_amb.data_ptr(), st), "gcfr_render_bwd")
-            gu = None if g_unit is None else _f32c(g_unit).reshape(B, 3)
+            gu = None if g_unit is None else _f32c(g_unit).reshape(B * L, 3)
             clamp = prm.clamp_light_z_min is not None
-            _lib.check(L_.gcfr_light_prep_bwd(light2.data_ptr(), B, int(clamp), float(prm.clamp_light_z_min or 0.0),
+            _lib.check(L_.gcfr_light_prep_bwd(light3.data_ptr(), B * L, int(clamp), float(prm.clamp_light_z_min or 0.0),
                                               float(prm.light_distance), _opt_ptr(gu), grad_pt.data_ptr(),
                                               grad_light.data_ptr(), st), "gcfr_light_prep_bwd")
-        return (grad_depth.reshape(B, 1, H, W), grad_albedo, grad_light, grad_amb.reshape(B).float(), None, None, None, None)
+        return (grad_depth.reshape(B, 1, H, W), grad_albedo, grad_light, grad_amb.float(), None, None, None, None, None)
 
 
 _CAMERA_CACHE = {}      # id(tensor) -> (weakref to the tensor, its in-place version, scalars)
@@ -695,26 +740,31 @@ def camera_scalars(camera_matrix: torch.Tensor):
 
 def render_from_depth_prepass(depth, light, camera_matrix, mask, params: RenderParams = RenderParams()):
     """The prepass of the `render_from_depth()` call that is about to follow, enqueued NOW on the device's side stream (see
-    `render_prepass`): call it as soon as depth (B,1,H,W), light (B,3) and the mask exist -- in RelightNet.forward that is
-    before the albedo decoder runs -- and hand the result to `render_from_depth(..., prepared=...)`.  Returns None where the
-    one-call form has to be used (per-image camera matrices: the three-stage path).  (Whether the march will track the argmin
-    -- autograd or not -- does not concern the prepass.)"""
+    `render_prepass`): call it as soon as depth (B,1,H,W), light (B,3) | (B,L,3) and the mask exist -- in RelightNet.forward
+    that is before the albedo decoder runs -- and hand the result to `render_from_depth(..., prepared=...)` together with the
+    SAME depth / light / mask tensors (checked there: `source_signature`).  Returns None where the one-call form has to be
+    used (per-image camera matrices: the three-stage path).  (Whether the march will track the argmin -- autograd or not --
+    does not concern the prepass.)"""
     B, _, H, W = depth.shape
     if camera_scalars(camera_matrix) is None:
         return None
     _require_device(depth, light, mask)
-    mask_u8 = mask_to_u8(mask).reshape(-1, H, W)
-    return render_prepass(depth.reshape(B, H, W), mask_u8, light.reshape(B, 1, 3), params)
+    light3 = light if (light.dim() == 3 and light.shape[0] == B) else light.reshape(B, 1, 3)
+    return render_prepass(depth.reshape(B, H, W), mask.reshape(-1, H, W), light3, params,
+                          src=source_signature(depth, mask, light))
 
 
 def render_from_depth(depth, albedo, light, ambient, camera_matrix, z_offset, mask,
                       params: RenderParams = RenderParams(), prepared: Optional[Prepared] = None):
-    """The whole T8:353-522 seam for one light per image: normals from depth, shading, ray march, composite.
-    Two launches forward (`gcfr_render_from_depth_fwd`: prepass, march with normals + shading in its epilogue) and,
-    with autograd active, one fused backward launch (`gcfr_render_bwd`) plus the tiny light-prep backward.
-    Same dict as `render()` plus "surface_normals" (unit, y negated).
-    `prepared`: the result of `render_from_depth_prepass()` on the same depth / light / mask / params: the prepass is already
-    on its way on the side stream and this call enqueues the march only (bit-identical)."""
+    """The whole T8:353-522 seam: normals from depth, shading, ray march, composite -- for one light per image (light (B,3),
+    ambient (B,): the reference's call shape and output shapes) or MANY lights per face (light (B,L,3), ambient (B,L): one
+    prepass and one normals stage per face, L marches; every per-light output carries a light axis after the batch axis,
+    `_result_dict`).  Two launches forward (`gcfr_render_from_depth_fwd`: prepass, march with normals + shading in its
+    epilogue; from NORMALS_KERNEL_MIN_LIGHTS lights per face the normals stage is its own launch) and, with autograd active,
+    one fused backward launch (`gcfr_render_bwd`, all L lights of a pixel in one thread) plus the tiny light-prep backward.
+    Same dict as `render()` plus "surface_normals" (unit, y negated; (B,3,H,W) whatever L).
+    `prepared`: the result of `render_from_depth_prepass()` on the same depth / light / mask tensors and params: the prepass
+    is already on its way on the side stream and this call enqueues the march only (bit-identical)."""
     from .normals import depth_to_normals
     B, _, H, W = depth.shape
     needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (depth, albedo, light, ambient))
@@ -725,20 +775,15 @@ def render_from_depth(depth, albedo, light, ambient, camera_matrix, z_offset, ma
         r["surface_normals"] = normals
         return r
     cam = k4 + (float(z_offset),)
+    _require_device(depth, albedo, light, ambient, mask)
+    light3, amb2, L, multi = _light_shapes(B, light, ambient)
+    src = source_signature(depth, mask, light) if prepared is not None else None
+    mask3 = mask.reshape(-1, H, W)                 # (converted to u8 inside render_fwd; with `prepared` the prepass's copy is used)
     if needs_grad:
-        _require_device(depth, albedo, light, ambient, mask)
-        mask_u8 = mask_to_u8(mask).reshape(-1, H, W)
         w, full, fin, ren, unit, nrm, md = _RenderFromDepthFunction.apply(
-            depth, albedo, light.reshape(B, 3), ambient.reshape(B), mask_u8, cam, params, prepared)
-        amb = ambient.to(torch.float32).reshape(B, 1, 1)
-        return dict(shadow_mask_weights=w, ambient_light=amb.expand(B, H, W), full_shading=full, rendered_images=ren,
-                    unit_light_direction=unit.reshape(B, 3, 1, 1), ambient_values=amb, final_shading=fin,
-                    minimum_distance=md, surface_normals=nrm)
-    o = render_fwd(depth.reshape(B, H, W), mask.reshape(-1, H, W), light.reshape(B, 1, 3), ambient.reshape(B, 1),
-                   None, albedo, params, want_argmin=False, camera=cam, prepared=prepared)
-    amb = ambient.detach().to(torch.float32).reshape(B, 1, 1)
-    return dict(shadow_mask_weights=o["shadow_mask_weights"][:, 0], ambient_light=amb.expand(B, H, W),
-                full_shading=o["full_shading"][:, 0], rendered_images=o["rendered_images"][:, 0],
-                unit_light_direction=o["unit_light_direction"].reshape(B, 3, 1, 1), ambient_values=amb,
-                final_shading=o["final_shading"][:, 0], minimum_distance=o["minimum_distance"][:, 0],
-                surface_normals=o["surface_normals"])
+            depth, albedo, light3, amb2, mask3, cam, params, prepared, src)
+        return _result_dict(B, H, W, multi, amb2, w, full, fin, ren, unit, md, normals=nrm)
+    o = render_fwd(depth.reshape(B, H, W), mask3, light3, amb2, None, albedo, params, want_argmin=False, camera=cam,
+                   prepared=prepared, src=src)
+    return _result_dict(B, H, W, multi, amb2.detach(), o["shadow_mask_weights"], o["full_shading"], o["final_shading"],
+                        o["rendered_images"], o["unit_light_direction"], o["minimum_distance"], normals=o["surface_normals"])

@@ -35,49 +35,52 @@ __device__ inline uint8_t quantise_u8(double v)
 
 struct ImagesArgs {
     const float *input_hwc;   // (B,H,W,3) f32 in [0,1]
-    const float *rendered;    // (B,3,H,W)
+    const float *rendered;    // (B,L,3,H,W): L relit images per photograph
     const float *albedo;      // (B,3,H,W) or null
     const float *depth;       // (B,H,W) or null
     const float *depth_range; // device {min, max} of -depth over the whole batch (S8:589-590), with depth
-    const float *shadow_w;    // (B,H,W) or null
-    const float *shading;     // (B,H,W) or null
+    const float *shadow_w;    // (B,L,H,W) or null
+    const float *shading;     // (B,L,H,W) or null
     const float *normals;     // (B,3,H,W) or null
     const uint8_t *mask;      // (MB,H,W) u8 skin mask as stored on disk; mask/255.0 is an f64 division (S1:580)
-    uint8_t *out_rendered;    // (B,H,W,3)
-    uint8_t *out_shadow, *out_albedo, *out_depth, *out_shading, *out_normals;  // (B,H,W) / (B,H,W,3) or null
-    int32_t mask_batch, H, W, mask_f32;
+    uint8_t *out_rendered;    // (B,L,H,W,3)
+    uint8_t *out_shadow, *out_albedo, *out_depth, *out_shading, *out_normals;  // shadow / shading (B,L,H,W); the per-photograph
+                                                                               // maps (B,H,W) / (B,H,W,3); or null
+    int32_t mask_batch, L, H, W, mask_f32;
 };
 
 __global__ __launch_bounds__(256) void inference_images_kernel(ImagesArgs a)
 {
     const size_t P = (size_t)a.H * a.W;
-    const int b = blockIdx.y;
+    const int bl = blockIdx.y;             // (photograph, light) pair; the per-photograph maps are written by light 0's threads
+    const int b = bl / a.L;
+    const bool first = bl - b * a.L == 0;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P)
         return;
     const uint8_t mk = a.mask[(size_t)(a.mask_batch == 1 ? 0 : b) * P + p];
     const float mf = (float)mk / 255.0f;                                   // SLT:540 (torch: u8 -> f32, IEEE division)
     const double m = a.mask_f32 ? (double)mf : (double)mk / 255.0;         // value of mask_3_channels (an f64 array)
-    const size_t hwc = ((size_t)b * P + p) * 3;
+    const size_t hwc = ((size_t)b * P + p) * 3, hwc_l = ((size_t)bl * P + p) * 3;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         // input_image = training_images*255.0; rendered_image = 255.0*rendered*mask; input[mask > 0] = rendered[mask > 0]
         const double keep = (double)a.input_hwc[hwc + ch] * 255.0;
-        const double paste = (double)(255.0f * a.rendered[((size_t)b * 3 + ch) * P + p]) * m;
-        a.out_rendered[hwc + ch] = quantise_u8(m > 0.0 ? paste : keep);
-        if (a.out_albedo)   // 255.0*albedo*mask3                                   S8:605
+        const double paste = (double)(255.0f * a.rendered[((size_t)bl * 3 + ch) * P + p]) * m;
+        a.out_rendered[hwc_l + ch] = quantise_u8(m > 0.0 ? paste : keep);
+        if (a.out_albedo && first)   // 255.0*albedo*mask3                                   S8:605
             a.out_albedo[hwc + ch] = quantise_u8((double)(255.0f * a.albedo[((size_t)b * 3 + ch) * P + p]) * m);
-        if (a.out_normals)  // (255.0*(n + 1.0)/2.0)*mask3, n f64 in the reference  S8:594, 608
+        if (a.out_normals && first)  // (255.0*(n + 1.0)/2.0)*mask3, n f64 in the reference  S8:594, 608
             a.out_normals[hwc + ch] = quantise_u8(((255.0 * ((double)a.normals[((size_t)b * 3 + ch) * P + p] + 1.0)) / 2.0) * m);
     }
-    const size_t o = (size_t)b * P + p;
+    const size_t o = (size_t)b * P + p, o_l = (size_t)bl * P + p;
     if (a.out_shadow) {  // 255.0*shadow_mask_weights*mask (single-channel mask in ITS dtype)   S8:604 / SLT:575
-        const float s255 = 255.0f * a.shadow_w[o];
-        a.out_shadow[o] = quantise_u8(a.mask_f32 ? (double)(s255 * mf) : (double)s255 * m);
+        const float s255 = 255.0f * a.shadow_w[o_l];
+        a.out_shadow[o_l] = quantise_u8(a.mask_f32 ? (double)(s255 * mf) : (double)s255 * m);
     }
     if (a.out_shading)  // 255.0*final_shading*mask, final_shading f64 in the reference          S8:607
-        a.out_shading[o] = quantise_u8((255.0 * (double)a.shading[o]) * m);
-    if (a.out_depth) {  // depth = -depth; (depth - amin)/(amax - amin) in f32; 255.0*depth*mask   S8:588-590, 606
+        a.out_shading[o_l] = quantise_u8((255.0 * (double)a.shading[o_l]) * m);
+    if (a.out_depth && first) {  // depth = -depth; (depth - amin)/(amax - amin) in f32; 255.0*depth*mask   S8:588-590, 606
         const float lo = a.depth_range[0], hi = a.depth_range[1];
         const float d = ((-a.depth[o]) - lo) / (hi - lo);
         const float d255 = 255.0f * d;
@@ -147,21 +150,21 @@ using namespace gcfr;
 
 extern "C" int gcfr_inference_images_u8(const float *input_hwc, const float *rendered, const float *albedo, const float *depth,
                                         const float *depth_range, const float *shadow_w, const float *final_shading,
-                                        const float *normals, const uint8_t *mask, int32_t mask_batch, int32_t B, int32_t H,
-                                        int32_t W, uint8_t *out_rendered, uint8_t *out_shadow, uint8_t *out_albedo,
+                                        const float *normals, const uint8_t *mask, int32_t mask_batch, int32_t B, int32_t L,
+                                        int32_t H, int32_t W, uint8_t *out_rendered, uint8_t *out_shadow, uint8_t *out_albedo,
                                         uint8_t *out_depth, uint8_t *out_shading, uint8_t *out_normals, int32_t mask_f32,
                                         void *stream)
 {
-    if (!input_hwc || !rendered || !mask || !out_rendered || B <= 0 || H <= 0 || W <= 0 || B > 65535 ||
+    if (!input_hwc || !rendered || !mask || !out_rendered || B <= 0 || L <= 0 || H <= 0 || W <= 0 || (int64_t)B * L > 65535 ||
         (mask_batch != 1 && mask_batch != B) || (mask_f32 != 0 && mask_f32 != 1))
         return GCFR_ERR_INVALID_ARGUMENT;
     if ((out_shadow && !shadow_w) || (out_albedo && !albedo) || (out_shading && !final_shading) || (out_normals && !normals) ||
         (out_depth && (!depth || !depth_range)))
         return GCFR_ERR_INVALID_ARGUMENT;
     ImagesArgs a{input_hwc, rendered, albedo, depth, depth_range, shadow_w, final_shading, normals, mask,
-                 out_rendered, out_shadow, out_albedo, out_depth, out_shading, out_normals, mask_batch, H, W, mask_f32};
+                 out_rendered, out_shadow, out_albedo, out_depth, out_shading, out_normals, mask_batch, L, H, W, mask_f32};
     const size_t P = (size_t)H * W;
-    hipLaunchKernelGGL(inference_images_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0,
+    hipLaunchKernelGGL(inference_images_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)(B * L)), dim3(256), 0,
                        (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? GCFR_OK : GCFR_ERR_LAUNCH;
 }

@@ -763,6 +763,15 @@ struct Knobs {
     unsigned long long *counters = nullptr;
 };
 
+// gcfr_options.phase == 1 (the prepass alone), read only from a struct whose size has been checked: a caller built against
+// another revision of the struct is refused by resolve_options() below, never interpreted field by field
+static inline bool prepass_only(const gcfr_options *opt)
+{
+    return opt && opt->struct_size == sizeof(gcfr_options) && opt->phase == 1;
+}
+
+static_assert(sizeof(gcfr_options) == 56, "gcfr_options: ABI revision 6 layout (include/gcfr.h); bump GCFR_ABI_VERSION with it");
+
 static int resolve_options(const gcfr_options *opt, Knobs &k)
 {
     if (!opt)
@@ -772,9 +781,8 @@ static int resolve_options(const gcfr_options *opt, Knobs &k)
     const int tw = opt->tile_w, g = opt->group;
     if ((tw != 0 && tw != 8 && tw != 16 && tw != 32 && tw != 64) || (g != 0 && g != 1 && g != 2 && g != 4) ||
         opt->ksplit < -1 || opt->ksplit > 1 || opt->depth_bound_skip < -1 || opt->depth_bound_skip > 1 ||
-        opt->schedule < -1 || opt->schedule > 0 || opt->tile_order < -1 || opt->tile_order > 0 || opt->lds_stage < -1 ||
-        opt->lds_stage > 1 || opt->pixels < -1 || opt->pixels > 1 || opt->phase < -1 || opt->phase > 2)
-        return GCFR_ERR_INVALID_ARGUMENT;  // (schedule / tile_order: the grid is the only schedule; the fields keep the struct layout)
+        opt->lds_stage < -1 || opt->lds_stage > 1 || opt->pixels < -1 || opt->pixels > 1 || opt->phase < -1 || opt->phase > 2)
+        return GCFR_ERR_INVALID_ARGUMENT;
     k.tile_w = tw;
     k.group = g ? g : 4;
     k.ksplit = opt->ksplit;
@@ -794,7 +802,7 @@ extern "C" void gcfr_options_default(gcfr_options *opt)
         return;
     *opt = gcfr_options{};
     opt->struct_size = (uint32_t)sizeof(gcfr_options);
-    opt->ksplit = opt->depth_bound_skip = opt->schedule = opt->tile_order = opt->lds_stage = -1;
+    opt->ksplit = opt->depth_bound_skip = opt->lds_stage = -1;
     opt->pixels = opt->phase = 0;
 }
 
@@ -866,7 +874,7 @@ static int shadow_fwd_impl(const float *depth, const uint8_t *mask_u8, int32_t m
                            int32_t *argmin, void *workspace, size_t workspace_bytes, void *stream,
                            const FusedShade &fs, const gcfr_options *opt)
 {
-    const bool pre_only = opt && opt->phase == 1;  // (the prepass alone: the march's operands may still be missing)
+    const bool pre_only = prepass_only(opt);  // (the prepass alone: the march's operands may still be missing)
     if (!depth || !mask_u8 || !light_pt || !t_table || (!min_dist && !pre_only))
         return GCFR_ERR_INVALID_ARGUMENT;
     if (B <= 0 || L <= 0 || N <= 0 || N > 4096 || H < 2 || W < 2 || H > 4096 || W > 4096 ||
@@ -1050,7 +1058,7 @@ extern "C" int gcfr_render_fwd(const float *light_raw, int32_t clamp_z, float cl
                                float *rendered, void *workspace, size_t workspace_bytes, void *stream,
                                const gcfr_options *opt)
 {
-    const bool pre_only = opt && opt->phase == 1;  // (gcfr_options.phase: the prepass reads depth, mask, light_raw and t_table only)
+    const bool pre_only = prepass_only(opt);  // (gcfr_options.phase: the prepass reads depth, mask, light_raw and t_table only)
     if (!light_raw || !unit_out || !light_pt_out || !workspace || (!pre_only && (!normals || !albedo || !ambient || !rendered)))
         return GCFR_ERR_INVALID_ARGUMENT;
     if (B <= 0 || L <= 0)
@@ -1087,7 +1095,7 @@ extern "C" int gcfr_render_from_depth_fwd(const float *light_raw, int32_t clamp_
                                           float *final_shading, float *rendered, void *workspace,
                                           size_t workspace_bytes, void *stream, const gcfr_options *opt)
 {
-    const bool pre_only = opt && opt->phase == 1;
+    const bool pre_only = prepass_only(opt);
     if (!light_raw || !unit_out || !light_pt_out || !workspace || (!pre_only && (!albedo || !ambient || !rendered)) ||
         B <= 0 || L <= 0 || fx == 0.0 || fy == 0.0)
         return GCFR_ERR_INVALID_ARGUMENT;

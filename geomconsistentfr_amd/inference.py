@@ -43,29 +43,36 @@ def camera_matrix(focal: float, H: int = 256, W: int = 256, device="cpu") -> tor
     return K.to(device)
 
 
+def _is_transfer(model) -> bool:
+    return isinstance(model, RelightNetLightingTransfer)
+
+
 def _as_batch(images) -> torch.Tensor:
     x = images.to(torch.float32) if torch.is_tensor(images) else torch.as_tensor(np.asarray(images), dtype=torch.float32)
     return x[None] if x.dim() == 3 else x
 
 
 @torch.no_grad()
-def relight_batch(model: RelightNetSingleImage, images, masks_u8, lights, ambient: float = 0.5,
-                  focal: float = 1570.0, device="cuda", epoch: int = 200):
+def relight_batch(model, images, masks_u8, lights, ambient: float = 0.5,
+                  focal: float = None, device="cuda", epoch: int = 200):
     """images (B,H,W,3) float [0,1]; masks_u8 (H,W) shared skin mask (the S1/S8 model takes ONE mask per
-    forward, S1:488) ; lights (B,3) target directions.  The lighting head's first output is the ambient the
-    model uses (plus the model's ambient_offset); `ambient` only feeds the unused target argument, as in S1:588.
-    Returns the model's 10-tuple (device tensors)."""
+    forward, S1:488) ; lights (B,3) target directions.  RelightNetSingleImage: the lighting head's first output is the ambient
+    the model uses (plus the model's ambient_offset); `ambient` only feeds the unused target argument, as in S1:588 (focal
+    1570).  RelightNetLightingTransfer: `ambient` IS the target ambient (SLT:545; focal 700).
+    Returns the model's 10- / 12-tuple (device tensors)."""
     x = _as_batch(images).to(device)
     B, H, W, _ = x.shape
     mask = torch.as_tensor(np.asarray(masks_u8), dtype=torch.float64).reshape(H, W, 1) / 255.0     # S1:580
     tl = torch.as_tensor(np.asarray(lights), dtype=torch.float32).reshape(B, 3, 1, 1).to(device)
     ta = torch.full((B, 1, 1), float(ambient), dtype=torch.float32, device=device)
-    return model(x, epoch, camera_matrix(focal, H, W, device), mask.to(device), tl, ta, mask[None].to(device))
+    if _is_transfer(model):
+        return model(x, epoch, camera_matrix(700.0 if focal is None else focal, H, W, device), mask.to(device), tl, ta)
+    return model(x, epoch, camera_matrix(1570.0 if focal is None else focal, H, W, device), mask.to(device), tl, ta, mask[None].to(device))
 
 
 @torch.no_grad()
-def relight_single_image(model: RelightNetSingleImage, image, mask_u8, light, ambient: float = 0.5,
-                         focal: float = 1570.0, device="cuda", fix_border: bool = False,
+def relight_single_image(model, image, mask_u8, light, ambient: float = 0.5,
+                         focal: float = None, device="cuda", fix_border: bool = False,
                          composite_mask_u8=None) -> np.ndarray:
     """S1:569-620 for one image: returns the composite (H,W,3) uint8 RGB (rendered face pasted into the input),
     composited and quantised on the device (gcfr_inference_images_u8); `fix_border=True` also applies
@@ -75,7 +82,7 @@ def relight_single_image(model: RelightNetSingleImage, image, mask_u8, light, am
 
 
 @torch.no_grad()
-def relight_images(model: RelightNetSingleImage, images, mask_u8, lights, ambient: float = 0.5, focal: float = 1570.0,
+def relight_images(model, images, mask_u8, lights, ambient: float = 0.5, focal: float = None,
                    device="cuda", fix_border: bool = False, composite_mask_u8=None) -> np.ndarray:
     """Batch form of S1:569-620 (+ the MATLAB border fix): (B,H,W,3) uint8 RGB composites.  Forward, compositing,
     quantisation and the border fix all run on the device; one device-to-host copy of B*H*W*3 bytes at the end.
@@ -86,10 +93,46 @@ def relight_images(model: RelightNetSingleImage, images, mask_u8, lights, ambien
     out = relight_batch(model, x, mask_u8, lights, ambient, focal, device)
     mask = torch.as_tensor(np.asarray(mask_u8 if composite_mask_u8 is None else composite_mask_u8), dtype=torch.uint8,
                            device=device)
-    imgs = pp.inference_images_device(x, out[5], mask)["rendered_image"]
+    imgs = pp.inference_images_device(x, out[5], mask, mask_f32=_is_transfer(model))["rendered_image"]
     if fix_border:
         imgs = pp.fix_border_artifacts_device(imgs, mask)
     return imgs.cpu().numpy()
+
+
+@torch.no_grad()
+def relight_lights_device(model, images, mask_u8, lights, ambient: float = 0.5, focal: float = None, device="cuda",
+                          fix_border: bool = False, composite_mask_u8=None, epoch: int = 200) -> torch.Tensor:
+    """`relight_lights` up to the bytes ON THE DEVICE: (B,L,H,W,3) uint8 tensor, nothing copied back.  `images` / `mask_u8` /
+    `lights` may already be device tensors (then nothing is uploaded either): what bench.py's `relight_e2e` leg times."""
+    x = _as_batch(images).to(device)
+    B, H, W, _ = x.shape
+    transfer = _is_transfer(model)
+    K = camera_matrix((700.0 if transfer else 1570.0) if focal is None else focal, H, W, device)
+    as_u8 = lambda m: (m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m))).to(device=device, dtype=torch.uint8)
+    m_u8 = as_u8(mask_u8)
+    mask = (m_u8.to(torch.float64).reshape(H, W, 1) / 255.0)                                                     # S1:580 / SLT:540
+    lights = (lights if torch.is_tensor(lights) else torch.as_tensor(np.asarray(lights, np.float32))).to(device=device, dtype=torch.float32)
+    lights = lights.reshape(-1, 3) if lights.dim() <= 2 else lights
+    out = model.forward_lights(x, epoch, K, mask, lights, float(ambient)) if transfer else model.forward_lights(x, epoch, K, mask, lights)
+    cm = m_u8 if composite_mask_u8 is None else as_u8(composite_mask_u8)
+    imgs = pp.inference_images_device(x, out[5], cm, mask_f32=transfer)["rendered_image"]                        # (B,L,H,W,3)
+    if fix_border:
+        L = imgs.shape[1]
+        imgs = pp.fix_border_artifacts_device(imgs.reshape(B * L, H, W, 3), cm).reshape(B, L, H, W, 3)
+    return imgs
+
+
+@torch.no_grad()
+def relight_lights(model, images, mask_u8, lights, ambient: float = 0.5, focal: float = None, device="cuda",
+                   fix_border: bool = False, composite_mask_u8=None, epoch: int = 200) -> np.ndarray:
+    """Every face of `images` (B,H,W,3) under every one of `lights` (L,3) -- e.g. the eleven directions the reference ships
+    (LIGHT_DIRECTIONS, S1:519-562) -- as (B,L,H,W,3) uint8 RGB composites.  ONE network pass, one prepass and one normals
+    stage per face, L marches, one image-kernel launch over all B*L composites: the scripts run the whole model once per
+    (face, light) (S1:582-620).  `model`: a RelightNetSingleImage (the lighting head's ambient + the model's offset, S1:342;
+    focal 1570) or a RelightNetLightingTransfer (`ambient` is the target ambient, SLT:545; focal 700).  Composite [b, l]
+    equals relight_images(model, images[b:b+1], mask_u8, lights[l:l+1]) given the same network outputs.  One device-to-host
+    copy of B*L*H*W*3 bytes at the end (`relight_lights_device` stops before it)."""
+    return relight_lights_device(model, images, mask_u8, lights, ambient, focal, device, fix_border, composite_mask_u8, epoch).cpu().numpy()
 
 
 @torch.no_grad()

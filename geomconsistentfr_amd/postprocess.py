@@ -23,7 +23,10 @@ def inference_images_device(input_images, rendered, mask_u8, albedo=None, depth=
     forward's device outputs: `rendered_image` always, the five diagnostic maps for whichever inputs are given.
     input_images (B,H,W,3) f32 in [0,1]; rendered / albedo / surface_normals (B,3,H,W); depth (B,1,H,W) or (B,H,W);
     shadow_mask_weights / final_shading (B,H,W); mask_u8 (1|B,H,W) or (H,W) uint8 skin mask as stored on disk (the kernel
-    forms the scripts' mask/255.0 itself: f64 as S1:580 / S8:569 hold it, or with mask_f32=True f32 as SLT:540 does)."""
+    forms the scripts' mask/255.0 itself: f64 as S1:580 / S8:569 hold it, or with mask_f32=True f32 as SLT:540 does).
+    Many lights per face: rendered (B,L,3,H,W) (and shadow_mask_weights / final_shading (B,L,H,W)) give `rendered_image`
+    (B,L,H,W,3) (`shadow_mask` / `shading` (B,L,H,W)) from ONE launch that reads each photograph once per light in place --
+    no L-fold copy of the input; the per-photograph maps (albedo, depth, normals) keep their (B,...) shapes."""
     import torch
     from . import _lib
     L_ = _lib.load()
@@ -33,6 +36,11 @@ def inference_images_device(input_images, rendered, mask_u8, albedo=None, depth=
     f = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
     x, rendered = f(x), f(rendered)
     B, H, W, _ = x.shape
+    multi = rendered.dim() == 5
+    L = rendered.shape[1] if multi else 1
+    lead = (B, L) if multi else (B,)
+    if tuple(rendered.shape) != lead + (3, H, W):
+        raise _lib.GcfrError("rendered must be (B,3,H,W) or (B,L,3,H,W) for input images %s; got %s" % (tuple(x.shape), tuple(rendered.shape)))
     if mask_u8.dtype != torch.uint8:
         raise _lib.GcfrError("mask_u8 must be the uint8 skin mask (0..255)")
     m = mask_u8.to(x.device).contiguous().reshape(-1, H, W)
@@ -43,22 +51,22 @@ def inference_images_device(input_images, rendered, mask_u8, albedo=None, depth=
         neg = -depth
         drange = torch.stack([neg.amin(), neg.amax()]).contiguous()              # stays on the device: no sync
     u8 = lambda *shape: torch.empty(shape, dtype=torch.uint8, device=x.device)
-    out = {"rendered_image": u8(B, H, W, 3)}
+    out = {"rendered_image": u8(*lead, H, W, 3)}
     if shadow_mask_weights is not None:
-        out["shadow_mask"] = u8(B, H, W)
+        out["shadow_mask"] = u8(*lead, H, W)
     if albedo is not None:
         out["albedo"] = u8(B, H, W, 3)
     if depth is not None:
         out["depth"] = u8(B, H, W)
     if final_shading is not None:
-        out["shading"] = u8(B, H, W)
+        out["shading"] = u8(*lead, H, W)
     if surface_normals is not None:
         out["surface_normals"] = u8(B, H, W, 3)
     p = lambda t: None if t is None else t.data_ptr()
     with torch.cuda.device(x.device):
         _lib.check(L_.gcfr_inference_images_u8(
             x.data_ptr(), rendered.data_ptr(), p(albedo), p(depth), p(drange), p(shadow_mask_weights), p(final_shading),
-            p(surface_normals), m.data_ptr(), m.shape[0], B, H, W, out["rendered_image"].data_ptr(), p(out.get("shadow_mask")),
+            p(surface_normals), m.data_ptr(), m.shape[0], B, L, H, W, out["rendered_image"].data_ptr(), p(out.get("shadow_mask")),
             p(out.get("albedo")), p(out.get("depth")), p(out.get("shading")), p(out.get("surface_normals")), int(bool(mask_f32)),
             torch.cuda.current_stream(x.device).cuda_stream), "gcfr_inference_images_u8")
     return out

@@ -115,6 +115,31 @@ class _Hourglass(nn.Module):
     def _camera(self, intrinsic_matrix):
         return self._pinned_camera if self._pinned_camera is not None else intrinsic_matrix
 
+    def render_lights(self, img, epoch, intrinsic_matrix, mask, lights, ambient_of):
+        """MANY target lights per face from ONE network pass: features() once, one prepass (on the side stream, under the
+        albedo decoder), one normals stage, L marches -- where the reference's scripts re-run the whole model per light
+        (S1:582-588 inside the loop over the light directions).  lights (L,3) shared by the batch, or (B,L,3);
+        `ambient_of(SL, B, L)` -> (B,L) ambient values.  Returns (albedo, depth, SL, lights (B,L,3), render dict with a light axis)."""
+        cam = self._camera(intrinsic_matrix)
+        B, H, W, _ = img.shape
+        lights = torch.as_tensor(lights, dtype=torch.float32, device=img.device)
+        if lights.dim() == 2:
+            lights = lights[None].expand(B, -1, 3)
+        lights = lights.reshape(B, -1, 3).contiguous()
+        L = lights.shape[1]
+        m1 = mask.reshape(1, H, W)
+        early = []
+
+        def on_depth(depth, SL):
+            early.append(render_from_depth_prepass(depth, lights, cam, m1, self.render_params))
+
+        albedo, depth, SL = self.features(img, epoch, on_depth if (self.hoist_prepass and img.is_cuda) else None)
+        r = render_from_depth(depth, albedo, lights, ambient_of(SL, B, L), cam, self.normal_z_offset, m1, self.render_params,
+                              prepared=early[0] if early else None)
+        return albedo, depth, SL, lights, r
+
+    hoist_prepass = True   # the render block's prepass on a side stream, under the albedo decoder (block.render_prepass)
+
     def features(self, img_nhwc, epoch, on_depth=None):
         """-> (albedo (B,3,H,W) in (0,1), depth (B,1,H,W) x100, SL_lin2 (B,1,1,4)).  T8:197-350.
         The DEPTH decoder runs first (the reference runs the albedo decoder first, T8:290 then T8:350; the two are independent
@@ -155,8 +180,6 @@ class RelightNet(_Hourglass):
         self.render_params = params or RenderParams.training()
         self.normal_z_offset = normal_z_offset                                          # T8:353
 
-    hoist_prepass = True   # the render block's prepass on a side stream, under the albedo decoder (block.render_prepass)
-
     def forward(self, img, epoch, intrinsic_matrix, masks):
         cam = self._camera(intrinsic_matrix)
         m3 = masks.reshape(masks.shape[0], masks.shape[1], masks.shape[2])
@@ -195,6 +218,18 @@ class RelightNetSingleImage(_Hourglass):
                 r["rendered_images"], r["unit_light_direction"], r["ambient_values"], r["final_shading"],
                 F.normalize(normals, p=2, dim=1))                                        # S1:505
 
+    def forward_lights(self, img, epoch, intrinsic_matrix, mask, target_lightings):
+        """`forward` for L target lights per face at once: target_lightings (L,3) (shared by the batch) or (B,L,3).  The same
+        10-tuple with a light axis behind the batch axis on every per-light entry: shadow_mask_weights / ambient_light /
+        full_shading / final_shading (B,L,H,W), rendered_images (B,L,3,H,W), unit_light_direction (B,L,3,1,1),
+        ambient_values (B,L,1,1); albedo, depth and the normals are per face.  Entry [:, l] equals `forward` with light l
+        (bit for bit given the same network outputs: tests/test_gpu_relight_lights.py)."""
+        amb_of = lambda SL, B, L: (SL[:, 0, 0, 0] + self.ambient_offset)[:, None].expand(B, L)       # S1:342, every light
+        albedo, depth, SL, _, r = self.render_lights(img, epoch, intrinsic_matrix, mask, target_lightings, amb_of)
+        return (albedo, depth, r["shadow_mask_weights"], r["ambient_light"], r["full_shading"],
+                r["rendered_images"], r["unit_light_direction"], r["ambient_values"], r["final_shading"],
+                F.normalize(r["surface_normals"], p=2, dim=1))
+
 
 class RelightNetLightingTransfer(_Hourglass):
     """Lighting-transfer inference form (test_relight_single_image_lighting_transfer.py)."""
@@ -218,6 +253,21 @@ class RelightNetLightingTransfer(_Hourglass):
         return (albedo, depth, r["shadow_mask_weights"], r["ambient_light"], r["full_shading"],
                 r["rendered_images"], r["unit_light_direction"], r["ambient_values"], r["final_shading"],
                 F.normalize(normals, p=2, dim=1), est_unit, SL[:, :, :, 0])              # SLT:514
+
+    def forward_lights(self, img, epoch, intrinsic_matrix, mask, target_lightings, target_ambient_values):
+        """`forward` for L target lights per face at once (see RelightNetSingleImage.forward_lights): target_lightings (L,3) or
+        (B,L,3); target_ambient_values a scalar, (L,) or (B,L).  The same 12-tuple with a light axis on the per-light entries."""
+        def amb_of(SL, B, L):
+            a = torch.as_tensor(target_ambient_values, dtype=torch.float32, device=SL.device)
+            return (a.reshape(1, -1) if a.numel() in (1, L) else a.reshape(B, L)).expand(B, L)
+        albedo, depth, SL, _, r = self.render_lights(img, epoch, intrinsic_matrix, mask, target_lightings, amb_of)
+        B = depth.shape[0]
+        est = SL[:, 0, 0, 1:4]
+        est = torch.stack([est[:, 0], est[:, 1], torch.clamp_min(est[:, 2], self.estimate_z_min)], 1)
+        est_unit = F.normalize(est, p=2, dim=1).reshape(B, 3, 1, 1)                     # SLT:329-335
+        return (albedo, depth, r["shadow_mask_weights"], r["ambient_light"], r["full_shading"],
+                r["rendered_images"], r["unit_light_direction"], r["ambient_values"], r["final_shading"],
+                F.normalize(r["surface_normals"], p=2, dim=1), est_unit, SL[:, :, :, 0])
 
 
 class PatchGAN(nn.Module):

@@ -47,8 +47,13 @@ const char *gcfr_version(void);
  *   3: round 3 -- gcfr_inference_images_u8 gained `mask_f32`; gcfr_abi_version itself; the metrics entry points.
  *   4: round 4 -- gcfr_options gained `pixels`.
  *   5: round 5 -- gcfr_options gained `phase` (the prepass as its own enqueue); gcfr_copy_probe.
+ *   6: round 6 -- gcfr_options lost the dead `schedule` / `tile_order` fields (sizeof 64 -> 56: `phase` had gone into what
+ *      was tail padding, so revision 5's struct_size could not tell a revision-4 caller from a revision-5 one -- this one
+ *      can); gcfr_inference_images_u8 gained `L` (relit images per photograph: many lights per face).
+ * struct_size guards the struct's SIZE only: a field added into padding does not change it.  The revision check is
+ * therefore mandatory for every binding, and every entry point validates struct_size before it reads any other field.
  */
-#define GCFR_ABI_VERSION 5
+#define GCFR_ABI_VERSION 6
 int32_t gcfr_abi_version(void);
 
 /*
@@ -63,12 +68,6 @@ typedef struct gcfr_options {
     int32_t group;             /* samples per skip group: 1, 2 or 4; 0 = auto (4) */
     int32_t ksplit;            /* split each tile's sample range over the 4 waves of a workgroup: 0, 1, -1 = auto by launch size */
     int32_t depth_bound_skip;  /* exact depth-bound group skip: 0, 1, -1 = auto (on) */
-    int32_t schedule;          /* how tiles reach waves: 0 (= -1, auto) the 3-D grid, one workgroup per four adjacent tiles,
-                                  image-major -- the only schedule.  Round 2 measured six alternatives (values 1 ... 6:
-                                  persistent waves, ordered grids, cooperating waves, work stealing, helping across the
-                                  chip; profiles/r02_schedule_experiments.md), all bit-identical and all slower; their code
-                                  left the library in round 3 and any other value is GCFR_ERR_INVALID_ARGUMENT */
-    int32_t tile_order;        /* 0 or -1 (it ordered the queues of the removed schedules; kept for the struct layout) */
     int32_t lds_stage;         /* the march's workgroups copy their image's mask (as a bitmap) and depth-bounds records into
                                   LDS and read them there instead of gathering them through the texture path: 0 off, 1 on
                                   (wherever the shape allows: W % 32 == 0, 26 KiB per workgroup, default tile and group),
@@ -313,9 +312,12 @@ int gcfr_light_prep_bwd(const float *light_raw, int32_t n, int32_t clamp_z, floa
  * (round half to even, clip to [0, 255]); RGB, HWC -- the bytes that end up in the PNG.
  * Replaces test_relight_single_image.py:601-620 (rendered image only) and
  * test_raytracing_relighting_CelebAHQ_DSSIM_8x.py:583-608 / ..._lighting_transfer.py:560-579 (all six).
+ * B photographs, L relit images per photograph (L = 1: the scripts' one target light per forward, S1:582-588; L > 1: the
+ * many-lights forward, all L composites of a face from ONE network pass -- the scripts re-run the model per light):
  *   input_hwc     (B,H,W,3) f32 in [0,1]   the photograph, as the scripts hold it (training_images)
- *   rendered      (B,3,H,W) f32            rendered_images                   -> out_rendered (B,H,W,3): the relit face
+ *   rendered      (B,L,3,H,W) f32          rendered_images                   -> out_rendered (B,L,H,W,3): the relit face
  *                                          pasted into the photograph where mask > 0
+ *   (albedo, depth, normals and their outputs are per photograph, (B,...); shadow_w / final_shading and theirs (B,L,H,W))
  *   albedo        (B,3,H,W) f32 or NULL    -> out_albedo  (B,H,W,3) = 255 albedo mask
  *   depth         (B,H,W) f32 or NULL      -> out_depth   (B,H,W)   = 255 (-depth - lo)/(hi - lo) mask, with
  *   depth_range   DEVICE {lo, hi} f32      = min / max of -depth over the whole batch (S8:589-590)
@@ -331,8 +333,8 @@ int gcfr_light_prep_bwd(const float *light_raw, int32_t n, int32_t clamp_z, floa
  */
 int gcfr_inference_images_u8(const float *input_hwc, const float *rendered, const float *albedo, const float *depth,
                              const float *depth_range, const float *shadow_w, const float *final_shading,
-                             const float *normals, const uint8_t *mask, int32_t mask_batch, int32_t B, int32_t H,
-                             int32_t W, uint8_t *out_rendered, uint8_t *out_shadow, uint8_t *out_albedo,
+                             const float *normals, const uint8_t *mask, int32_t mask_batch, int32_t B, int32_t L,
+                             int32_t H, int32_t W, uint8_t *out_rendered, uint8_t *out_shadow, uint8_t *out_albedo,
                              uint8_t *out_depth, uint8_t *out_shading, uint8_t *out_normals, int32_t mask_f32,
                              void *stream);
 

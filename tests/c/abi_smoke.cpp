@@ -117,14 +117,13 @@ int main()
         return 1;
     }
     // (1) one call
-    // per-call options: explicit knobs (the grid schedule, LDS staging of the mask / bounds records; the NULL-options calls
+    // per-call options: explicit knobs (LDS staging of the mask / bounds records; the NULL-options calls
     // below use the defaults) and an event pair the library records around the march kernel
     gcfr_options opt;
     gcfr_options_default(&opt);
     hipEvent_t ev0, ev1;
     CK(hipEventCreate(&ev0));
     CK(hipEventCreate(&ev1));
-    opt.schedule = 0;
     opt.lds_stage = 1;   // (bit-identical by contract: the three-call forward below runs with the defaults and must agree)
     opt.event_start = ev0;
     opt.event_stop = ev1;

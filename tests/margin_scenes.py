@@ -566,3 +566,45 @@ def family_wrap_edge(seed, H=256, W=256, B=12):
 
 
 FAMILIES["wrap_edge"] = family_wrap_edge
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# W2 the wrap partner DECIDES results and late samples win (tests/test_gpu_horizon.py::test_rays_running_along_column_zero...,
+#    round 6: into the audit's list).  The light point's x is the image's left edge EXACTLY (C_x = -W/2: the reference's nine-way
+#    branch still treats it as "inside", T8:404), so the rays of column 0 climb straight up that column with u_x = -1e-4 at every
+#    sample and read column W-1 as their left bilinear corner with weight 1e-4 (index -1 wraps, T8:488-491).  Column W-1 is masked
+#    out and holds a wall that RAMPS with the height a climbing ray has gained (1e-4 x wall ~ the ray's own height: the blended
+#    surface stays near the ray, so the minima of column 0 sit at LATE samples, inside the trailing loop's reach).  A horizon
+#    table that leaves the wrap partner out (mutant 13) or a dilation that does not wrap (mutant 14) puts the cap below that wall:
+#    the termination's claim `S_k >= 0.998 g^2` is then false for samples that were never evaluated -- what tools/audit.py counts.
+#    seed % 2: the left edge (columns) / the top edge (rows: C_y = H/2, rays running along row 0 read row H-1).
+# ---------------------------------------------------------------------------------------------------------------------------
+def family_wrap_column(seed, H=256, W=256, B=4):
+    rng = np.random.default_rng(29000 + seed)
+    _, _, r, c = grids(H, W)
+    top = seed % 2 == 1
+    dirs = [(0.8, 0.6), (0.9, 0.43), (0.6, 0.8), (0.95, 0.3)][:B]
+    pts, depth = [], []
+    mask = np.zeros((B, H, W), np.uint8)
+    for b, (along, lz) in enumerate(dirs):
+        along, lz = along + 0.03 * rng.standard_normal(), lz + 0.03 * rng.standard_normal()
+        n = np.hypot(along, lz)
+        R = 4013.0
+        far, up = R * along / n, R * abs(lz) / n
+        d = (8.0 + 3.0 * np.sin(r / 17.0) * np.cos(c / 13.0) + 0.2 * rng.random((H, W))).astype(f32)
+        slope = up / far                                     # height gained per pixel travelled along the edge
+        if not top:                                          # light at x = -W/2 exactly, above the image: rays of column 0 climb the rows
+            pts.append([-(W / 2.0), far, up])
+            mask[b, :, :64] = 1                              # touches column 0, nowhere near column W-1
+            gained = 0.5 * slope * np.arange(H)[::-1]        # half the height a ray from the bottom row has gained at that row
+            d[2:200, W - 1] = (1e4 * (10.0 + gained))[2:200].astype(f32)
+        else:                                                # light at y = H/2 exactly, to the right: rays of row 0 run along the columns
+            pts.append([far, H / 2.0, up])
+            mask[b, :64, :] = 1                              # touches row 0, nowhere near row H-1
+            gained = 0.5 * slope * np.arange(W)
+            d[H - 1, 2:200] = (1e4 * (10.0 + gained))[2:200].astype(f32)
+        depth.append(d)
+    return dict(depth=np.stack(depth), mask=mask, light_pt=np.array(pts, f32)[:, None, :], t_table=table(), pixels_mask=False)
+
+
+FAMILIES["wrap_column"] = family_wrap_column

@@ -47,10 +47,11 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert L.gcfr_light_prep(None, 1, 1, 0.0, 4013.0, None, None, None) == -1
     assert L.gcfr_shade_fwd(None, None, None, None, None, None, 1, 1, 8, 8, 0.5, None, None, None, None, None) == -1
     # the inference image side: null planes, a diagnostic output without its input, mask batch neither 1 nor B, in-place border fix
-    assert L.gcfr_inference_images_u8(None, None, None, None, None, None, None, None, None, 1, 1, 8, 8, None, None, None, None, None, None, 0, None) == -1
-    assert L.gcfr_inference_images_u8(16, 16, None, None, None, None, None, None, 16, 1, 1, 8, 8, 16, 16, None, None, None, None, 0, None) == -1
-    assert L.gcfr_inference_images_u8(16, 16, None, None, None, None, None, None, 16, 2, 3, 8, 8, 16, None, None, None, None, None, 0, None) == -1
-    assert L.gcfr_inference_images_u8(16, 16, None, None, None, None, None, None, 16, 1, 1, 8, 8, 16, None, None, None, None, None, 2, None) == -1
+    assert L.gcfr_inference_images_u8(None, None, None, None, None, None, None, None, None, 1, 1, 1, 8, 8, None, None, None, None, None, None, 0, None) == -1
+    assert L.gcfr_inference_images_u8(16, 16, None, None, None, None, None, None, 16, 1, 1, 1, 8, 8, 16, 16, None, None, None, None, 0, None) == -1
+    assert L.gcfr_inference_images_u8(16, 16, None, None, None, None, None, None, 16, 2, 3, 1, 8, 8, 16, None, None, None, None, None, 0, None) == -1
+    assert L.gcfr_inference_images_u8(16, 16, None, None, None, None, None, None, 16, 1, 1, 1, 8, 8, 16, None, None, None, None, None, 2, None) == -1
+    assert L.gcfr_inference_images_u8(16, 16, None, None, None, None, None, None, 16, 1, 1, 0, 8, 8, 16, None, None, None, None, None, 0, None) == -1   # L = 0
     assert L.gcfr_fix_border_u8(16, 16, 1, 1, 8, 8, 16, None) == -1
 
 
@@ -62,8 +63,8 @@ def test_options_struct_defaults_and_layout():
     L = _lib.load()
     o = _lib.Options()
     L.gcfr_options_default(ctypes.byref(o))
-    assert o.struct_size == ctypes.sizeof(_lib.Options) == 64
-    assert (o.tile_w, o.group, o.ksplit, o.depth_bound_skip, o.schedule, o.tile_order, o.lds_stage) == (0, 0, -1, -1, -1, -1, -1)
+    assert o.struct_size == ctypes.sizeof(_lib.Options) == 56      # ABI 6 (64 at revisions 4 and 5: they are refused, below)
+    assert (o.tile_w, o.group, o.ksplit, o.depth_bound_skip, o.lds_stage) == (0, 0, -1, -1, -1)
     assert o.pixels == 0                 # the one result-changing knob is off unless asked for
     assert not o.event_start and not o.event_stop and not o.counters
     # argument validation happens on the host before any launch, so it can be exercised without a GPU: dummy non-null
@@ -75,10 +76,17 @@ def test_options_struct_defaults_and_layout():
     bad = _lib.options()
     bad.struct_size = 8
     assert L.gcfr_shadow_fwd(*args, ctypes.byref(bad)) == -1
-    bad = _lib.options(schedule=7)
-    assert L.gcfr_shadow_fwd(*args, ctypes.byref(bad)) == -1
-    assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(schedule=2))) == -1      # the grid is the only schedule
-    assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(tile_order=2))) == -1
+    # a caller built against revision 4 / 5 of the struct (64 bytes, `schedule` / `tile_order` in front of `lds_stage`): its
+    # struct_size is refused BEFORE any other field is read -- also a `phase` of 1 at the old offset is never interpreted
+    # (round-5 advisor finding: `opt->phase` was read ahead of the size check)
+    class OldOptions(ctypes.Structure):
+        _fields_ = [("struct_size", ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in ("tile_w", "group", "ksplit", "depth_bound_skip",
+                    "schedule", "tile_order", "lds_stage")] + [(n, ctypes.c_void_p) for n in ("event_start", "event_stop", "counters")] + \
+                   [("pixels", ctypes.c_int32), ("phase", ctypes.c_int32)]
+    old = OldOptions(struct_size=64, ksplit=-1, depth_bound_skip=-1, schedule=-1, tile_order=-1, lds_stage=-1, phase=1)
+    assert ctypes.sizeof(OldOptions) == 64
+    ws_args = args[:14] + (dummy, 1 << 30, None)
+    assert L.gcfr_shadow_fwd(*ws_args, ctypes.byref(old)) == -1
     assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(pixels=2))) == -1
     # pixels = mask lives in the workspace path's argmin march: refused (not ignored) without a workspace or without argmin
     assert L.gcfr_shadow_fwd(*args, ctypes.byref(_lib.options(pixels=1))) == -1

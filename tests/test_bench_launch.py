@@ -51,11 +51,26 @@ def test_gpus8_dry_run_keeps_the_books_of_configs3(workload):
     assert d["parallelism"] == "dp8"
 
 
+def test_gpus8_dry_run_at_configs4_shape_keeps_every_light_of_a_face_on_one_rank():
+    """BASELINE configs[4] (512 x 512 faces, 18 light directions per image, 320 march steps, 8 GPUs): one face per rank, all 18
+    lights of that face on its rank (no light is split across ranks, no data-path collective) -- the launch line the driver would use
+    on an 8-GPU node is `python3 bench.py --gpus 8 --size 512 --lights 18 --samples 320 --faces 1`."""
+    p = _run(["--gpus", "8", "--dry-run", "--size", "512", "--lights", "18", "--samples", "320", "--faces", "1"], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 8 and d["ranks"] == 8 and d["ranks_seen"] == [float(r) for r in range(8)]
+    assert d["faces_per_rank"] == 1 and d["global_batch"] == 8 and d["lights_per_face"] == 18
+    assert d["face_lights_per_rank"] == 18 and d["lights_split_across_ranks"] is False
+    assert d["nominal_ray_steps_per_step"] == 8 * 18 * 512 * 512 * 320
+    assert d["relight_e2e_leg_runs"] is False                      # the end-to-end leg belongs to the 1-GPU headline line
+
+
 def test_single_rank_needs_no_launcher():
     p = _run(["--dry-run"])
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["self_launched"] is False
+    assert d["relight_e2e_leg_runs"] is True and d["lights_per_face"] == 1
 
 
 def test_without_a_gpu_the_real_command_fails_loudly():

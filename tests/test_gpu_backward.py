@@ -244,50 +244,55 @@ def test_fused_backward_equals_three_kernel_backward():
         assert np.abs(a - b).max() <= 2e-6 * scale, (name, np.abs(a - b).max(), scale)
 
 
-def test_fused_backward_multi_light_equals_sum_of_single_lights():
-    """gcfr_render_bwd with L=2 lights per image (C ABI called directly) == the sum of two L=1 autograd runs."""
-    from geomconsistentfr_amd import RenderParams, _lib
+@pytest.mark.parametrize("path", ["from_depth", "three_kernel"])
+def test_multi_light_backward_equals_sum_of_single_lights(path):
+    """Many lights per face through the PUBLIC differentiable entries -- `render_from_depth(light (B,L,3), ambient (B,L))`
+    (one fused backward launch, gcfr_render_bwd with L lights) and `render(...)` with explicit normals (shade_bwd -> shadow_bwd)
+    -- against L runs of the one-light form: forward tensors bit-equal per light, gradients of depth / albedo the sum over the
+    lights, gradients of each light / ambient its own."""
+    from geomconsistentfr_amd import RenderParams, render
     from geomconsistentfr_amd import block as R
-    L_ = _lib.load()
+    from geomconsistentfr_amd.normals import depth_to_normals
     rng = np.random.default_rng(33)
-    B, L, Hs, Ws = 2, 2, 48, 64
+    B, L, Hs, Ws = 2, 3, 48, 64
     d = dev()
-    depth = torch.from_numpy((20 * rng.random((B, Hs, Ws))).astype(np.float32)).to(d)
+    depth = (20 * rng.random((B, 1, Hs, Ws))).astype(np.float32)
     mask = torch.from_numpy((rng.random((B, Hs, Ws)) > 0.2).astype(np.uint8)).to(d)
-    albedo = torch.from_numpy(rng.random((B, 3, Hs, Ws), dtype=np.float32)).to(d)
-    light = torch.from_numpy(rng.standard_normal((B, L, 3)).astype(np.float32)).to(d)
-    amb = torch.from_numpy((0.3 + 0.4 * rng.random((B, L))).astype(np.float32)).to(d)
+    albedo = rng.random((B, 3, Hs, Ws), dtype=np.float32)
+    light = rng.standard_normal((B, L, 3)).astype(np.float32)
+    amb = (0.3 + 0.4 * rng.random((B, L))).astype(np.float32)
     G = torch.from_numpy(rng.standard_normal((B, L, 3, Hs, Ws)).astype(np.float32)).to(d)
+    Gw = torch.from_numpy(rng.standard_normal((B, L, Hs, Ws)).astype(np.float32)).to(d)
+    Gu = torch.from_numpy(rng.standard_normal((B, L, 3, 1, 1)).astype(np.float32)).to(d)
     prm = RenderParams(n_samples=40, dt=0.02)
-    cam = (700.0, 700.0, Ws / 2.0, Hs / 2.0, 500.0)
     K = camera(700.0, Hs, Ws).to(d)
-    # multi-light forward + one fused backward launch through the C ABI
-    o = R.render_fwd(depth, mask, light, amb, None, albedo, prm, want_argmin=True, camera=cam)
-    g_alb = torch.empty_like(albedo)
-    g_depth = torch.zeros_like(depth)
-    g_pt = torch.zeros((B, L, 3), dtype=torch.float64, device=d)
-    g_amb = torch.zeros((B, L), dtype=torch.float64, device=d)
-    tt = R.sample_table(prm, d)
-    _lib.check(L_.gcfr_render_bwd(depth.data_ptr(), albedo.data_ptr(), o["light_pt"].data_ptr(), amb.data_ptr(),
-                                  o["minimum_distance"].data_ptr(), o["argmin"].data_ptr(), None, B, L, Hs, Ws, prm.n_samples,
-                                  tt.data_ptr(), *cam[:4], cam[4], 1, 0.5, None, None, None, G.data_ptr(), None,
-                                  g_alb.data_ptr(), g_depth.data_ptr(), g_pt.data_ptr(), g_amb.data_ptr(),
-                                  torch.cuda.current_stream().cuda_stream), "gcfr_render_bwd")
-    torch.cuda.synchronize()
-    # reference: one autograd run per light, summed
-    sum_alb, sum_depth = torch.zeros_like(albedo), torch.zeros_like(depth)
+
+    def run(dl, al, li, am):
+        if path == "from_depth":
+            return R.render_from_depth(dl, al, li, am, K, 500.0, mask, prm)
+        return render(dl, al, li, am, depth_to_normals(dl, K, z_offset=500.0), mask, prm)
+
+    leaves = [_leaf(a) for a in (depth, albedo, light, amb)]
+    o = run(*leaves)
+    assert tuple(o["rendered_images"].shape) == (B, L, 3, Hs, Ws) and tuple(o["shadow_mask_weights"].shape) == (B, L, Hs, Ws)
+    assert tuple(o["unit_light_direction"].shape) == (B, L, 3, 1, 1) and tuple(o["ambient_values"].shape) == (B, L, 1, 1)
+    ((o["rendered_images"] * G).sum() + (o["shadow_mask_weights"] * Gw).sum() + (o["unit_light_direction"] * Gu).sum()).backward()
+    sum_alb, sum_depth = torch.zeros_like(leaves[1]), torch.zeros_like(leaves[0])
     for l in range(L):
-        dl = depth[:, None].clone().requires_grad_()
-        al = albedo.clone().requires_grad_()
-        li = light[:, l].clone().requires_grad_()
-        am = amb[:, l].clone().requires_grad_()
-        r = R.render_from_depth(dl, al, li, am, K, cam[4], mask, prm)
-        (r["rendered_images"] * G[:, l]).sum().backward()
-        sum_alb += al.grad
-        sum_depth += dl.grad[:, 0]
-        np.testing.assert_allclose(g_amb[:, l].cpu().numpy(), am.grad.cpu().numpy(), rtol=1e-5)
-    assert float((g_alb - sum_alb).abs().max()) <= 1e-5 * float(sum_alb.abs().max())
-    assert float((g_depth - sum_depth).abs().max()) <= 1e-5 * float(sum_depth.abs().max())
+        one = [_leaf(depth), _leaf(albedo), _leaf(light[:, l]), _leaf(amb[:, l])]
+        r = run(*one)
+        for k in ("rendered_images", "shadow_mask_weights", "full_shading", "final_shading", "minimum_distance"):
+            assert torch.equal(r[k], o[k][:, l]), (k, l)
+        assert torch.equal(r["unit_light_direction"], o["unit_light_direction"][:, l])
+        ((r["rendered_images"] * G[:, l]).sum() + (r["shadow_mask_weights"] * Gw[:, l]).sum()
+         + (r["unit_light_direction"] * Gu[:, l]).sum()).backward()
+        sum_alb += one[1].grad
+        sum_depth += one[0].grad
+        np.testing.assert_allclose(leaves[3].grad[:, l].cpu().numpy(), one[3].grad.cpu().numpy(), rtol=1e-5)
+        gl, gl1 = leaves[2].grad[:, l].cpu().numpy(), one[2].grad.cpu().numpy()
+        np.testing.assert_allclose(gl, gl1, rtol=1e-4, atol=1e-5 * np.abs(gl1).max())
+    assert float((leaves[1].grad - sum_alb).abs().max()) <= 1e-5 * float(sum_alb.abs().max())
+    assert float((leaves[0].grad - sum_depth).abs().max()) <= 1e-5 * float(sum_depth.abs().max())
 
 
 @pytest.mark.parametrize("Ws", [40, 72, 100, 24, 56, 34])
@@ -331,59 +336,39 @@ def test_fused_backward_wrapped_column_runs_at_widths_not_multiple_of_16(Ws):
 
 
 def test_config5_backward_18_lights_512_equals_eighteen_single_light_backwards():
-    """BASELINE configs[4] shape, backward: one 512 x 512 face, 18 lights, 320 samples through ONE launch of the restaged
-    multi-light kernel (gcfr_render_bwd, L = 18; round 3: per-light f32 staging, 145 VGPRs / 3 waves per SIMD instead of
-    200 / 2) against the sum of eighteen autograd runs of the single-light path, which the golden gradients of the
-    reference pin (test_fused_backward_matches_reference_autograd).  A materialised-oracle autograd at this size would
-    need ~26 GB of host memory per (face, light) -- the oracle pins the single-light kernel at sizes it can hold
+    """BASELINE configs[4] shape, backward: one 512 x 512 face, 18 lights, 320 samples through the public many-lights entry
+    (`render_from_depth` with light (1,18,3): ONE launch of the restaged multi-light kernel, gcfr_render_bwd with L = 18;
+    round 3: per-light f32 staging, 145 VGPRs / 3 waves per SIMD instead of 200 / 2) against the sum of eighteen autograd
+    runs of the one-light form, which the golden gradients of the reference pin
+    (test_fused_backward_matches_reference_autograd).  A materialised-oracle autograd at this size would need ~26 GB of
+    host memory per (face, light) -- the oracle pins the single-light kernel at sizes it can hold
     (test_backward_matches_materialised_oracle_small), this test carries that to the multi-light kernel at full size."""
-    import bench
-    from geomconsistentfr_amd import RenderParams, _lib
+    from scenes import synth_faces_sized
+    from geomconsistentfr_amd import RenderParams
     from geomconsistentfr_amd import block as R
-    L_ = _lib.load()
     d = dev()
     S, L, N = 512, 18, 320
-    depth_np, mask_np, albedo_np, _n, light_np, amb_np = bench.synth_faces_sized(1, 5, S, L)
+    depth_np, mask_np, albedo_np, _n, light_np, amb_np = synth_faces_sized(1, 5, S, L)
     rng = np.random.default_rng(55)
-    depth = torch.from_numpy(depth_np).to(d)
     mask = torch.from_numpy(mask_np).to(d)
-    albedo = torch.from_numpy(albedo_np).to(d)
-    light = torch.from_numpy(light_np).to(d)
-    amb = torch.from_numpy(amb_np).to(d)
     prm = RenderParams(n_samples=N, dt=0.8 / N)
-    cam = (3140.0, 3140.0, S / 2.0, S / 2.0, 1610.0)
+    z_off = 1610.0
     K = camera(3140.0, S, S).to(d)
     G = torch.from_numpy(rng.standard_normal((1, L, 3, S, S)).astype(np.float32)).to(d) * mask[:, None, None].float()
     Gw = torch.from_numpy(rng.standard_normal((1, L, S, S)).astype(np.float32)).to(d)
-    o = R.render_fwd(depth, mask, light, amb, None, albedo, prm, want_argmin=True, camera=cam)
-    g_alb, g_depth = torch.empty_like(albedo), torch.zeros_like(depth)
-    g_pt = torch.zeros((1, L, 3), dtype=torch.float64, device=d)
-    g_amb = torch.zeros((1, L), dtype=torch.float64, device=d)
-    tt = R.sample_table(prm, d)
-    for normals_fwd in (o["surface_normals"], None):          # the forward's normals read back / recomputed from the stencil
-        g_depth.zero_(), g_pt.zero_(), g_amb.zero_()
-        _lib.check(L_.gcfr_render_bwd(depth.data_ptr(), albedo.data_ptr(), o["light_pt"].data_ptr(), amb.data_ptr(),
-                                      o["minimum_distance"].data_ptr(), o["argmin"].data_ptr(),
-                                      None if normals_fwd is None else normals_fwd.data_ptr(), 1, L, S, S, N, tt.data_ptr(),
-                                      *cam[:4], cam[4], 1, 0.5, Gw.data_ptr(), None, None, G.data_ptr(), None, g_alb.data_ptr(),
-                                      g_depth.data_ptr(), g_pt.data_ptr(), g_amb.data_ptr(),
-                                      torch.cuda.current_stream().cuda_stream), "gcfr_render_bwd")
-        torch.cuda.synchronize()
-        if normals_fwd is not None:
-            first = (g_alb.clone(), g_depth.clone(), g_pt.clone(), g_amb.clone())
-    for a_, b_ in zip(first, (g_alb, g_depth, g_pt, g_amb)):   # both normal sources: the same numbers up to atomic order
-        assert float((a_ - b_).abs().max()) <= 2e-6 * float(a_.abs().max())
-    sum_alb, sum_depth = torch.zeros_like(albedo), torch.zeros_like(depth)
+    leaves = [_leaf(a) for a in (depth_np[:, None], albedo_np, light_np, amb_np)]
+    o = R.render_from_depth(leaves[0], leaves[1], leaves[2], leaves[3], K, z_off, mask, prm)
+    ((o["rendered_images"] * G).sum() + (o["shadow_mask_weights"] * Gw).sum()).backward()
+    g_depth, g_alb, g_amb = leaves[0].grad[:, 0], leaves[1].grad, leaves[3].grad
+    sum_alb, sum_depth = torch.zeros_like(g_alb), torch.zeros_like(g_depth)
     for l in range(L):
-        dl = depth[:, None].clone().requires_grad_()
-        al = albedo.clone().requires_grad_()
-        li = light[:, l].clone().requires_grad_()
-        am = amb[:, l].clone().requires_grad_()
-        r = R.render_from_depth(dl, al, li, am, K, cam[4], mask, prm)
+        one = [_leaf(depth_np[:, None]), _leaf(albedo_np), _leaf(light_np[:, l]), _leaf(amb_np[:, l])]
+        r = R.render_from_depth(one[0], one[1], one[2], one[3], K, z_off, mask, prm)
+        assert torch.equal(r["rendered_images"], o["rendered_images"][:, l])
         ((r["rendered_images"] * G[:, l]).sum() + (r["shadow_mask_weights"] * Gw[:, l]).sum()).backward()
-        sum_alb += al.grad
-        sum_depth += dl.grad[:, 0]
-        np.testing.assert_allclose(g_amb[:, l].cpu().numpy(), am.grad.cpu().numpy(), rtol=2e-5)
+        sum_alb += one[1].grad
+        sum_depth += one[0].grad[:, 0]
+        np.testing.assert_allclose(g_amb[:, l].cpu().numpy(), one[3].grad.cpu().numpy(), rtol=2e-5)
     assert float(sum_depth.abs().max()) > 0
     assert float((g_alb - sum_alb).abs().max()) <= 1e-5 * float(sum_alb.abs().max())
     assert float((g_depth - sum_depth).abs().max()) <= 1e-5 * float(sum_depth.abs().max())

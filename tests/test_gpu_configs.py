@@ -45,10 +45,6 @@ def camera(f, Hh, Ww):
 CASES = list(all_cases())
 
 
-def _experimental():
-    return False      # the schedules round 2 rejected left the library in round 3 (they build from commit 4db51f3)
-
-
 @pytest.mark.parametrize("name,case", CASES, ids=[c[0] for c in CASES])
 def test_minimum_distance_and_argmin_match_the_reference(name, case):
     """HIP workspace kernel vs what the reference's torch.min returned.  Bit-equal except where torch-CPU's
@@ -78,12 +74,12 @@ def test_minimum_distance_and_argmin_match_the_reference(name, case):
 def test_config5_full_shape_18_lights_512_320():
     """BASELINE configs[4] on one GPU: one 512 x 512 face, 18 light directions, 320 march steps (1.51 G ray-steps)
     -- minimum distance and argmin bit-equal to the C oracle, fused shading within the north_star gates."""
-    import bench
+    import scenes
     import c_oracle
     from geomconsistentfr_amd import RenderParams
     from geomconsistentfr_amd import block as R
     S, L, N = 512, 18, 320
-    depth, mask, albedo, normals, light, amb = bench.synth_faces_sized(1, 3, S, L)
+    depth, mask, albedo, normals, light, amb = scenes.synth_faces_sized(1, 3, S, L)
     prm = RenderParams(n_samples=N, dt=0.0025)
     out = R.render_fwd(to_dev(depth), to_dev(mask), to_dev(light), to_dev(amb), to_dev(normals), to_dev(albedo), prm,
                        want_argmin=True)
@@ -98,25 +94,24 @@ def test_config5_full_shape_18_lights_512_320():
     ref = c_oracle.shade(normals.astype(np.float64), depth, albedo, pt_o.reshape(1, L, 3), amb, md_o)
     assert np.abs(out["shadow_mask_weights"].cpu().numpy() - ref["shadow_w"]).max() <= 1e-6
     assert np.abs(out["rendered_images"].cpu().numpy() - ref["rendered"]).max() <= 1e-6
-    # every schedule gives the same bits at this shape too (16 x 4 tiles, 4096 tiles per light)
+    # explicit default options give the same bits at this shape too (16 x 4 tiles, 4096 tiles per light)
     from geomconsistentfr_amd import _lib
-    for sched, order in (((0, 0), (1, 2), (2, 2), (3, 4), (4, -1)) if _experimental() else ((0, 0),)):
-        o2 = R.render_fwd(to_dev(depth), to_dev(mask), to_dev(light), to_dev(amb), to_dev(normals), to_dev(albedo), prm,
-                          want_argmin=True, options=_lib.options(schedule=sched, tile_order=order))
-        assert torch.equal(o2["minimum_distance"], out["minimum_distance"]) and torch.equal(o2["argmin"], out["argmin"])
-        assert torch.equal(o2["rendered_images"], out["rendered_images"])
+    o2 = R.render_fwd(to_dev(depth), to_dev(mask), to_dev(light), to_dev(amb), to_dev(normals), to_dev(albedo), prm,
+                      want_argmin=True, options=_lib.options())
+    assert torch.equal(o2["minimum_distance"], out["minimum_distance"]) and torch.equal(o2["argmin"], out["argmin"])
+    assert torch.equal(o2["rendered_images"], out["rendered_images"])
 
 
 def test_config3_batch32_fused_forward_backward():
     """BASELINE configs[2]'s render block: B = 32 faces, 256 x 256 x 160, fused forward (normals + march + shading)
     and the one-launch fused backward.  Forward bit-deterministic, backward repeatable within f32 atomic jitter,
     batch-independent, and equal to autograd through the materialised oracle on two faces of the batch."""
-    import bench
+    import scenes
     import materialised as M
     from normals_restatement import depth_to_normals
     from geomconsistentfr_amd.block import render_from_depth
     B = 32
-    depth, mask, albedo, _normals, light, amb = bench.synth_faces(B, 100)
+    depth, mask, albedo, _normals, light, amb = scenes.synth_faces(B, 100)
     rng = np.random.default_rng(5)
     depth = depth + (2.0 * rng.random(depth.shape)).astype(np.float32)      # training-time depth is not smooth
     G_r = rng.random((B, 3, H, W), dtype=np.float32)
@@ -164,17 +159,15 @@ def test_soak_slice_is_bit_exact():
     distances 30 ... 1e5): minimum distance AND argmin bit-equal to the C oracle on every unmasked pixel."""
     import soak_parity
     from geomconsistentfr_amd import _lib
-    extra = [_lib.options(schedule=4), _lib.options(schedule=1, tile_order=2), _lib.options(schedule=3, tile_order=4)] if _experimental() else []
-    for opt in [None, _lib.options(tile_w=16, group=2)] + extra:
+    for opt in [None, _lib.options(tile_w=16, group=2)]:
         r = soak_parity.run_soak(200 if opt is None else 40, seed=20260928, options=opt)
         assert r["pixels_compared"] > (2_000_000 if opt is None else 300_000)
         assert r["lit_mask_mismatches"] == 0 and r["argmin_differences"] == 0, r
         assert r["max_abs_err_min_dist"] == 0.0, r
-    # the inference kernels (no argmin): the grid and the work-stealing schedule
-    for opt in (_lib.options(schedule=0),) + ((_lib.options(schedule=5), _lib.options(schedule=5, depth_bound_skip=0)) if _experimental() else ()):
-        r = soak_parity.run_soak(120, seed=77, options=opt, want_argmin=False)
-        assert r["pixels_compared"] > 1_000_000
-        assert r["lit_mask_mismatches"] == 0 and r["max_abs_err_min_dist"] == 0.0, r
+    # the inference kernels (no argmin)
+    r = soak_parity.run_soak(120, seed=77, options=_lib.options(), want_argmin=False)
+    assert r["pixels_compared"] > 1_000_000
+    assert r["lit_mask_mismatches"] == 0 and r["max_abs_err_min_dist"] == 0.0, r
 
 
 def _adversarial_surfaces(Hs, Ws, rng):
@@ -215,13 +208,12 @@ def test_adversarial_surfaces_for_the_depth_bound_skip(light_distance):
     pt_o = c_oracle.light_prep(lights.reshape(-1, 3), clamp_z_min=0.0, light_distance=light_distance)[1].reshape(B, 3, 3)
     md_o, am_o = c_oracle.shadow_min_distance(depth, mask, pt_o, c_oracle.sample_table(0.025, 0.8 / N, N))
     lit = md_o < 1e5
-    for tw, sched in ((0, -1), (8, 0), (16, 0), (32, 0), (64, 0)) + (((8, 4), (16, 4), (16, 1), (32, 2), (64, 3), (8, 2)) if _experimental() else ()):
-        md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm,
-                                     options=_lib.options(tile_w=tw, schedule=sched, ksplit=0, tile_order=2 if sched in (1, 2, 3) else -1))
+    for tw in (0, 8, 16, 32, 64):
+        md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, options=_lib.options(tile_w=tw, ksplit=0))
         md, am = md.cpu().numpy(), am.cpu().numpy()
         bad = np.argwhere(md != md_o)
-        assert bad.size == 0, (tw, sched, list(surf)[bad[0][0]], bad[:3].tolist())
-        assert np.array_equal(am[lit], am_o[lit]), (tw, sched)
+        assert bad.size == 0, (tw, list(surf)[bad[0][0]], bad[:3].tolist())
+        assert np.array_equal(am[lit], am_o[lit]), tw
 
 
 def test_two_host_threads_two_streams_different_options():

@@ -261,10 +261,10 @@ def test_config5_shape_with_forced_grid_schedule_against_the_c_oracle():
     sys.path.insert(0, os.path.join(root, "oracle"))
     sys.path.insert(0, root)
     import c_oracle
-    import bench
+    import scenes
     from geomconsistentfr_amd import _lib, RenderParams, light_prep, shadow_min_distance
     dev = torch.device("cuda:0")
-    depth, mask, _, _, light, _ = bench.synth_faces_sized(1, 3, 512, 18, "ellipse")
+    depth, mask, _, _, light, _ = scenes.synth_faces_sized(1, 3, 512, 18, "ellipse")
     prm = RenderParams(n_samples=320, dt=0.8 / 320)
     _, pt = light_prep(torch.from_numpy(light.reshape(18, 3)).to(dev), prm)
     _, pt_o = c_oracle.light_prep(light.reshape(18, 3), clamp_z_min=0.0)

@@ -26,12 +26,6 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _sched(cases):
-    """Keep the (.., schedule, ..) cases the library can run: the grid is the only schedule since round 3 (the
-    alternatives round 2 measured and rejected were removed; they build from commit 4db51f3)."""
-    return [c for c in cases if max(c[1] if isinstance(c, tuple) else c, 0) == 0]
-
-
 def to_dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
 
@@ -224,11 +218,10 @@ def test_sample_range_split_is_bit_identical(N):
     prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
     _, pt = light_prep(to_dev(lights), prm)
     ref_md, ref_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=False)
-    for ks, sched in _sched([(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (1, -1)]):   # grid, tile queue, strided, ordered grid, cooperative, k-split
-        md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True,
-                                     options=_lib.options(ksplit=ks, schedule=sched))
-        assert torch.equal(md, ref_md), (ks, sched)
-        assert torch.equal(am, ref_am), (ks, sched)
+    for ks in (0, 1):                                   # one tile per wave (the grid), k-split
+        md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True, options=_lib.options(ksplit=ks))
+        assert torch.equal(md, ref_md), ks
+        assert torch.equal(am, ref_am), ks
 
 
 def _compact_masks(Hs, Ws):
@@ -263,12 +256,11 @@ def test_mask_bounding_box_pruning_is_exact(Hs, Ws, N):
     prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N)
     _, pt = light_prep(to_dev(lights), prm)
     ref_md, ref_am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=False)
-    for ks, sched, order in _sched([(0, 0, 0), (0, 1, 0), (0, 1, 1), (0, 2, 2), (0, 2, 0), (0, 3, 2), (0, 3, 4), (0, 4, -1), (1, -1, -1)]):
-        md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True,
-                                     options=_lib.options(ksplit=ks, schedule=sched, tile_order=order))
+    for ks in (0, 1):
+        md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True, options=_lib.options(ksplit=ks))
         bad = (md != ref_md).nonzero()
-        assert torch.equal(md, ref_md), (ks, sched, order, bad[:5].tolist())
-        assert torch.equal(am, ref_am), (ks, sched, order)
+        assert torch.equal(md, ref_md), (ks, bad[:5].tolist())
+        assert torch.equal(am, ref_am), ks
     empty = list(masks).index("empty")
     assert torch.all(ref_md[empty] == 1e6)
     # one mask shared by the whole batch (S1 form): bounding box of mask 0 applies to every image
@@ -403,11 +395,10 @@ def test_depth_bound_skip_is_exact_for_every_tile_shape(Hs, Ws, N, dt):
     for zb in (1, 0):
         for tw in (8, 16, 32, 64):
             for grp in ((4, 2, 1) if tw == 8 else (4,)):
-                for sched in [c[1] for c in _sched([(0, x) for x in ((0, 4, 2, 1, 3) if grp == 4 else (0, 4))])]:
-                    opt = _lib.options(depth_bound_skip=zb, tile_w=tw, group=grp, schedule=sched, ksplit=0)
-                    md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True, options=opt)
-                    assert torch.equal(md, ref_md), (zb, tw, grp, sched)
-                    assert torch.equal(am, ref_am), (zb, tw, grp, sched)
+                opt = _lib.options(depth_bound_skip=zb, tile_w=tw, group=grp, ksplit=0)
+                md, am = shadow_min_distance(to_dev(depth), to_dev(mask), pt, prm, use_workspace=True, options=opt)
+                assert torch.equal(md, ref_md), (zb, tw, grp)
+                assert torch.equal(am, ref_am), (zb, tw, grp)
 
 
 def test_render_fwd_plan_matches_eager_call_and_overlaps_on_two_streams():

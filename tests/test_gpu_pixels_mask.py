@@ -18,8 +18,8 @@ DEV = torch.device("cuda:0")
 
 
 def _faces(B, rough):
-    import bench
-    depth, mask, albedo, normals, light, amb = bench.synth_faces(B, seed0=11)
+    import scenes
+    depth, mask, albedo, normals, light, amb = scenes.synth_faces(B, seed0=11)
     if rough:
         depth = depth + (400.0 * np.random.default_rng(3).random(depth.shape)).astype(np.float32)
     mask[1, 40:44, 200:230] = 1                      # an island far from the face: its pixels march, its neighbours do not

@@ -147,3 +147,48 @@ def test_phase_one_needs_no_albedo_and_phase_two_needs_its_operands():
     torch.cuda.synchronize()
     _, pt_ref = R.light_prep(light, prm)
     assert torch.equal(pt, pt_ref)
+
+
+def test_a_stale_prepared_is_refused_not_rendered():
+    """Round-5 advisor finding: render_fwd(prepared=...) used to substitute the prepass's own tensors BEFORE comparing, so a
+    Prepared built from other (or since overwritten) depth / light of the same shapes rendered the old data without an error
+    and autograd returned gradients for the wrong input.  The caller's tensors are now compared with the prepass's record
+    (address, in-place version, shape, strides, dtype)."""
+    from geomconsistentfr_amd import RenderParams
+    from geomconsistentfr_amd import block as R
+    from geomconsistentfr_amd._lib import GcfrError
+    depth, mask, light, amb, nrm, alb = _inputs()
+    prm = RenderParams(n_samples=64, dt=0.0125)
+    cam = (1570.0, 1570.0, 64.0, 48.0, 1610.0)
+    kw = dict(want_argmin=True, camera=cam)
+    pre = R.render_prepass(depth, mask, light, prm, want_argmin=True)
+    with pytest.raises(GcfrError):                                            # another depth tensor of the same shape
+        R.render_fwd(depth.clone(), mask, light, amb, None, alb, prm, prepared=pre, **kw)
+    with pytest.raises(GcfrError):                                            # another light
+        R.render_fwd(depth, mask, light + 0.1, amb, None, alb, prm, prepared=pre, **kw)
+    with pytest.raises(GcfrError):                                            # another mask
+        R.render_fwd(depth, 1 - mask, light, amb, None, alb, prm, prepared=pre, **kw)
+    ok = R.render_fwd(depth, mask, light, amb, None, alb, prm, prepared=pre, **kw)      # the very tensors: accepted
+    ok = {k: v.clone() for k, v in ok.items() if v is not None}
+    original = depth.clone()
+    depth.add_(1.0)                                                           # written in place since the prepass
+    with pytest.raises(GcfrError):
+        R.render_fwd(depth, mask, light, amb, None, alb, prm, prepared=pre, **kw)
+    torch.cuda.synchronize()
+    depth.copy_(original)
+    ref = R.render_fwd(depth, mask, light, amb, None, alb, prm, **kw)
+    assert torch.equal(ok["rendered_images"], ref["rendered_images"])
+    # the differentiable wrapper: the same check, through render_from_depth_prepass / render_from_depth
+    K = torch.zeros(1, 3, 3, dtype=torch.float64)
+    K[:, 0, 0] = K[:, 1, 1] = 1570.0
+    K[:, 2, 2] = 1.0
+    K[:, 0, 2], K[:, 1, 2] = 64.0, 48.0
+    d4 = depth[:, None].clone().requires_grad_()
+    l2 = light[:, 0].clone().requires_grad_()
+    pre = R.render_from_depth_prepass(d4, l2, K, mask, prm)
+    with pytest.raises(GcfrError):
+        R.render_from_depth(d4.detach().clone().requires_grad_(), alb, l2, amb[:, 0], K, 1610.0, mask, prm, prepared=pre)
+    r = R.render_from_depth(d4, alb, l2, amb[:, 0], K, 1610.0, mask, prm, prepared=pre)
+    r["rendered_images"].sum().backward()
+    r2 = R.render_from_depth(d4.detach(), alb, l2.detach(), amb[:, 0], K, 1610.0, mask, prm)
+    assert torch.equal(r["rendered_images"], r2["rendered_images"]) and float(d4.grad.abs().max()) > 0

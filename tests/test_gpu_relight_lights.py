@@ -1,0 +1,168 @@
+"""GPU: many lights per face at the boundary callers use (round 6; BASELINE configs[4]'s actual use).
+
+`RelightNetSingleImage.forward_lights` / `RelightNetLightingTransfer.forward_lights` / `inference.relight_lights`: ONE network
+pass, one prepass and one normals stage per face, L marches, one image-kernel launch -- against L calls of the one-light
+forms (what the reference does: the whole model once per light, S1:582-588), at the eleven directions the reference ships
+(S1:519-562).  The network's convolutions are MIOpen's (not run-to-run reproducible), so the bit-level comparisons run on
+FIXED head outputs (a subclass whose features() returns given tensors and fires the prepass hook the way the real one does);
+the real network with the shipped lighting-transfer checkpoint is compared within a byte tolerance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+H = W = 256
+
+
+def _lights11():
+    from geomconsistentfr_amd.inference import LIGHT_DIRECTIONS
+    return np.asarray(list(LIGHT_DIRECTIONS.values()), np.float32)
+
+
+def _fixed_heads(B, seed):
+    import scenes
+    depth, mask, albedo, _n, _l, _a = scenes.synth_faces(B, seed)
+    rng = np.random.default_rng(seed)
+    sl = np.concatenate([0.4 + 0.2 * rng.random((B, 1)), rng.standard_normal((B, 3))], 1).astype(np.float32).reshape(B, 1, 1, 4)
+    return depth[:, None], albedo, sl, (mask[0] * 255).astype(np.uint8)
+
+
+def _fixed(cls, heads, **kw):
+    d0, a0, sl0, _ = heads
+
+    class Fixed(cls):
+        def features(self, img, epoch, on_depth=None):
+            albedo, depth, SL = [torch.from_numpy(x).to(DEV) for x in (a0, d0, sl0)]
+            if on_depth is not None:
+                on_depth(depth, SL)
+            return albedo, depth, SL
+
+    return Fixed(**kw).to(DEV).eval()
+
+
+def _K(f):
+    from geomconsistentfr_amd.inference import camera_matrix
+    return camera_matrix(f, H, W, DEV)
+
+
+@pytest.mark.parametrize("hoist", [True, False])
+def test_single_image_forward_lights_equals_eleven_forwards(hoist):
+    from geomconsistentfr_amd.relightnet import RelightNetSingleImage
+    B = 3
+    heads = _fixed_heads(B, 40)
+    net = _fixed(RelightNetSingleImage, heads)
+    net.hoist_prepass = hoist
+    lights = _lights11()
+    img = torch.zeros(B, H, W, 3, device=DEV)
+    mask = torch.from_numpy(heads[3].astype(np.float64) / 255.0).reshape(H, W, 1).to(DEV)
+    with torch.no_grad():
+        many = net.forward_lights(img, 200, _K(1570.0), mask, lights)
+        assert len(many) == 10 and tuple(many[5].shape) == (B, 11, 3, H, W) and tuple(many[2].shape) == (B, 11, H, W)
+        assert tuple(many[6].shape) == (B, 11, 3, 1, 1) and tuple(many[7].shape) == (B, 11, 1, 1) and tuple(many[9].shape) == (B, 3, H, W)
+        for l in range(11):
+            tl = torch.from_numpy(np.repeat(lights[l][None], B, 0)).reshape(B, 3, 1, 1).to(DEV)
+            one = net(img, 200, _K(1570.0), mask, tl, torch.zeros(B, 1, 1, device=DEV), mask[None])
+            for k in (2, 3, 4, 5, 6, 7, 8):
+                assert torch.equal(many[k][:, l], one[k]), (k, l)
+            assert torch.equal(many[9], one[9]) and torch.equal(many[0], one[0]) and torch.equal(many[1], one[1])
+        # per-face light sets (B,L,3): face b under its own rotation of the eleven
+        per_face = np.stack([np.roll(lights, b, axis=0)[:4] for b in range(B)])
+        pf = net.forward_lights(img, 200, _K(1570.0), mask, per_face)
+        for b in range(B):
+            for l in range(4):
+                assert torch.equal(pf[5][b, l], many[5][b, (l - b) % 11])
+
+
+def test_lighting_transfer_forward_lights_equals_forwards():
+    from geomconsistentfr_amd.relightnet import RelightNetLightingTransfer
+    B = 2
+    heads = _fixed_heads(B, 7)
+    net = _fixed(RelightNetLightingTransfer, heads)
+    lights = _lights11()[:5]
+    ambs = np.array([0.5, 0.45, 0.6, 0.3, 0.55], np.float32)
+    img = torch.zeros(B, H, W, 3, device=DEV)
+    mask = (torch.from_numpy(heads[3]).to(DEV).reshape(H, W, 1) / 255.0)                      # f32, as SLT:540
+    with torch.no_grad():
+        many = net.forward_lights(img, 200, _K(700.0), mask, lights, ambs)
+        assert len(many) == 12
+        for l in range(5):
+            tl = torch.from_numpy(np.repeat(lights[l][None], B, 0)).reshape(B, 3, 1, 1).to(DEV)
+            one = net(img, 200, _K(700.0), mask, tl, torch.full((B, 1, 1), float(ambs[l]), device=DEV))
+            for k in (2, 3, 4, 5, 6, 7, 8):
+                assert torch.equal(many[k][:, l], one[k]), (k, l)
+            for k in (9, 10, 11):
+                assert torch.equal(many[k], one[k])
+
+
+@pytest.mark.parametrize("transfer", [False, True])
+def test_relight_lights_bytes_equal_eleven_relight_images_calls(transfer):
+    """(B,11) uint8 composites from ONE forward_lights + ONE image-kernel launch == eleven relight_images() calls, byte for byte,
+    border fix included."""
+    from geomconsistentfr_amd import inference as inf
+    from geomconsistentfr_amd.relightnet import RelightNetLightingTransfer, RelightNetSingleImage
+    B = 2
+    heads = _fixed_heads(B, 90)
+    net = _fixed(RelightNetLightingTransfer if transfer else RelightNetSingleImage, heads)
+    rng = np.random.default_rng(3)
+    images = rng.random((B, H, W, 3), dtype=np.float32)
+    lights = _lights11()
+    for fix in (False, True):
+        got = inf.relight_lights(net, images, heads[3], lights, ambient=0.5, device=DEV, fix_border=fix)
+        assert got.shape == (B, 11, H, W, 3) and got.dtype == np.uint8
+        for l in range(11):
+            one = inf.relight_images(net, images, heads[3], np.repeat(lights[l][None], B, 0), ambient=0.5, device=DEV, fix_border=fix)
+            np.testing.assert_array_equal(got[:, l], one, err_msg="light %d fix_border %s" % (l, fix))
+    assert got.std() > 10                                                                # not a blank image
+
+
+def test_image_kernel_many_lights_equals_per_light_launches():
+    """gcfr_inference_images_u8 with L relit images per photograph (ABI 6): the photograph is read in place once per light --
+    the same bytes as L launches, diagnostic maps included, both mask modes, per-face masks."""
+    from geomconsistentfr_amd import postprocess as pp
+    rng = np.random.default_rng(12)
+    B, L, Hs, Ws = 3, 4, 40, 56
+    f = lambda *s: torch.from_numpy(rng.random(s, dtype=np.float32)).to(DEV)
+    x, ren, w, fin = f(B, Hs, Ws, 3), f(B, L, 3, Hs, Ws) * 1.2 - 0.1, f(B, L, Hs, Ws), f(B, L, Hs, Ws) * 1.1
+    alb, depth, nrm = f(B, 3, Hs, Ws), f(B, 1, Hs, Ws) * 80 - 40, f(B, 3, Hs, Ws) * 2 - 1
+    masks = torch.from_numpy(rng.choice([0, 64, 128, 255], size=(B, Hs, Ws)).astype(np.uint8)).to(DEV)
+    for mask_f32 in (False, True):
+        for m in (masks, masks[:1]):
+            many = pp.inference_images_device(x, ren, m, albedo=alb, depth=depth, shadow_mask_weights=w, final_shading=fin,
+                                              surface_normals=nrm, mask_f32=mask_f32)
+            assert tuple(many["rendered_image"].shape) == (B, L, Hs, Ws, 3) and tuple(many["albedo"].shape) == (B, Hs, Ws, 3)
+            for l in range(L):
+                one = pp.inference_images_device(x, ren[:, l], m, albedo=alb, depth=depth, shadow_mask_weights=w[:, l],
+                                                 final_shading=fin[:, l], surface_normals=nrm, mask_f32=mask_f32)
+                for k in ("rendered_image", "shadow_mask", "shading"):
+                    assert torch.equal(many[k][:, l], one[k]), (k, l)
+                for k in ("albedo", "depth", "surface_normals"):
+                    assert torch.equal(many[k], one[k]), k
+
+
+def test_relight_lights_with_the_shipped_checkpoint_close_to_per_light_runs():
+    """The real network (the reference's lighting-transfer checkpoint, tests/golden/slt_checkpoint_epoch106.npz) on the
+    reference's own input photographs: relight_lights against per-light relight_images.  Two network passes need not agree to
+    the last bit (MIOpen), a shadow decision can flip on isolated pixels: >= 99.9 % of the bytes identical, >= 99.99 % within 1."""
+    from geomconsistentfr_amd import inference as inf
+    from geomconsistentfr_amd.relightnet import RelightNetLightingTransfer
+    sd = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "slt_checkpoint_epoch106.npz")).items()}
+    net = RelightNetLightingTransfer()
+    net.load_state_dict(sd, strict=True)
+    net = net.float().to(DEV).eval()
+    za, zb = [np.load(os.path.join(GOLDEN, "slt_main_%s.npz" % t)) for t in ("a", "b")]
+    images = np.stack([za["input_u8"] / 255.0, zb["input_u8"] / 255.0]).astype(np.float32)
+    lights = _lights11()
+    got = inf.relight_lights(net, images, za["mask_u8"], lights, ambient=0.5, device=DEV)
+    assert got.shape == (2, 11, H, W, 3)
+    for l in (0, 5, 10):
+        one = inf.relight_images(net, images, za["mask_u8"], np.repeat(lights[l][None], 2, 0), ambient=0.5, device=DEV)
+        diff = np.abs(got[:, l].astype(int) - one.astype(int))
+        assert (diff == 0).mean() >= 0.999 and (diff <= 1).mean() >= 0.9999, (l, (diff == 0).mean(), diff.max())
+    # the lights differ from each other (eleven different images, not one repeated)
+    assert np.abs(got[:, 0].astype(int) - got[:, 4].astype(int)).mean() > 1.0

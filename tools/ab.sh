@@ -6,7 +6,7 @@
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
 CFGS=("$@")
-[ ${#CFGS[@]} -eq 0 ] && CFGS=("schedule=1" "schedule=0" "schedule=1,tile_order=1" "schedule=1,tile_order=2")
+[ ${#CFGS[@]} -eq 0 ] && CFGS=("default" "tile_w=16" "tile_w=8,group=2" "lds_stage=0")
 for round in 1 2 3; do
   for cfg in "${CFGS[@]}"; do
     unset GCFR_HIP_LIB

@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--config5", type=int, default=0, help="N faces at configs[4]'s shape (512 x 512 x 320, 18 lights) instead of the mixed-size soak")
     ap.add_argument("--cases", type=int, default=240)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--tune", type=str, default="", help="comma list of gcfr_options knobs, e.g. schedule=0,tile_w=16")
+    ap.add_argument("--tune", type=str, default="", help="comma list of gcfr_options knobs, e.g. ksplit=0,tile_w=16")
     ap.add_argument("--no-argmin", action="store_true", help="the inference kernels (six waves / SIMD, no argmin output)")
     a = ap.parse_args()
     from geomconsistentfr_amd import _lib

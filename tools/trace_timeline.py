@@ -9,7 +9,7 @@ that tell a tail problem (few long waves at the end) from an imbalance problem (
 from a rate problem (every wave slow).
 
 usage: GCFR_HIP_LIB=geomconsistentfr_amd/lib/counters.so python tools/trace_timeline.py [--faces 8]
-       [--tune "schedule=0" --tune "schedule=3,tile_order=3" ...] [--out gpurun_out/x.npz]
+       [--tune "tile_w=16" --tune "tile_w=8,group=2" ...] [--out gpurun_out/x.npz]
 """
 import argparse
 import json
@@ -86,7 +86,7 @@ def main():
     args = (t(depth), t(mask), t(light).reshape(B, 1, 3), t(amb).reshape(B, 1), t(normals), t(albedo))
     n_tiles = B * 16 * 64                                      # 16 x 4 tiles of a 256 x 256 face
     saved = {}
-    for tune in (a.tune or ["schedule=0"]):
+    for tune in (a.tune or [""]):
         knobs = {k: int(v) for k, v in (kv.split("=") for kv in tune.split(",") if kv)}
         buf = torch.zeros(_lib.N_COUNTERS + 4 * n_tiles, dtype=torch.int64, device=dev)
         for rep in range(3):                                   # the last repetition is the one analysed (warm caches)
