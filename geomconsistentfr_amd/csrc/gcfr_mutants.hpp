@@ -25,6 +25,16 @@
 // 11  c1 > 0 ("the ray is still rising") in both termination tests                   dropped
 // 13  horizon tables: wrap partners (prefix tables include the last column / row, suffix the first)   left out
 // 14  horizon tables: the dilation of the live cells wraps where the gathers do      no wrap
+//     (round 6, on 13 / 14 and the audit build, profiles/r06_audit_wrap.json.  tests/margin_scenes.py family `wrap_column` -- a
+//      wall that ramps with the rays' own height in the masked-out wrap-partner column / row, light point exactly on the image's
+//      edge -- makes mutant 14 contradict 51,164 termination claims and fail tests/test_gpu_margins.py end to end.  Mutant 13
+//      changes nothing there, and with the reference's sample tables (t <= 0.82, T8:468) it cannot: a sample reads column -1
+//      (= W-1) only if floor(u_x) = -1, i.e. x + t dx < -W/2 + 1e-4, and the end point is clamped to x >= -W/2 (T8:462-465); a lane
+//      heading LEFT (dx < 0: the prefix table) starts at x >= -W/2 + 1 and needs t > 1 - 1e-4 / |dx| to get there, a lane in column
+//      0 has dx >= 0 and looks up the SUFFIX table, which holds column W-1 by construction; rows likewise.  A caller's table that
+//      reaches t = 1 (the prepass accepts tables inside [0, 1]) does let a prefix lane's LAST sample read the wrap partner: family
+//      `wrap_last_sample` marches such a table over a wall sized so that this last sample is the minimum -- mutant 13 then
+//      contradicts 242,244 termination claims (14: 261,834) and fails test_gpu_margins.py[wrap_last_sample-*]; the product: 0.)
 // 15  march_grid: a tile that hands itself to the rough variant is re-run by it      not re-run
 // 16  tie predecessor (first index of the minimal DISTANCE, torch.min)               never re-marched
 // 17  pixels = mask: a pixel whose own mask cell is zero is not marched (value 1e6)   marched after all

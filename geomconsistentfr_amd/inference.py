@@ -65,9 +65,11 @@ def relight_batch(model, images, masks_u8, lights, ambient: float = 0.5,
     mask = torch.as_tensor(np.asarray(masks_u8), dtype=torch.float64).reshape(H, W, 1) / 255.0     # S1:580
     tl = torch.as_tensor(np.asarray(lights), dtype=torch.float32).reshape(B, 3, 1, 1).to(device)
     ta = torch.full((B, 1, 1), float(ambient), dtype=torch.float32, device=device)
+    # (the camera matrix stays a HOST tensor: block.camera_scalars reads it without a device round trip; a fresh device tensor
+    #  per call -- what the scripts pass, S1:588 -- would cost a device-to-host synchronisation per pass)
     if _is_transfer(model):
-        return model(x, epoch, camera_matrix(700.0 if focal is None else focal, H, W, device), mask.to(device), tl, ta)
-    return model(x, epoch, camera_matrix(1570.0 if focal is None else focal, H, W, device), mask.to(device), tl, ta, mask[None].to(device))
+        return model(x, epoch, camera_matrix(700.0 if focal is None else focal, H, W), mask.to(device), tl, ta)
+    return model(x, epoch, camera_matrix(1570.0 if focal is None else focal, H, W), mask.to(device), tl, ta, mask[None].to(device))
 
 
 @torch.no_grad()
@@ -107,7 +109,7 @@ def relight_lights_device(model, images, mask_u8, lights, ambient: float = 0.5, 
     x = _as_batch(images).to(device)
     B, H, W, _ = x.shape
     transfer = _is_transfer(model)
-    K = camera_matrix((700.0 if transfer else 1570.0) if focal is None else focal, H, W, device)
+    K = camera_matrix((700.0 if transfer else 1570.0) if focal is None else focal, H, W)          # host: read without a sync
     as_u8 = lambda m: (m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m))).to(device=device, dtype=torch.uint8)
     m_u8 = as_u8(mask_u8)
     mask = (m_u8.to(torch.float64).reshape(H, W, 1) / 255.0)                                                     # S1:580 / SLT:540
@@ -133,6 +135,74 @@ def relight_lights(model, images, mask_u8, lights, ambient: float = 0.5, focal: 
     equals relight_images(model, images[b:b+1], mask_u8, lights[l:l+1]) given the same network outputs.  One device-to-host
     copy of B*L*H*W*3 bytes at the end (`relight_lights_device` stops before it)."""
     return relight_lights_device(model, images, mask_u8, lights, ambient, focal, device, fix_border, composite_mask_u8, epoch).cpu().numpy()
+
+
+class RelightSession:
+    """Steady-state serving form of `relight_lights_device` for a fixed shape: B photographs x L lights of H x W.
+
+    The eager pass is host-bound -- ~350 kernel launches of the network's small convolutions, the block's two and the image
+    kernel's one, issued one by one from Python (bench.py `relight_e2e`: 4.7 ms per pass of 8 faces of which the GPU is busy a
+    fraction).  Here the WHOLE pass -- network forward (eval), render block, uint8 image kernel -- is captured ONCE into a
+    hipGraph on static buffers; `run(images)` copies the new photographs into the static input and replays it: one launch per
+    pass.  Nothing in the block allocates or synchronises (include/gcfr.h), MIOpen runs in immediate mode (no find pass inside
+    the capture), the camera matrix is a host tensor.  The captured kernels are the eager pass's kernels with the eager pass's
+    arguments: the composites equal `relight_lights_device` on the same inputs up to MIOpen's own run-to-run jitter
+    (tests/test_gpu_relight_lights.py).  `graph=False` keeps the static buffers and runs eagerly (the A/B)."""
+
+    def __init__(self, model, B: int, mask_u8, lights, ambient: float = 0.5, focal: float = None, device="cuda",
+                 H: int = 256, W: int = 256, fix_border: bool = False, composite_mask_u8=None, graph: bool = True, epoch: int = 200):
+        self.model, self.device, self.epoch, self.ambient, self.fix_border = model, torch.device(device), epoch, float(ambient), fix_border
+        self.transfer = _is_transfer(model)
+        self.K = camera_matrix((700.0 if self.transfer else 1570.0) if focal is None else focal, H, W)       # host
+        as_u8 = lambda m: (m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m))).to(device=self.device, dtype=torch.uint8)
+        self.m_u8 = as_u8(mask_u8).reshape(H, W)
+        self.cm = self.m_u8 if composite_mask_u8 is None else as_u8(composite_mask_u8).reshape(H, W)
+        self.mask = (self.m_u8.to(torch.float64).reshape(H, W, 1) / 255.0)
+        lights = (lights if torch.is_tensor(lights) else torch.as_tensor(np.asarray(lights, np.float32))).to(device=self.device, dtype=torch.float32)
+        self.lights = (lights.reshape(-1, 3) if lights.dim() <= 2 else lights).contiguous()
+        self.x = torch.zeros((B, H, W, 3), dtype=torch.float32, device=self.device)
+        self.ambient_dev = torch.full((1,), self.ambient, dtype=torch.float32, device=self.device)   # (no host-to-device copy inside the capture)
+        self.out = None
+        self.graph = None
+        if graph:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):                     # warm-up outside the capture (allocator, MIOpen's solution look-up)
+                for _ in range(2):
+                    self._pass()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._pass()
+
+    @torch.no_grad()
+    def _pass(self):
+        hoist = self.model.hoist_prepass
+        self.model.hoist_prepass = hoist and self.graph is None and not torch.cuda.is_current_stream_capturing()
+        try:                                                  # (inside a graph there is no launch latency for a side stream to hide)
+            if self.transfer:
+                o = self.model.forward_lights(self.x, self.epoch, self.K, self.mask, self.lights, self.ambient_dev)
+            else:
+                o = self.model.forward_lights(self.x, self.epoch, self.K, self.mask, self.lights)
+        finally:
+            self.model.hoist_prepass = hoist
+        imgs = pp.inference_images_device(self.x, o[5], self.cm, mask_f32=self.transfer)["rendered_image"]
+        if self.fix_border:
+            B, L, H, W, _ = imgs.shape
+            imgs = pp.fix_border_artifacts_device(imgs.reshape(B * L, H, W, 3), self.cm).reshape(B, L, H, W, 3)
+        return imgs
+
+    @torch.no_grad()
+    def run(self, images=None) -> torch.Tensor:
+        """images (B,H,W,3) f32 in [0,1] (host or device; None = whatever the static input holds) -> (B,L,H,W,3) uint8 DEVICE
+        tensor; with a graph it is overwritten by the next run."""
+        if images is not None:
+            self.x.copy_(_as_batch(images), non_blocking=True)
+        if self.graph is None:
+            return self._pass()
+        self.graph.replay()
+        return self.out
 
 
 @torch.no_grad()

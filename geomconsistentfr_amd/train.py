@@ -49,22 +49,70 @@ def _gauss_window(size: int, sigma: float, device, dtype):
     return g / g.sum()
 
 
+class _DepthwiseBlur(torch.autograd.Function):
+    """Separable 'valid' Gaussian blur of every channel (the SSIM's window), forward AND backward through ATen's own depthwise
+    convolution kernels instead of MIOpen (round 6, profiles/r06_train_step_breakdown.md).  MIOpen has no tuned solver for a
+    depthwise 11 x 1 convolution over 3 channels: it runs CK's grouped-convolution kernel at 3 groups (70 us per 25-MB map, five
+    times what the bytes need) or, for the 15-group stacked form, its NAIVE reference kernel (`naive_conv_ab_nonpacked_*`, 0.7 ms
+    forward and 1.25 ms backward per launch) -- the SSIM term cost ~3.4 ms of the 33-ms step.  With `cudnn.flags(enabled=False)`
+    (which is what switches MIOpen off in PyTorch-ROCm) the dispatcher takes `conv_depthwise2d`, a bandwidth-bound kernel.  The
+    window is symmetric, so the backward of a valid correlation is the same correlation of the zero-padded upstream gradient:
+    two more depthwise convolutions, under the same switch (autograd's own convolution backward re-selects the backend when it
+    RUNS, outside the forward's context).  Same fp32 sums of the same eleven products per output; the order of the additions is
+    the kernel's, as it is MIOpen's in the other form (which differs between its solvers too)."""
+
+    @staticmethod
+    def forward(ctx, t, wh, ww):
+        C = t.shape[1]
+        ctx.save_for_backward(wh, ww)
+        with torch.backends.cudnn.flags(enabled=False):
+            return F.conv2d(F.conv2d(t, wh, groups=C), ww, groups=C)
+
+    @staticmethod
+    def backward(ctx, g):
+        wh, ww = ctx.saved_tensors
+        C = g.shape[1]
+        p = wh.shape[2] - 1
+        with torch.backends.cudnn.flags(enabled=False):
+            g = F.conv2d(F.conv2d(g.contiguous(), ww, groups=C, padding=(0, p)), wh, groups=C, padding=(p, 0))
+        return g, None, None
+
+
 def ssim(X: torch.Tensor, Y: torch.Tensor, data_range: float = 1.0, size_average: bool = True,
-         nonnegative_ssim: bool = True, win_size: int = 11, win_sigma: float = 1.5) -> torch.Tensor:
-    """Gaussian-window SSIM, separable 'valid' filtering, per-channel mean, K = (0.01, 0.03)."""
+         nonnegative_ssim: bool = True, win_size: int = 11, win_sigma: float = 1.5, stacked: bool = False,
+         blur_kernels: str = "aten") -> torch.Tensor:
+    """Gaussian-window SSIM, separable 'valid' filtering, per-channel mean, K = (0.01, 0.03).
+    `blur_kernels` (device tensors only): "aten" = the depthwise convolutions through ATen's own kernels (`_DepthwiseBlur`),
+    "miopen" = plain F.conv2d as in rounds 2-5 (MIOpen picks the solver).  On the CPU both are F.conv2d.
+    `stacked` (round 6): the five blurred maps -- X, Y, X*X, Y*Y, X*Y -- come from ONE pair of depthwise convolutions over the
+    five inputs stacked on the channel axis (15 groups) instead of five pairs over 3 groups: a depthwise convolution filters
+    every channel on its own, so each map is the same sum of the same eleven products either way (value bit-equal on the CPU,
+    tests/test_train_host.py; the gradient with respect to X is the same three terms added in another order by autograd: 1 ulp);
+    ten convolution launches become two in the forward, and as many in the backward.  MEASURED AND NOT KEPT as the default:
+    with MIOpen's kernels the stacked form is 0.45 ms per step SLOWER (forward -0.45 ms, backward +0.97 ms: it lands on the naive
+    solver; profiles/r06_ssim_ab.txt)."""
     C = X.shape[1]
     g = _gauss_window(win_size, win_sigma, X.device, X.dtype)
-    wh = g.view(1, 1, -1, 1).repeat(C, 1, 1, 1)
-    ww = g.view(1, 1, 1, -1).repeat(C, 1, 1, 1)
+    n_maps = 5 if stacked else 1
+    wh = g.view(1, 1, -1, 1).repeat(n_maps * C, 1, 1, 1)
+    ww = g.view(1, 1, 1, -1).repeat(n_maps * C, 1, 1, 1)
+
+    if blur_kernels not in ("aten", "miopen"):
+        raise ValueError("blur_kernels must be 'aten' or 'miopen'")
 
     def blur(t):
-        return F.conv2d(F.conv2d(t, wh, groups=C), ww, groups=C)
+        if blur_kernels == "aten" and t.is_cuda:
+            return _DepthwiseBlur.apply(t, wh, ww)
+        return F.conv2d(F.conv2d(t, wh, groups=n_maps * C), ww, groups=n_maps * C)
 
     C1, C2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
-    mu1, mu2 = blur(X), blur(Y)
-    s1 = blur(X * X) - mu1 * mu1
-    s2 = blur(Y * Y) - mu2 * mu2
-    s12 = blur(X * Y) - mu1 * mu2
+    if stacked:
+        mu1, mu2, xx, yy, xy = blur(torch.cat([X, Y, X * X, Y * Y, X * Y], dim=1)).split(C, dim=1)
+    else:
+        mu1, mu2, xx, yy, xy = blur(X), blur(Y), blur(X * X), blur(Y * Y), blur(X * Y)
+    s1 = xx - mu1 * mu1
+    s2 = yy - mu2 * mu2
+    s12 = xy - mu1 * mu2
     cs = (2 * s12 + C2) / (s1 + s2 + C2)
     ssim_map = ((2 * mu1 * mu2 + C1) / (mu1 * mu1 + mu2 * mu2 + C1)) * cs
     per_channel = ssim_map.flatten(2).mean(-1)
@@ -111,12 +159,12 @@ def synthetic_batch(B: int, seed0: int, H: int = 256, W: int = 256, device="cpu"
 # ------------------------------------------------------------------------------------------------
 # losses and the step
 # ------------------------------------------------------------------------------------------------
-def generator_losses(out, batch, logits_fake_for_g) -> Dict[str, torch.Tensor]:
+def generator_losses(out, batch, logits_fake_for_g, ssim_stacked: bool = False, ssim_blur: str = "aten") -> Dict[str, torch.Tensor]:
     """The seven generator-side terms of T8:633-645.  `out` is RelightNet.forward's 8-tuple."""
     albedo, depth, _w, _amb_l, _full, rendered, unit_light, ambient_values = out
     B = rendered.shape[0]
     img = batch["images"].permute(0, 3, 1, 2)
-    m3 = batch["masks_fill"].permute(0, 3, 1, 2).repeat(1, 3, 1, 1)
+    m3 = batch["masks_fill"].permute(0, 3, 1, 2).expand(-1, 3, -1, -1)     # (a view: the reference's .repeat copies the mask three times, T8:619)
     L = {}
     L["recon"] = 20.0 * F.mse_loss(rendered * m3, img * m3, reduction="sum") / m3.sum()                     # T8:633
     L["depth"] = F.l1_loss(depth.permute(0, 2, 3, 1) * batch["masks"], batch["depths"] * batch["masks"],
@@ -128,7 +176,8 @@ def generator_losses(out, batch, logits_fake_for_g) -> Dict[str, torch.Tensor]:
                                   reduction="sum") / batch["masks_fill"].sum()                              # T8:639
     L["generator"] = 0.01 * F.binary_cross_entropy_with_logits(logits_fake_for_g, torch.ones_like(logits_fake_for_g))
     composite = rendered * m3 + (1.0 - m3) * img
-    L["DSSIM"] = 8.0 * (1 - ssim(composite, img, data_range=1.0, size_average=True, nonnegative_ssim=True)) / 2.0
+    L["DSSIM"] = 8.0 * (1 - ssim(composite, img, data_range=1.0, size_average=True, nonnegative_ssim=True, stacked=ssim_stacked,
+                                blur_kernels=ssim_blur)) / 2.0
     L["total"] = sum(L.values())
     return L
 
@@ -152,6 +201,10 @@ class TrainConfig:
     shortcut: str = "3x3"
     bucket_cap_mb: int = 32     # one flat bucket per model (see module docstring)
     miopen_find: bool = True    # torch.backends.cudnn.benchmark: MIOpen picks the fastest conv algorithm (+9 % step rate)
+    ssim_stacked: bool = False  # the SSIM's five blurs as one pair of depthwise convolutions over stacked inputs (`ssim`): measured
+                                # 0.45 ms per step slower with MIOpen's kernels (profiles/r06_ssim_ab.txt): off
+    ssim_blur: str = "aten"     # "aten": the SSIM's depthwise blurs through ATen's conv_depthwise2d kernels (`_DepthwiseBlur`);
+                                # "miopen": F.conv2d as in rounds 2-5 (CK grouped / naive solvers: ~3 ms per step more)
     render_pixels: str = "all"  # "mask": the render block leaves out the pixels outside the mask (RenderParams.pixels; every loss
                                 # multiplies them by the mask, T8:619-643: bit-equal losses, half the training march)
 
@@ -247,7 +300,7 @@ class Trainer:
         if self.distributed:
             self._wrap_generator(epoch)
         img = batch["images"].permute(0, 3, 1, 2)
-        m3 = batch["masks_fill"].permute(0, 3, 1, 2).repeat(1, 3, 1, 1)
+        m3 = batch["masks_fill"].permute(0, 3, 1, 2).expand(-1, 3, -1, -1)
         out = self.net(batch["images"], epoch, self.K, batch["masks_fill"])              # T8:618
         rendered = out[5]
         composite = rendered * m3 + (1.0 - m3) * img
@@ -265,7 +318,7 @@ class Trainer:
         for p in self.patchgan.parameters():
             p.requires_grad_(False)
         try:
-            L = generator_losses(out, batch, self.patchgan(composite))
+            L = generator_losses(out, batch, self.patchgan(composite), self.cfg.ssim_stacked, self.cfg.ssim_blur)
             L["total"].backward()
         finally:
             for p in self.patchgan.parameters():

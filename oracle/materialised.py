@@ -98,9 +98,10 @@ def _end_points(x, y, C, H, W):
     return torch.stack([Ex, Ey])
 
 
-def min_distance_one(depth_hw, mask_hw, C, p: BlockParams):
+def min_distance_one(depth_hw, mask_hw, C, p: BlockParams, return_all: bool = False):
     """Minimum point-to-line distance over the sample table for ONE image.  T8:375-515.
-    depth_hw (H,W) f32; mask_hw (H,W) any dtype (0 = outside); C (3,) f32.  -> (values (H,W), idx (H,W))."""
+    depth_hw (H,W) f32; mask_hw (H,W) any dtype (0 = outside); C (3,) f32.  -> (values (H,W), idx (H,W));
+    return_all: also the (N,H,W) distances the minimum was taken over (T8:512), before any bonus."""
     H, W = depth_hw.shape
     N = p.n_samples
     xx, yy = pixel_grids(H, W)
@@ -134,6 +135,8 @@ def min_distance_one(depth_hw, mask_hw, C, p: BlockParams):
     out = (mask_hw[row_r, col_r] == 0).reshape(N, H, W)                      # T8:510
     d = torch.logical_not(out) * d + out * 1000000.0                         # T8:512
     values, idx = torch.min(d, dim=0)                                        # T8:514
+    if return_all:
+        return values, idx, d
     if p.inside_bonus != 0.0 and p.bonus_box is not None:                    # S1:495-496
         bx0, bx1, by0, by1 = p.bonus_box
         LX, LY = float(C[0].detach()), float(C[1].detach())

@@ -5,7 +5,9 @@ Random T8 batches (B = 3, 256 x 256, 160 samples) through the IMPORTED, UNMODIFI
                              shadow weights bit-equal, shading / RGB within 1e-12 / 1e-7;
   * oracle/gcfr_oracle.c     minimum_distance within 2 f32 ulps (d = sqrt(.)/sqrt(.), T8:509: torch-CPU's vectorised sqrt is
                              not correctly rounded -- one ulp per sqrt -- the C oracle's sqrtf is), masked minima equal,
-                             argmin equal wherever the distance bits agree, shadow weight <= 2e-6, RGB <= 1e-6.
+                             argmin equal wherever the distance bits agree EXCEPT ties inside that rounding (the reference's
+                             own distance at the C oracle's index is within one ulp of its minimum: a handful of pixels in
+                             24 M; each is re-derived from the port's (N,H,W) distances), shadow weight <= 2e-6, RGB <= 1e-6.
 Input families (the regime the smooth fixtures do not reach -- round-5 verdict, missing 3):
   depth   untrained   100 x the depth head of a freshly initialised reference RelightNet (re-seeded every 10 batches)
           noise5 / noise40 / noise400   ellipsoid + Gaussian noise     uniform1500   U(-1500, 1500)     normal30  N(0, 30)
@@ -177,7 +179,21 @@ def check_batch(model, depth, mask, albedo, light4):
     res["c_max_ulps"] = int(ulps.max()) if ulps.size else 0
     res["c_value_biteq_frac"] = float((md[both] == md_ref[both]).mean()) if both.any() else 1.0
     same = both & (md == md_ref)
-    res["c_index_mismatch_where_bits_agree"] = int((am[same] != am_ref[same]).sum())
+    differ = same & (am != am_ref)
+    res["c_index_mismatch_where_bits_agree"] = int(differ.sum())
+    # ... each of them must be a TIE inside the reference's own rounding: the reference's distance at the C oracle's index is
+    # within one ulp of the reference's minimum (its vectorised sqrt put two samples the C oracle separates on the same value, or
+    # the other way round; first index wins, T8:514).  Anything else is a violation.
+    unexplained = 0
+    for b in np.unique(np.nonzero(differ)[0]):
+        with torch.no_grad():
+            _, _, d_all = M.min_distance_one(torch.from_numpy(depth[b]), torch.from_numpy(mask[b]), pt[b], p, return_all=True)
+        d_all = d_all.numpy()
+        for r_, c_ in zip(*np.nonzero(differ[b])):
+            at_c = np.float32(d_all[am[b, r_, c_], r_, c_])
+            ulps = abs(int(at_c.view(np.int32)) - int(md_ref[b, r_, c_].view(np.int32)))
+            unexplained += int(ulps > 1)
+    res["c_index_mismatch_unexplained"] = unexplained
     res["c_index_eq_frac"] = float((am[both] == am_ref[both]).mean()) if both.any() else 1.0
     sh = c_oracle.shade(n.numpy(), depth, albedo_used, ptc[:, None, :], light4[:, :1], md[:, None])
     res["c_w_err"] = float(np.abs(sh["shadow_w"][:, 0] - out[2].numpy()).max())
@@ -190,7 +206,7 @@ def check_batch(model, depth, mask, albedo, light4):
 def violations(r):
     v = []
     for k in ("mat_value_mismatch", "mat_index_mismatch", "mat_w_mismatch", "c_unit_mismatch", "c_lit_mismatch",
-              "c_masked_value_mismatch", "c_index_mismatch_where_bits_agree"):
+              "c_masked_value_mismatch", "c_index_mismatch_unexplained"):
         if r[k]:
             v.append(k)
     if r["mat_full_err"] > 1e-12 or r["mat_rgb_err"] > 1e-7:
@@ -230,6 +246,7 @@ def run(batches, seed, verbose=True):
                       min_biteq_frac=min(r["c_value_biteq_frac"] for r in rows),
                       min_index_eq_frac=min(r["c_index_eq_frac"] for r in rows),
                       index_mismatches_where_bits_agree=sum(r["c_index_mismatch_where_bits_agree"] for r in rows),
+                      index_mismatches_not_a_one_ulp_tie=sum(r["c_index_mismatch_unexplained"] for r in rows),
                       lit_mismatches=sum(r["c_lit_mismatch"] for r in rows),
                       worst_w_err=max(r["c_w_err"] for r in rows), worst_full_shading_err=max(r["c_full_err"] for r in rows),
                       worst_rgb_err=max(r["c_rgb_err"] for r in rows)),

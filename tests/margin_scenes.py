@@ -608,3 +608,43 @@ def family_wrap_column(seed, H=256, W=256, B=4):
 
 
 FAMILIES["wrap_column"] = family_wrap_column
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# W3 the PREFIX tables' wrap partner (mutant 13): a sample table that reaches t = 1.  With the reference's tables (t <= 0.82) a ray
+#    heading towards column 0 never gets there (csrc/gcfr_mutants.hpp, note on 13 / 14); a caller's table may end at t = 1 -- the
+#    prepass accepts tables inside [0, 1] -- and then the LAST sample of a ray that ends on the image's left edge sits at
+#    u_x = -1e-4: its left bilinear corner is column W-1 (index -1 wraps, T8:488-491), weight 1e-4.  Light far to the left and level
+#    (every ray ends on x = -W/2, T8:399-403), mask on the left quarter, column W-1 masked out and holding, per row, the wall that
+#    lifts the blended surface of that row's column-0 cell to the height the ray of the pixel K0 columns in has reached at t = 1:
+#    for pixels around column K0 the LAST sample is the minimum.  The trailing loop's cap for a ray heading left is the prefix
+#    maximum over the columns it can still touch -- which must hold column W-1.
+# ---------------------------------------------------------------------------------------------------------------------------
+def family_wrap_last_sample(seed, H=256, W=256, B=4, K0=30):
+    rng = np.random.default_rng(31000 + seed)
+    X, Y, r, c = grids(H, W)
+    n = 160
+    tt = 0.2 + np.arange(n, dtype=np.float64) * ((0.8 / (n - 1)) * (1.0 - 1e-9))        # t_159 = 1 - 8e-10: inside [0, 1]
+    depth, pts = [], []
+    mask = np.zeros((B, H, W), np.uint8)
+    mask[:, :, :64] = 1
+    for b in range(B):
+        el = np.deg2rad(rng.uniform(22.0, 40.0))
+        az = np.pi + np.deg2rad(rng.uniform(-0.6, 0.6))
+        C = far_light(az, el, 4013.0)
+        d = (8.0 + 1.5 * np.sin(r / 19.0) * np.cos(c / 15.0) + 0.1 * rng.random((H, W))).astype(f32)
+        k0 = K0 + int(rng.integers(-6, 7))
+        x0, y0, z0 = X[:, k0], Y[:, k0], d[:, k0].astype(np.float64)
+        s_end = (-(W / 2.0) - x0) / (C[0] - x0)                   # the ray's 3-D parameter where it crosses x = -W/2
+        h = z0 + s_end * (C[2] - z0)                              # ... and its height there
+        y_end = y0 + s_end * (C[1] - y0)
+        rows = np.clip(np.rint(H / 2.0 - y_end).astype(int), 0, H - 1)   # the row whose column-0 / column-(W-1) cells that sample blends
+        wall = np.full(H, 9.0)
+        wall[rows] = (h - (1.0 - 1e-4) * d[rows, 0].astype(np.float64)) / 1e-4
+        d[:, W - 1] = wall.astype(f32)
+        depth.append(d)
+        pts.append([C])
+    return dict(depth=np.stack(depth), mask=mask, light_pt=np.array(pts, f32), t_table=tt, pixels_mask=False)
+
+
+FAMILIES["wrap_last_sample"] = family_wrap_last_sample

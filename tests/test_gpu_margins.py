@@ -37,8 +37,9 @@ KILLERS = [
     ("cliffs2", 18, [22]), ("cliffs2", 63, [22]),                          # the bounds grid's stride: a group's reach + 3 cells
     ("parallel3", 0, [4, 23]), ("parallel3", 1, [4]),                      # K2 r: the f32 noise of the distance far from zero
     ("pits2", 0, [23]), ("level", 12, [23]),
-    ("wrap_column", 0, [13, 14]), ("wrap_column", 1, [13, 14]),            # the horizon tables' wrap partners: a ramped wall in the
-]                                                                          # wrap-partner column / row decides late samples (round 6)
+    ("wrap_column", 0, [14]), ("wrap_column", 1, []),                      # the horizon tables' wrap partners: a ramped wall in the
+    ("wrap_last_sample", 0, [13]), ("wrap_last_sample", 1, [13]),          # wrap-partner column / row decides late samples (round 6);
+]                                                                          # a table reaching t = 1: the PREFIX tables' wrap partner
 
 
 def _march(sc, want_argmin, pixels=0):

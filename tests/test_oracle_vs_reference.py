@@ -100,3 +100,17 @@ def test_oracles_match_a_live_reference_forward():
     assert np.abs(sh["shadow_w"][:, 0] - out[2].numpy()).max() <= 2e-6
     assert np.abs(sh["full_shading"][:, 0] - out[4].numpy()).max() <= 1e-6
     assert np.abs(sh["rendered"][:, 0] - out[5].numpy()).max() <= 1e-6
+
+
+def test_soak_slice_rough_depth_and_branch_boundaries():
+    """Two batches of oracle/soak_vs_reference.py (seed 7: an untrained reference network's depth, noise-400 / noise-5 ellipsoids,
+    U(-1500, 1500), a light ON a branch boundary and one an ulp outside it; random 70 % masks with holes): the materialised port
+    bit-equal to the reference's torch.min values and indices, the C oracle within 2 f32 ulps (one per torch-CPU sqrt) with the same
+    index wherever the bits agree.  The committed 120-batch run of the same script: profiles/r06_oracle_vs_reference_soak.json."""
+    import soak_vs_reference as S
+    summary, rows = S.run(2, 7, verbose=False)
+    assert summary["violations"] == 0, [r["violations"] for r in rows]
+    assert summary["materialised"]["value_mismatches"] == 0 and summary["materialised"]["index_mismatches"] == 0
+    assert summary["c_oracle"]["worst_ulps"] <= 2 and summary["c_oracle"]["index_mismatches_not_a_one_ulp_tie"] == 0
+    assert summary["c_oracle"]["min_index_eq_frac"] >= 0.999
+    assert "untrained" in summary["depth_families"] and {"on", "ulp_out"} <= set(summary["boundary_lights"])

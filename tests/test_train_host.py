@@ -57,6 +57,27 @@ def test_ssim_restatement():
     assert abs(float(ssim(Xt, Yt)) - _ssim_naive(X, Y)) < 1e-10
 
 
+def test_ssim_stacked_convolutions_are_bit_equal_to_the_five_separate_ones():
+    """Round 6 (the training step's breakdown, profiles/r06_train_step_breakdown.md): the SSIM's five blurred maps from ONE pair of
+    depthwise convolutions over the stacked inputs.  A depthwise convolution filters each channel on its own, so value and gradient
+    are the same numbers either way -- the value bit for bit on the CPU, where the convolution is deterministic."""
+    from geomconsistentfr_amd.train import ssim
+    torch.manual_seed(3)
+    X0 = torch.rand(2, 3, 48, 40)
+    Y = torch.rand(2, 3, 48, 40)
+    res = []
+    for stacked in (False, True):
+        X = X0.clone().requires_grad_()
+        v = ssim(X, Y, stacked=stacked)
+        v.backward()
+        res.append((v.detach().clone(), X.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])                                  # the loss value: the same bits
+    # the gradient: X's three contributions (through blur(X), blur(X*X), blur(X*Y)) are added by autograd in another order
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 4e-7 * float(res[0][1].abs().max())
+    per_image = [ssim(X0, Y, size_average=False, stacked=s) for s in (False, True)]
+    assert torch.equal(per_image[0], per_image[1])
+
+
 def test_synthetic_batch_is_deterministic_and_rank_disjoint():
     from geomconsistentfr_amd.train import synthetic_batch
     a = synthetic_batch(2, 5, 64, 64)

@@ -46,11 +46,18 @@ for step in "$@"; do
       bash tools/prof.sh ${TAG}_fwd128 fwd --faces 128 > $O/prof_fwd128.log 2>&1
       python tools/summarize_profile.py $TAG > $O/summarize.log 2>&1; tail -3 $O/summarize.log ;;
     train_breakdown)
-      ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tb && timeout 1200 rocprofv3 --kernel-trace --output-format csv -d /tmp/tb -o tb -- \
-          python $OLDPWD/tools/train_breakdown.py run --steps 10 > /tmp/tb_run.log 2>&1 )
-      grep '^{' /tmp/tb_run.log | tail -1 > $O/train_phases.json
-      python tools/train_breakdown.py classify /tmp/tb --phases $O/train_phases.json --out $O/train_step_breakdown.md > /dev/null 2> $O/train_classify.err
-      head -30 $O/train_step_breakdown.md ;;
+      # (1) the phases without a profiler attached (events only): the step as the bench times it;  (2) the kernel trace of the same
+      # run with a sentinel launch at every phase boundary -> by class, by phase, every kernel name.  Both for the step as it is
+      # (SSIM blurs through ATen's depthwise kernels) and as rounds 2-5 ran it (--ssim-blur miopen): the "before" table.
+      for kb in aten miopen; do
+        timeout 600 python tools/train_breakdown.py run --steps 10 --ssim-blur $kb > $O/train_phases_noprof_$kb.log 2>&1; grep '^{' $O/train_phases_noprof_$kb.log | tail -1 > $O/train_phases_noprof_$kb.json
+        ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/tb && timeout 1200 rocprofv3 --kernel-trace --output-format csv -d /tmp/tb -o tb -- \
+            python $OLDPWD/tools/train_breakdown.py run --steps 10 --phase-sentinels --ssim-blur $kb > /tmp/tb_run.log 2>&1 )
+        grep '^{' /tmp/tb_run.log | tail -1 > $O/train_phases_$kb.json
+        python tools/train_breakdown.py classify /tmp/tb --phases $O/train_phases_$kb.json --noprof $O/train_phases_noprof_$kb.json \
+            --out $O/train_step_breakdown_$kb.md --json $O/train_step_kernels_$kb.json > /dev/null 2> $O/train_classify_$kb.err
+        head -22 $O/train_step_breakdown_$kb.md; cat $O/train_phases_noprof_$kb.json; echo
+      done ;;
     audit) GCFR_HIP_LIB=$PWD/geomconsistentfr_amd/lib/audit.so timeout 900 python tools/audit.py --random 800 --family-seeds 8 --more facets=60,pits2=24 --out $O/audit_product.json | tail -c 600; echo ;;
     audit_matrix)
       mkdir -p $O/audit_matrix; s=200; export GCFR_HIP_LIB=$PWD/geomconsistentfr_amd/lib/audit_full.so
