@@ -121,11 +121,10 @@ def cpu_baseline(seed0=0, runs=2, with_backward=True):
                      "best of %s threads: %.2f s/batch" % (runs, sorted(by_threads), by_threads[best]["median_s"])}
     if with_backward:
         torch.set_num_threads(best)
-        med, ts = median_time(forward_backward, runs)
+        med, ts = median_time(forward_backward, 1)       # (one run: ~8 s; round 6 gave its second run's time to the relight_e2e leg)
         out["forward_backward"] = {"value": steps / med, "unit": "ray-steps/s", "cores": best, "median_s": med,
                                    "runs_s": ts, "faces_per_s": B / med,
-                                   "sample": "same batch, forward + autograd backward of sum(rendered) + sum(shadow weights), "
-                                             "median of %d runs" % runs}
+                                   "sample": "same batch, forward + autograd backward of sum(rendered) + sum(shadow weights), one run"}
     torch.set_num_threads(cores)
     return out
 
