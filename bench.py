@@ -803,7 +803,9 @@ def run_render(a, rk):
             aux["train"] = {"skipped": "time budget: %.0f s used before the training leg" % (time.perf_counter() - T_START)}
         else:
             try:
-                aux["train"] = train_leg_subprocess(steps=12, warmup=6)
+                # (10 timed steps = two whole periods of the discriminator's every-fifth-step schedule, T8:624: rounds 3-5 timed 12, which
+                #  holds three 8-ms D steps instead of 2.4 -- +0.4 ms per step of bias)
+                aux["train"] = train_leg_subprocess(steps=10, warmup=6)
             except Exception as e:
                 aux["train"] = {"error": repr(e)}
         leg("train_s")

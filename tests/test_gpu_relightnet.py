@@ -47,7 +47,7 @@ def inject(net, depth, albedo, raw4):
     return net.to(DEV).eval()
 
 
-@pytest.mark.parametrize("idx", [0, 2])
+@pytest.mark.parametrize("idx", [0, 2, 6])          # 6 = t8_g: noise-40 / noise-400 / untrained-network depth, (1,0,0), (0,0,1), z < 0
 def test_training_forward_returns_the_reference_8_tuple(idx):
     from geomconsistentfr_amd.relightnet import RelightNet
     name, case = list(t8_batches())[idx]

@@ -8,7 +8,7 @@
     tools/mutants.py build-audit [n ...]  (CPU)  lib/mut_<n>_audit.so: the mutant as an AUDIT build (-DGCFR_COUNTERS -DGCFR_AUDIT, tools/audit.py)
     tools/mutants.py run-audit [n ...]    (GPU)  tools/audit.py over the same scenes with each of them: does a claim of the march stop
                                                  HOLDING without the margin, decisive or not? -> gpurun_out/mutants/audit.json
-    tools/mutants.py table             (CPU)  gpurun_out/mutants/{results,audit}.json -> profiles/r05_mutants.md
+    tools/mutants.py table [tag]       (CPU)  gpurun_out/mutants/{results,audit}.json -> profiles/<tag>_mutants.md (default tag: r06)
 
 A mutant that survives is a margin nobody tests: it gets a DIRECTED test built from the mechanism's own geometry
 (tests/test_gpu_margins.py), not a larger soak.
@@ -122,13 +122,13 @@ def run(ns, select=SELECT, extra=()):
             json.dump(results, f, indent=1, sort_keys=True)
 
 
-def table():
+def table(tag="r06"):
     results = json.load(open(os.path.join(OUT_DIR, "results.json")))
     ap = os.path.join(OUT_DIR, "audit.json")
     audit = json.load(open(ap)) if os.path.exists(ap) else {}
     names = mutant_table()
     chk0 = audit.get("0", {}).get("checked", {})
-    lines = ["# Mutants of the march's exactness machinery (round 5)", "",
+    lines = ["# Mutants of the march's exactness machinery (%s: both columns run again on that round's final source)" % tag, "",
              "`csrc/gcfr_mutants.hpp`: `-DGCFR_MUT=<n>` removes or inverts ONE safety margin.  Two ways of asking whether the margin is tested:",
              "",
              "* **end to end** -- `tools/mutants.py run`: `pytest -m gpu -x -k \"%s\"` with `GCFR_HIP_LIB=lib/mut_<n>.so` (fast build: 16 x 4" % SELECT,
@@ -186,7 +186,7 @@ def table():
               "**Mutants 3 and 5** are single terms of the bound's error budget `Kerr = K1 + K2 r + n (1.2e-2 + 8e-6 max(H, W))`.  The three terms",
               "budget for three different effects -- the reference's 1e-4 position offset times |BCz| (K1), the f32 roundings of the distance's",
               "products (K2 r), the offset times the surface's slope (plane term) -- each about ten times over (the product's column on the right:",
-              "no evaluation of the bound uses more than 0.13 of Kerr -- `r05_audit_product.json`: 9.6 G claims), and they are ADDED.  End to end, `Kerr = 0` (23) dies in five scene families",
+              "no evaluation of the bound uses more than 0.13 of Kerr -- `%s_audit_product.json`), and they are ADDED.  End to end, `Kerr = 0` (23) dies in five scene families" % tag,
               "and `K2 = 0` (4) wherever the scene sits far from zero, but with K1 or the plane term alone removed the other two plus the 0.2 %",
               "slack cover its effect in every case that DECIDES a minimum: K1's effect (1.4e-4 |BCz|) exceeds the rest only within 43 px of an",
               "overhead light's foot, the plane term's (8e-4 n on slopes 4 + 4) only where such slopes make the depth range -- and with it K2 r --",
@@ -196,17 +196,19 @@ def table():
               "`facets` (steep planar facets on the tiles' grid under level light, 60 seeds) -- the bound used up %.1f and %.1f times what was left of" % (s3, s5),
               "Kerr.  Both margins are needed for the claim `g > 0 => S_k >= 0.998 g^2` to hold, and `tests/test_gpu_audit.py` tests exactly that claim.",
               "",
-              "**What the audit does not see** (13, 14 on these scenes; 15, 16, 17, 24 by construction): mutants that break no claim about unevaluated",
-              "samples -- the rough variant's re-run, the tie predecessor, `pixels = mask`'s definition, the `any_masked` bookkeeping -- or whose",
-              "scenes the audit's list does not hold (the horizon tables' wrap partners: masks touching only the image's edge); the end-to-end",
-              "column kills them.  The two columns are complementary.",
+              "**What the audit does not see** (15, 16, 17, 24 by construction): mutants that break no claim about unevaluated",
+              "samples -- the rough variant's re-run, the tie predecessor, `pixels = mask`'s definition, the `any_masked` bookkeeping; the end-to-end",
+              "column kills them.  The two columns are complementary.  (Round 5's table also listed 13 and 14 here -- the horizon tables' wrap",
+              "partners: the audit's scene list did not hold a scene on which they decide.  Round 6 added the families `wrap_column` and",
+              "`wrap_last_sample` (tests/margin_scenes.py; the latter marches a table that reaches t = 1, the only way a PREFIX table's wrap",
+              "partner can be read: note in csrc/gcfr_mutants.hpp), and both mutants now contradict claims there and die end to end on them.)",
               "",
               "**Removed from the list with a proof that they cannot change a result** (`csrc/gcfr_mutants.hpp`): the candidate range's extra",
               "sample of slack either side (floor / ceil already err by up to a step on the safe side; an accepted table deviates < 0.08 steps",
               "from uniform), the trailing loop's `any_masked |= gone` (a lane that is gone when a group is consumed has just had that group's",
               "all-zero mask bytes read; a lane that goes in the trailing loop holds bestS < safeS), and `pixels = mask` counting a lane outside",
               "the image as own-pixel-off (it repeats a pixel and stores nothing)."]
-    path = os.path.join(REPO, "profiles", "r05_mutants.md")
+    path = os.path.join(REPO, "profiles", "%s_mutants.md" % tag)
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
     print(path)
@@ -224,6 +226,6 @@ if __name__ == "__main__":
     elif what == "run-audit":
         run_audit(ns)
     elif what == "table":
-        table()
+        table(*[a for a in sys.argv[2:3] if not a.lstrip("-").isdigit()])
     else:
         sys.exit(__doc__)
