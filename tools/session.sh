@@ -12,7 +12,9 @@
 #   bench_train      bench.py --workload train --steps 20                         -> bench_train.json
 #   bench:<flags>    bench.py with the given flags (use _ for spaces)             -> bench_<flags>.json
 #   gpus2            the N = 2 launch rehearsed on this box (--oversubscribe over gloo when it has one GPU), both workloads
-#   profile          tools/prof.sh <tag> fwd + bwd + fwd128, then tools/summarize_profile.py <tag> (kernel trace + the PMC passes)
+#   profile          tools/prof.sh <tag> fwd + bwd + fwd128 (kernel trace + the PMC passes -> gpurun_out/prof_<tag>_{fwd,bwd,fwd128}, merged back
+#                    by gpurun) and a first tools/summarize_profile.py <tag> for the log; profiles/ on the box does not travel back: run
+#                    `python tools/summarize_profile.py <tag>` again at home on the merged directories, then tools/design_table.py --write
 #   train_breakdown  rocprofv3 --kernel-trace of tools/train_breakdown.py run     -> train_trace/, train_phases.json, train_step_breakdown.md
 #   audit            tools/audit.py on lib/audit.so (random 800 + every directed family)  -> audit_product.json
 #   audit_matrix     the audit over every tile shape / group size / LDS / k-split (lib/audit_full.so: tools/build_variant.sh audit_full

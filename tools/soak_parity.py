@@ -63,8 +63,10 @@ def run_soak(n_cases, seed=0, options=None, sizes=None, want_argmin=True, pixels
     """`n_cases` random (depth, mask, light) cases in batches of 8: HIP workspace kernel vs the C oracle.
     Returns the tallies (pixels compared, lit/masked disagreements, worst min-distance error, argmin differences)."""
     rng = np.random.default_rng(seed)
+    rng_b = np.random.default_rng([seed, 0xB0DE])        # its own stream: the cases of earlier rounds' seeds stay what they were
     dev = torch.device("cuda:0")
     sizes = sizes or [(64, 64, 48), (96, 128, 80), (130, 70, 37), (128, 128, 160), (256, 256, 160)]
+    n_boundary = 0
     worst = {"abs": 0.0, "rel": 0.0}
     n_pix = n_arg_diff = n_lit_mismatch = 0
     t0 = time.time()
@@ -82,9 +84,24 @@ def run_soak(n_cases, seed=0, options=None, sizes=None, want_argmin=True, pixels
         ld = [4013.0, 4013.0, 60.0, 500.0, 1.0e5, 30.0][(it // 5) % 6]
         prm = RenderParams(n_samples=N, t0=0.025, dt=0.8 / N, light_distance=ld)
         _, pt = light_prep(torch.from_numpy(lights).to(dev), prm)
+        _, pt_o = c_oracle.light_prep(lights, clamp_z_min=0.0, light_distance=ld)
+        assert np.array_equal(pt.cpu().numpy(), pt_o)
+        # round 6: one case in six gets its light POINT moved exactly onto -- or one f32 ulp either side of -- a boundary of the
+        # reference's nine-way end-point branch (T8:386-431: x = -W/2, W/2 - 1; y = 1 - H/2, H/2), where `<` / `<=` decide which of
+        # the nine forms every ray of the image takes; both sides are handed the same point
+        for b in range(B):
+            if rng_b.random() < 1.0 / 6.0:
+                axis = int(rng_b.integers(0, 2))
+                edge = [(-(W / 2.0), W - W / 2.0 - 1), (1 - H / 2.0, H / 2.0)][axis][int(rng_b.integers(0, 2))]
+                v = np.float32(edge)
+                step = int(rng_b.integers(-1, 2))
+                if step:
+                    v = np.nextafter(v, np.float32(np.inf * step))
+                pt_o[b, axis] = v
+                n_boundary += 1
+        pt = torch.from_numpy(pt_o).to(dev)
         md, am = shadow_min_distance(torch.from_numpy(depth).to(dev), torch.from_numpy(mask).to(dev),
                                      pt.reshape(B, 1, 3), prm, options=options, want_argmin=want_argmin)
-        _, pt_o = c_oracle.light_prep(lights, clamp_z_min=0.0, light_distance=ld)
         md_o, am_o = c_oracle.shadow_min_distance(depth, mask, pt_o[:, None, :], c_oracle.sample_table(0.025, 0.8 / N, N))
         if pixels_mask:    # gcfr_options.pixels = 1: a pixel whose own mask cell is zero carries the masked value, every other pixel the oracle's
             md_o[:, 0][mask == 0] = 1e6
@@ -101,7 +118,8 @@ def run_soak(n_cases, seed=0, options=None, sizes=None, want_argmin=True, pixels
             worst["rel"] = max(worst["rel"], float((err / np.maximum(np.abs(md_o[both]), 1.0)).max()))
         n_pix += int(both.sum())
         n_arg_diff += int((am[both] != am_o[both]).sum())
-    return {"cases": (n_cases // B) * B, "seed": seed, "pixels_compared": n_pix, "lit_mask_mismatches": n_lit_mismatch,
+    return {"cases": (n_cases // B) * B, "seed": seed, "cases_with_the_light_point_on_a_branch_boundary": n_boundary,
+            "pixels_compared": n_pix, "lit_mask_mismatches": n_lit_mismatch,
             "max_abs_err_min_dist": worst["abs"], "max_rel_err_min_dist": worst["rel"],
             "argmin_differences": n_arg_diff, "argmin_difference_rate": n_arg_diff / max(n_pix, 1),
             "seconds": time.time() - t0}
