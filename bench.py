@@ -1111,14 +1111,15 @@ def run_train(a, rk):
         "vs_baseline": None, "dtype": "f32 network (MIOpen) + f64/f32 render block", "data": "synthetic",
         "config": {"workload": m["workload"],
                    "faces_per_gpu": B, "global_batch": B * world, "H": 256, "W": 256, "n_samples": N_SAMPLES,
-                   "parallelism": "dp%d" % world, "epoch": m["epoch"]},
+                   "parallelism": "dp%d" % world, "epoch": m["epoch"],
+                   "ssim_blur": "aten (train._DepthwiseBlur: the SSIM's depthwise blurs on ATen's kernels; rounds 2-5: MIOpen's, +3 ms)"},
         "faces_per_sec": m["faces_per_sec"],
         "train_step_ms": m["step_ms"], "train_faces_per_sec": m["faces_per_sec"], "train_march_kernel_ms": march_ms,
         "train_bwd_kernel_ms": bwd_ms,
         "render_block_ms": {"forward_march_kernel": march_ms, "fused_backward_kernel": bwd_ms,
                             "share_of_step": m["render_block_share_of_step"],
-                            "note": "the step is MIOpen-bound (fp32 convolutions of the hourglass and PatchGAN); the render "
-                                    "block's two big kernels are this share of it"},
+                            "note": "the step is MIOpen's fp32 convolutions and BatchNorm (59 %) plus bandwidth-bound ATen glue "
+                                    "(profiles/r06_train_step_breakdown_aten.md); the render block's two big kernels are this share of it"},
         "roofline": bwd_roof,
     }
 
