@@ -147,10 +147,15 @@ class RelightSession:
     pass.  Nothing in the block allocates or synchronises (include/gcfr.h), MIOpen runs in immediate mode (no find pass inside
     the capture), the camera matrix is a host tensor.  The captured kernels are the eager pass's kernels with the eager pass's
     arguments: the composites equal `relight_lights_device` on the same inputs up to MIOpen's own run-to-run jitter
-    (tests/test_gpu_relight_lights.py).  `graph=False` keeps the static buffers and runs eagerly (the A/B)."""
+    (tests/test_gpu_relight_lights.py).  `graph=False` keeps the static buffers and runs eagerly (the A/B).
+    `miopen_find=True`: the warm-up passes run with `torch.backends.cudnn.benchmark` on, so MIOpen SEARCHES the fastest solver
+    for each of the network's convolutions at this batch size (once per process and shape: seconds to a minute or two of
+    construction time on a cold kernel cache) and the capture then holds those solvers instead of the immediate-mode
+    heuristic's picks; the flag is restored afterwards."""
 
     def __init__(self, model, B: int, mask_u8, lights, ambient: float = 0.5, focal: float = None, device="cuda",
-                 H: int = 256, W: int = 256, fix_border: bool = False, composite_mask_u8=None, graph: bool = True, epoch: int = 200):
+                 H: int = 256, W: int = 256, fix_border: bool = False, composite_mask_u8=None, graph: bool = True, epoch: int = 200,
+                 miopen_find: bool = False):
         self.model, self.device, self.epoch, self.ambient, self.fix_border = model, torch.device(device), epoch, float(ambient), fix_border
         self.transfer = _is_transfer(model)
         self.K = camera_matrix((700.0 if self.transfer else 1570.0) if focal is None else focal, H, W)       # host
@@ -164,17 +169,23 @@ class RelightSession:
         self.ambient_dev = torch.full((1,), self.ambient, dtype=torch.float32, device=self.device)   # (no host-to-device copy inside the capture)
         self.out = None
         self.graph = None
-        if graph:
+        find_before = torch.backends.cudnn.benchmark
+        if miopen_find:
+            torch.backends.cudnn.benchmark = True
+        try:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(side):                     # warm-up outside the capture (allocator, MIOpen's solution look-up)
-                for _ in range(2):
+            with torch.cuda.stream(side):                     # warm-up outside the capture (allocator, MIOpen's solution look-up / search)
+                for _ in range(2 if graph else (1 if miopen_find else 0)):
                     self._pass()
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = self._pass()
+            if graph:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.out = self._pass()
+        finally:
+            torch.backends.cudnn.benchmark = find_before
 
     @torch.no_grad()
     def _pass(self):
