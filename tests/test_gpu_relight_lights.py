@@ -213,3 +213,28 @@ def test_relight_session_with_the_real_network_matches_the_eager_pass():
     diff = np.abs(got.astype(int) - want.astype(int))
     assert (diff == 0).mean() >= 0.999 and (diff <= 1).mean() >= 0.9999, ((diff == 0).mean(), diff.max())
     assert got.std() > 10
+
+
+def test_relight_session_miopen_find_restores_the_flag_and_gives_the_same_images():
+    """`miopen_find=True` switches `torch.backends.cudnn.benchmark` on for the session's warm-up only (MIOpen searches its solvers
+    there) and restores it; the composites stay within the byte tolerance of the eager pass (another solver = other last bits)."""
+    from geomconsistentfr_amd import inference as inf
+    from geomconsistentfr_amd.relightnet import RelightNetLightingTransfer
+    sd = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "slt_checkpoint_epoch106.npz")).items()}
+    net = RelightNetLightingTransfer()
+    net.load_state_dict(sd, strict=True)
+    net = net.float().to(DEV).eval()
+    za = np.load(os.path.join(GOLDEN, "slt_main_a.npz"))
+    images = (za["input_u8"] / 255.0).astype(np.float32)[None]
+    lights = _lights11()[:3]
+    for before in (False, True):
+        torch.backends.cudnn.benchmark = before
+        try:
+            sess = inf.RelightSession(net, 1, za["mask_u8"], lights, ambient=0.5, device=DEV, miopen_find=True)
+            assert torch.backends.cudnn.benchmark is before
+        finally:
+            torch.backends.cudnn.benchmark = False
+        got = sess.run(images).cpu().numpy()
+        want = inf.relight_lights(net, images, za["mask_u8"], lights, ambient=0.5, device=DEV)
+        diff = np.abs(got.astype(int) - want.astype(int))
+        assert (diff == 0).mean() >= 0.999 and (diff <= 1).mean() >= 0.9999, ((diff == 0).mean(), diff.max())
