@@ -661,6 +661,53 @@ def relight_e2e_leg(dev, B=FACES_PER_GPU, n_lights=11, iters=20, warmup=4):
     return out
 
 
+def relight_e2e_ranks(rk, B=FACES_PER_GPU, n_lights=11, iters=30):
+    """The end-to-end relight rate on N > 1 ranks (the metric's "relit faces/sec ... 1/2/4/8 GPU"): every rank relights ITS OWN B
+    photographs through its own inference.RelightSession (network + block + image kernel as one hipGraph) -- photographs are
+    independent, so there is no collective in the data path (weak scaling); the timed regions are fenced (barrier + synchronize)
+    on both sides and the max over ranks counts.  A COLLECTIVE: every rank calls it; a rank that fails keeps taking part in the
+    fences and reports its failure through the gather, so no rank is left waiting."""
+    err, sess, x = None, {}, None
+    try:
+        from geomconsistentfr_amd import inference as inf
+        from geomconsistentfr_amd.relightnet import RelightNetLightingTransfer
+        sd = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(ROOT, "tests", "golden", "slt_checkpoint_epoch106.npz")).items()}
+        net = RelightNetLightingTransfer()
+        net.load_state_dict(sd, strict=True)
+        net = net.float().to(rk.dev).eval()
+        depth, mask, albedo, _n, _l, _a = synth_faces(B, rk.rank * 1_000_000)
+        shade = 0.45 + 0.55 * np.clip(depth / 80.0, 0, 1)
+        x = torch.from_numpy((albedo * shade[:, None]).transpose(0, 2, 3, 1).astype(np.float32).copy()).to(rk.dev)
+        m_u8 = torch.from_numpy((mask[0] * 255).astype(np.uint8)).to(rk.dev)
+        lights = torch.from_numpy(LIGHTS18[:11].copy()).to(rk.dev)
+        for L in (1, n_lights):
+            sess[L] = inf.RelightSession(net, B, m_u8, lights[:L], 0.5, device=rk.dev, miopen_find=(L == 1))
+            for _ in range(4):
+                sess[L].run(x)
+    except Exception as e:                                                    # noqa: BLE001
+        err = repr(e)[:300]
+    elapsed = {}
+    for L in (1, n_lights):
+        rk.fence()
+        t0 = time.perf_counter()
+        if err is None:
+            for _ in range(iters):
+                sess[L].run(x)
+        rk.fence()
+        elapsed[L] = rk.max_over_ranks(time.perf_counter() - t0)
+    failed = rk.gather(0.0 if err is None else 1.0)
+    if rk.rank != 0:
+        return None
+    if any(failed):
+        return {"error": err or "rank(s) %s failed" % [i for i, f in enumerate(failed) if f]}
+    return {"faces_per_gpu": B, "lights": n_lights, "ranks": rk.world, "passes": iters, "scaling": "weak",
+            "graph_faces_per_sec_1_light": rk.world * B * iters / elapsed[1],
+            "graph_images_per_sec_%d_lights" % n_lights: rk.world * B * n_lights * iters / elapsed[n_lights],
+            "graph_ms_per_pass_1_light": 1e3 * elapsed[1] / iters, "graph_ms_per_pass_%d_lights" % n_lights: 1e3 * elapsed[n_lights] / iters,
+            "note": "whole job: every rank relights its own %d photographs through its own hipGraph session (network forward + HIP render "
+                    "block + HIP image kernel), no data-path collective; fenced on both sides, max over ranks" % B}
+
+
 def library_srchash():
     try:
         from geomconsistentfr_amd import build as hb
@@ -820,6 +867,10 @@ def run_render(a, rk):
             except Exception as e:
                 aux["train"] = {"error": repr(e)}
         leg("train_s")
+    relight_ranks = None
+    if headline and world > 1 and not a.no_worst_case:       # N > 1: the end-to-end relight rate of the whole job (a collective)
+        relight_ranks = relight_e2e_ranks(rk)
+        leg("relight_e2e_s")
     if rank != 0:
         return None
     algo_bytes = rsps * ALGO_BYTES_PER_RAY_STEP                              # per launch (one rank)
@@ -932,6 +983,11 @@ def run_render(a, rk):
         "throughput_in_flight": {"faces_in_flight_per_gpu": B * n_streams, "ray_steps_per_sec": value},
         "roofline": roof,
     }
+    if relight_ranks is not None:
+        out["relight_e2e"] = relight_ranks
+        if "graph_faces_per_sec_1_light" in relight_ranks:
+            out["relight_e2e_graph_faces_per_sec"] = relight_ranks["graph_faces_per_sec_1_light"]
+            out["relight_e2e_graph_lights11_images_per_sec"] = relight_ranks["graph_images_per_sec_11_lights"]
     if worst is not None:
         out["worst_case"] = worst
         for k in ("ones_mask", "depth_noise_400", "ffhq", "train_depth_b32", "train_depth_b32_pixels_mask"):    # scalars at the top level too
@@ -1173,7 +1229,10 @@ def run_dry(a, rk):
             "lights_per_face": a.lights, "face_lights_per_rank": faces * a.lights, "lights_split_across_ranks": False,
             "size": a.size, "samples": a.samples,
             # the end-to-end relight leg (relight_e2e_leg) belongs to rank 0's single-GPU headline line only
-            "relight_e2e_leg_runs": bool(rk.world == 1 and a.workload == "render" and not a.no_worst_case)}
+            "relight_e2e_leg_runs": bool(rk.world == 1 and a.workload == "render" and not a.no_worst_case),
+            # ... and with N > 1 ranks of the headline shape every rank relights its own photographs (relight_e2e_ranks, weak scaling)
+            "relight_e2e_ranks_runs": bool(rk.world > 1 and a.workload == "render" and not a.no_worst_case and a.size == 256
+                                           and a.lights == 1 and a.samples == 160 and a.faces == FACES_PER_GPU)}
 
 
 def main():

@@ -49,6 +49,8 @@ def test_gpus8_dry_run_keeps_the_books_of_configs3(workload):
     assert d["seed0_per_rank"] == [r * 1_000_000 for r in range(8)]
     assert d["nominal_ray_steps_per_step"] == 8 * faces * 256 * 256 * 160
     assert d["parallelism"] == "dp8"
+    # the end-to-end relight rate of the whole job is part of the N-rank render line (every rank relights its own photographs)
+    assert d["relight_e2e_ranks_runs"] is (workload == "render") and d["relight_e2e_leg_runs"] is False
 
 
 def test_gpus8_dry_run_at_configs4_shape_keeps_every_light_of_a_face_on_one_rank():
@@ -63,6 +65,7 @@ def test_gpus8_dry_run_at_configs4_shape_keeps_every_light_of_a_face_on_one_rank
     assert d["face_lights_per_rank"] == 18 and d["lights_split_across_ranks"] is False
     assert d["nominal_ray_steps_per_step"] == 8 * 18 * 512 * 512 * 320
     assert d["relight_e2e_leg_runs"] is False                      # the end-to-end leg belongs to the 1-GPU headline line
+    assert d["relight_e2e_ranks_runs"] is False                    # ... and its N-rank form to the headline shape (256 x 256, one light)
 
 
 def test_single_rank_needs_no_launcher():
