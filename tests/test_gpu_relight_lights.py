@@ -238,3 +238,36 @@ def test_relight_session_miopen_find_restores_the_flag_and_gives_the_same_images
         want = inf.relight_lights(net, images, za["mask_u8"], lights, ambient=0.5, device=DEV)
         diff = np.abs(got.astype(int) - want.astype(int))
         assert (diff == 0).mean() >= 0.999 and (diff <= 1).mean() >= 0.9999, ((diff == 0).mean(), diff.max())
+
+
+def test_two_sessions_in_flight_on_two_streams_do_not_disturb_each_other():
+    """bench.py's throughput form of the end-to-end leg: two RelightSessions (own static buffers, own graphs) replayed
+    round-robin on two HIP streams.  Each must give the bytes it gives alone."""
+    from geomconsistentfr_amd import inference as inf
+    from geomconsistentfr_amd.relightnet import RelightNetSingleImage
+    B = 2
+    heads = _fixed_heads(B, 90)
+    net = _fixed(RelightNetSingleImage, heads)
+    rng = np.random.default_rng(8)
+    imgs = [torch.from_numpy(rng.random((B, H, W, 3), dtype=np.float32)).to(DEV) for _ in range(2)]
+    lights = _lights11()
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    sess = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            sess.append(inf.RelightSession(net, B, heads[3], lights, device=DEV))
+    torch.cuda.synchronize()
+    alone = []
+    for i in range(2):
+        alone.append(sess[i].run(imgs[i]).clone())
+        torch.cuda.synchronize()
+    outs = [None, None]
+    for rep in range(6):
+        i = rep % 2
+        streams[i].wait_stream(torch.cuda.current_stream(DEV))
+        with torch.cuda.stream(streams[i]):
+            outs[i] = sess[i].run(imgs[i])
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(outs[i], alone[i]), i
+    assert not torch.equal(alone[0], alone[1])

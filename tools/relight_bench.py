@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--faces", default="8,32")
     ap.add_argument("--lights", default="1,11")
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--in-flight", default="2,4", help="also: this many sessions replayed round-robin on their own streams")
     ap.add_argument("--find", default="0,1", help="miopen_find settings, in this order (PyTorch caches a convolution's solver per process "
                                                   "and shape: whichever runs first decides for both -- use one process per setting)")
     a = ap.parse_args()
@@ -56,6 +57,29 @@ def main():
                 print(json.dumps({"faces": B, "lights": L, "miopen_find": find, "ms_per_pass": 1e3 * t, "images_per_sec": B * L / t,
                                   "faces_per_sec": B / t, "session_build_s": build_s}), flush=True)
                 del sess
+                # several sessions in flight on their own streams (independent batches, as bench.py's headline keeps four render
+                # batches in flight): a batch-8 network pass does not fill the chip
+                for n_fly in [int(v) for v in a.in_flight.split(",") if int(v) > 1]:
+                    streams = [torch.cuda.Stream(device=dev) for _ in range(n_fly)]
+                    many = []
+                    for st in streams:
+                        with torch.cuda.stream(st):
+                            many.append(inf.RelightSession(net, B, m_u8, lights[:L], 0.5, device=dev))
+                    torch.cuda.synchronize()
+
+                    def go(n):
+                        for i in range(n):
+                            with torch.cuda.stream(streams[i % n_fly]):
+                                many[i % n_fly].run(x)
+                    go(2 * n_fly)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    go(a.iters)
+                    torch.cuda.synchronize()
+                    t = (time.perf_counter() - t0) / a.iters
+                    print(json.dumps({"faces": B, "lights": L, "miopen_find": find, "sessions_in_flight": n_fly, "ms_per_pass": 1e3 * t,
+                                      "images_per_sec": B * L / t, "faces_per_sec": B / t}), flush=True)
+                    del many
 
 
 if __name__ == "__main__":
