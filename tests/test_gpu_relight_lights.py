@@ -215,29 +215,25 @@ def test_relight_session_with_the_real_network_matches_the_eager_pass():
     assert got.std() > 10
 
 
-def test_relight_session_miopen_find_restores_the_flag_and_gives_the_same_images():
+def test_relight_session_miopen_find_restores_the_flag():
     """`miopen_find=True` switches `torch.backends.cudnn.benchmark` on for the session's warm-up only (MIOpen searches its solvers
-    there) and restores it; the composites stay within the byte tolerance of the eager pass (another solver = other last bits)."""
+    there: bench.py's leg and tools/relight_bench.py run it on the real network, +14 %) and restores whatever the caller had set.
+    On fixed head outputs (no convolution runs: the test costs no search) the composites are the eager pass's."""
     from geomconsistentfr_amd import inference as inf
-    from geomconsistentfr_amd.relightnet import RelightNetLightingTransfer
-    sd = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "slt_checkpoint_epoch106.npz")).items()}
-    net = RelightNetLightingTransfer()
-    net.load_state_dict(sd, strict=True)
-    net = net.float().to(DEV).eval()
-    za = np.load(os.path.join(GOLDEN, "slt_main_a.npz"))
-    images = (za["input_u8"] / 255.0).astype(np.float32)[None]
+    from geomconsistentfr_amd.relightnet import RelightNetSingleImage
+    heads = _fixed_heads(1, 12)
+    net = _fixed(RelightNetSingleImage, heads)
+    images = np.random.default_rng(2).random((1, H, W, 3), dtype=np.float32)
     lights = _lights11()[:3]
     for before in (False, True):
         torch.backends.cudnn.benchmark = before
         try:
-            sess = inf.RelightSession(net, 1, za["mask_u8"], lights, ambient=0.5, device=DEV, miopen_find=True)
-            assert torch.backends.cudnn.benchmark is before
+            for graph in (True, False):
+                sess = inf.RelightSession(net, 1, heads[3], lights, device=DEV, miopen_find=True, graph=graph)
+                assert torch.backends.cudnn.benchmark is before
+                np.testing.assert_array_equal(sess.run(images).cpu().numpy(), inf.relight_lights(net, images, heads[3], lights, device=DEV))
         finally:
             torch.backends.cudnn.benchmark = False
-        got = sess.run(images).cpu().numpy()
-        want = inf.relight_lights(net, images, za["mask_u8"], lights, ambient=0.5, device=DEV)
-        diff = np.abs(got.astype(int) - want.astype(int))
-        assert (diff == 0).mean() >= 0.999 and (diff <= 1).mean() >= 0.9999, ((diff == 0).mean(), diff.max())
 
 
 def test_two_sessions_in_flight_on_two_streams_do_not_disturb_each_other():
