@@ -59,7 +59,10 @@ class _DepthwiseBlur(torch.autograd.Function):
     window is symmetric, so the backward of a valid correlation is the same correlation of the zero-padded upstream gradient:
     two more depthwise convolutions, under the same switch (autograd's own convolution backward re-selects the backend when it
     RUNS, outside the forward's context).  Same fp32 sums of the same eleven products per output; the order of the additions is
-    the kernel's, as it is MIOpen's in the other form (which differs between its solvers too)."""
+    the kernel's, as it is MIOpen's in the other form (which differs between its solvers too).
+    (`cudnn.flags` is PROCESS-wide state, switched for the few microseconds these four calls take to enqueue: a convolution issued
+    by another host thread of the same process in that window would take ATen's path too -- correct, slower.  One process per GPU
+    with one training thread, as `Trainer` runs, has no such thread; autograd's backward thread runs while the main thread waits.)"""
 
     @staticmethod
     def forward(ctx, t, wh, ww):
