@@ -624,6 +624,10 @@ def relight_e2e_leg(dev, B=FACES_PER_GPU, n_lights=11, iters=20, warmup=4):
         find_s, find_err = time.perf_counter() - t0, None
     except Exception as e:
         find_s, find_err = None, repr(e)[:200]
+    # the two streams of every "2 in flight" measurement below: created ONCE.  (torch hands out pooled streams round-robin and HIP
+    # maps streams onto a handful of hardware queues; this process has created dozens by now, and a pair created later in the leg
+    # was seen to serialise -- 28.7 k instead of 41.3 k images/s at eleven lights, reproducibly -- while this pair overlaps.)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
     with torch.no_grad():
         t_feat = timed(lambda: net.features(x, 200), iters)
         for L in (1, n_lights):
@@ -638,7 +642,6 @@ def relight_e2e_leg(dev, B=FACES_PER_GPU, n_lights=11, iters=20, warmup=4):
                 del sess
                 # ... and two such sessions replayed round-robin on their own streams (independent batches in flight, as the
                 # headline keeps four render batches in flight): one batch-8 network pass does not fill the chip
-                streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
                 pair = []
                 for st in streams:
                     with torch.cuda.stream(st):
@@ -652,7 +655,18 @@ def relight_e2e_leg(dev, B=FACES_PER_GPU, n_lights=11, iters=20, warmup=4):
                         pair[i].run(x)
                 t2 = timed(two, iters * 4)
                 res[L].update(graph2_ms_per_pass=1e3 * t2, graph2_images_per_sec=B * L / t2)
-                del pair
+                pair.clear()
+                # ... and the same two sessions on a copy of the network whose eval-mode BatchNorms are folded into its convolutions
+                # (inference.fold_batchnorm: a deployment form -- network outputs agree to ~1e-5, composites on >= 99.9 % of the bytes)
+                folded = inf.fold_batchnorm(net)
+                for st in streams:
+                    with torch.cuda.stream(st):
+                        pair.append(inf.RelightSession(folded, B, m_u8, lights[:L], 0.5, device=dev))
+                torch.cuda.synchronize(dev)
+                t3 = timed(two, iters * 4)
+                res[L].update(graph2_folded_images_per_sec=B * L / t3)
+                pair.clear()
+                del folded
             except Exception as e:
                 res[L]["graph_error"] = repr(e)[:300]
     out = {"faces": B, "lights": n_lights, "network_forward_ms": 1e3 * t_feat,
@@ -667,6 +681,8 @@ def relight_e2e_leg(dev, B=FACES_PER_GPU, n_lights=11, iters=20, warmup=4):
            "graph_ms_per_pass_%d_lights" % n_lights: res[n_lights].get("graph_ms_per_pass"),
            "graph_2_in_flight_faces_per_sec_1_light": res[1].get("graph2_images_per_sec"),
            "graph_2_in_flight_images_per_sec_%d_lights" % n_lights: res[n_lights].get("graph2_images_per_sec"),
+           "graph_2_in_flight_folded_bn_faces_per_sec_1_light": res[1].get("graph2_folded_images_per_sec"),
+           "graph_2_in_flight_folded_bn_images_per_sec_%d_lights" % n_lights: res[n_lights].get("graph2_folded_images_per_sec"),
            "graph_error": res[1].get("graph_error") or res[n_lights].get("graph_error"),
            "miopen_find_seconds": find_s, "miopen_find_error": find_err,
            "reference_equivalent_passes": n_lights,
@@ -676,7 +692,8 @@ def relight_e2e_leg(dev, B=FACES_PER_GPU, n_lights=11, iters=20, warmup=4):
                    "bytes to the host; `graph_*` = the same pass (copy of the photographs into a static input included) replayed from "
                    "ONE hipGraph (inference.RelightSession): the eager pass is bound by ~350 launches issued from Python, the graph by "
                    "the GPU; `graph_2_in_flight_*` = two such sessions (two independent batches of B photographs) replayed round-robin on two "
-                   "HIP streams: the throughput form, as the headline's four render batches in flight.  The reference produces L images of "
+                   "HIP streams: the throughput form, as the headline's four render batches in flight; `*_folded_bn_*` = the same on a copy of the "
+                   "network with its eval-mode BatchNorms folded into the convolutions (inference.fold_batchnorm; outputs agree to ~1e-5).  The reference produces L images of "
                    "a face with L full passes (S1:582-588)."}
     del net
     return out
@@ -1033,7 +1050,9 @@ def run_render(a, rk):
                         relight_e2e_graph_faces_per_sec=re2.get("graph_faces_per_sec_1_light"),
                         relight_e2e_graph_lights11_images_per_sec=re2.get("graph_images_per_sec_11_lights"),
                         relight_e2e_graph_2_in_flight_faces_per_sec=re2.get("graph_2_in_flight_faces_per_sec_1_light"),
-                        relight_e2e_graph_2_in_flight_lights11_images_per_sec=re2.get("graph_2_in_flight_images_per_sec_11_lights"))
+                        relight_e2e_graph_2_in_flight_lights11_images_per_sec=re2.get("graph_2_in_flight_images_per_sec_11_lights"),
+                        relight_e2e_folded_bn_2_in_flight_faces_per_sec=re2.get("graph_2_in_flight_folded_bn_faces_per_sec_1_light"),
+                        relight_e2e_folded_bn_2_in_flight_lights11_images_per_sec=re2.get("graph_2_in_flight_folded_bn_images_per_sec_11_lights"))
         if "step_ms" in tr:
             flat.update(train_step_ms=tr["step_ms"], train_faces_per_sec=tr["faces_per_sec"],
                         train_march_kernel_ms=tr["march_kernel_ms"], train_bwd_kernel_ms=tr["bwd_kernel_ms"],

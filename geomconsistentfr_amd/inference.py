@@ -137,6 +137,47 @@ def relight_lights(model, images, mask_u8, lights, ambient: float = 0.5, focal: 
     return relight_lights_device(model, images, mask_u8, lights, ambient, focal, device, fix_border, composite_mask_u8, epoch).cpu().numpy()
 
 
+def fold_batchnorm(model):
+    """An EVAL-mode copy of a RelightNet* model with every BatchNorm folded into the convolution in front of it.
+
+    The hourglass applies `bn_X(conv_X(x))` / `bn_X(deconv_X(x))` everywhere (T8:199-350; `_Hourglass._cb`).  In eval mode a
+    BatchNorm is the affine map `y = (x - mean) * gamma / sqrt(var + eps) + beta` with constants, so it folds into the
+    convolution's weight (scaled per OUTPUT channel: dim 0 of a Conv2d weight, dim 1 of a ConvTranspose2d weight) and bias; the
+    copy's `bn_X` modules become `nn.Identity` and 56 elementwise kernels per pass disappear (the convolutions stay MIOpen's).
+    A deployment optimisation for inference only: the folded products are rounded once more than the reference's two-step
+    evaluation (network outputs agree to ~1e-6 relative, the uint8 composites on >= 99.9 % of the bytes:
+    tests/test_gpu_relight_lights.py); the copy's state_dict no longer has the reference's BatchNorm entries, so checkpoints are
+    loaded into the ORIGINAL model and folded afterwards.  Raises if the model is in training mode (batch statistics do not fold)."""
+    import copy
+    import torch.nn as nn
+    if model.training:
+        raise ValueError("fold_batchnorm needs model.eval(): training-mode BatchNorm uses batch statistics")
+    m = copy.deepcopy(model)
+    with torch.no_grad():
+        for name, bn in list(m.named_children()):
+            if not name.startswith("bn_") or not isinstance(bn, nn.BatchNorm2d):
+                continue
+            base = name[3:]
+            conv = getattr(m, "conv_" + base, None)
+            kind = "conv"
+            if conv is None:
+                conv, kind = getattr(m, "deconv_" + base, None), "deconv"
+            if conv is None:
+                continue
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            shift = bn.bias - bn.running_mean * scale
+            if kind == "conv":
+                conv.weight.mul_(scale.reshape(-1, 1, 1, 1))
+            else:                                               # ConvTranspose2d: (in, out / groups, kH, kW)
+                conv.weight.mul_(scale.reshape(1, -1, 1, 1))
+            if conv.bias is None:
+                conv.bias = nn.Parameter(shift.clone())
+            else:
+                conv.bias.mul_(scale).add_(shift)
+            setattr(m, name, nn.Identity())
+    return m.eval()
+
+
 class RelightSession:
     """Steady-state serving form of `relight_lights_device` for a fixed shape: B photographs x L lights of H x W.
 

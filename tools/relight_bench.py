@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--faces", default="8,32")
     ap.add_argument("--lights", default="1,11")
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--fold-bn", type=int, default=0, help="1: the network with its BatchNorms folded into the convolutions")
     ap.add_argument("--in-flight", default="2,4", help="also: this many sessions replayed round-robin on their own streams")
     ap.add_argument("--find", default="0,1", help="miopen_find settings, in this order (PyTorch caches a convolution's solver per process "
                                                   "and shape: whichever runs first decides for both -- use one process per setting)")
@@ -34,6 +35,8 @@ def main():
     net = RelightNetLightingTransfer()
     net.load_state_dict(sd, strict=True)
     net = net.float().to(dev).eval()
+    if a.fold_bn:
+        net = inf.fold_batchnorm(net)            # eval-mode BatchNorm folded into the convolutions (inference.fold_batchnorm)
     lights = torch.from_numpy(scenes.LIGHTS18[:11].copy()).to(dev)
     for B in [int(v) for v in a.faces.split(",")]:
         depth, mask, albedo, _n, _l, _a = scenes.synth_faces(B, 0)
@@ -54,8 +57,8 @@ def main():
                     sess.run(x)
                 torch.cuda.synchronize()
                 t = (time.perf_counter() - t0) / a.iters
-                print(json.dumps({"faces": B, "lights": L, "miopen_find": find, "ms_per_pass": 1e3 * t, "images_per_sec": B * L / t,
-                                  "faces_per_sec": B / t, "session_build_s": build_s}), flush=True)
+                print(json.dumps({"faces": B, "lights": L, "miopen_find": find, "fold_bn": bool(a.fold_bn), "ms_per_pass": 1e3 * t,
+                                  "images_per_sec": B * L / t, "faces_per_sec": B / t, "session_build_s": build_s}), flush=True)
                 del sess
                 # several sessions in flight on their own streams (independent batches, as bench.py's headline keeps four render
                 # batches in flight): a batch-8 network pass does not fill the chip
@@ -77,7 +80,7 @@ def main():
                     go(a.iters)
                     torch.cuda.synchronize()
                     t = (time.perf_counter() - t0) / a.iters
-                    print(json.dumps({"faces": B, "lights": L, "miopen_find": find, "sessions_in_flight": n_fly, "ms_per_pass": 1e3 * t,
+                    print(json.dumps({"faces": B, "lights": L, "miopen_find": find, "fold_bn": bool(a.fold_bn), "sessions_in_flight": n_fly, "ms_per_pass": 1e3 * t,
                                       "images_per_sec": B * L / t, "faces_per_sec": B / t}), flush=True)
                     del many
 
