@@ -297,3 +297,29 @@ def test_folded_batchnorm_copy_relights_to_the_same_bytes():
     want = inf.relight_lights(net, images, za["mask_u8"], lights, ambient=0.5, device=DEV)
     diff = np.abs(got.astype(int) - want.astype(int))
     assert (diff == 0).mean() >= 0.999 and (diff <= 1).mean() >= 0.9999, ((diff == 0).mean(), diff.max())
+
+
+@pytest.mark.parametrize("L", [1, 16, 18])
+def test_forward_lights_at_the_normals_stage_crossover(L):
+    """From 16 lights per face on the normals stencil runs as its own launch in front of the march (block.normals_stage_for) --
+    also behind a hoisted prepass.  L = 1 (a light axis of length one), 16 and 18 (BASELINE configs[4]'s count) against single
+    forwards, bit for bit on fixed head outputs."""
+    from geomconsistentfr_amd import block as R
+    from geomconsistentfr_amd.relightnet import RelightNetSingleImage
+    import scenes
+    B = 2
+    heads = _fixed_heads(B, 5)
+    net = _fixed(RelightNetSingleImage, heads)
+    lights = scenes.LIGHTS18[:L]
+    assert R.normals_stage_for(L) == ("kernel" if L >= 16 else "fused")
+    img = torch.zeros(B, H, W, 3, device=DEV)
+    mask = torch.from_numpy(heads[3].astype(np.float64) / 255.0).reshape(H, W, 1).to(DEV)
+    with torch.no_grad():
+        many = net.forward_lights(img, 200, _K(1570.0), mask, lights)
+        assert tuple(many[5].shape) == (B, L, 3, H, W)
+        for l in sorted({0, L // 2, L - 1}):
+            tl = torch.from_numpy(np.repeat(lights[l][None], B, 0)).reshape(B, 3, 1, 1).to(DEV)
+            one = net(img, 200, _K(1570.0), mask, tl, torch.zeros(B, 1, 1, device=DEV), mask[None])
+            for k in (2, 4, 5, 6, 8):
+                assert torch.equal(many[k][:, l], one[k]), (k, l)
+            assert torch.equal(many[9], one[9])
