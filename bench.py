@@ -559,15 +559,16 @@ class RenderRig:
         pairs = []
         torch.cuda.synchronize()
         with torch.cuda.stream(self.streams[0]):
-            for _ in range(n):
+            for k in range(n):
                 e0, e1 = ev.new(), ev.new()
                 opt = self._lib.options(**self.knobs, event_start=e0, event_stop=e1, pixels=int(self.prm.pixels == "mask"))
                 pairs.append((e0, e1, opt))
                 if self.use_plans:
-                    keep = self.plans[0].options          # (the plan's own: base knobs + what RenderParams.pixels asked for)
-                    self.plans[0].options = opt
-                    self.plans[0](*self.inputs[0])
-                    self.plans[0].options = keep
+                    b = k % self.n_batches if self.n_batches > self.n_streams else 0     # (many distinct batches: cycle them -- cold inputs)
+                    keep = self.plans[b].options          # (the plan's own: base knobs + what RenderParams.pixels asked for)
+                    self.plans[b].options = opt
+                    self.plans[b](*self.inputs[b])
+                    self.plans[b].options = keep
                 else:
                     self.eager_step(opt)
         torch.cuda.synchronize()
@@ -770,9 +771,10 @@ def run_render(a, rk):
     from_depth = (not a.normals_in) and mode in ("plan", "eager")      # (the direct / unfused A/B forms take normals as input)
     headline = (a.size == 256 and a.lights == 1 and a.samples == 160 and a.mask == "ellipse" and a.depth_noise == 0.0
                 and a.data == "synthetic" and B == FACES_PER_GPU and not knobs and mode == "plan" and from_depth
-                and not a.argmin and a.pixels == "all" and a.normals_stage in ("auto", "fused"))
+                and not a.argmin and a.pixels == "all" and a.normals_stage in ("auto", "fused") and not a.batches)
     rig = RenderRig(rk, B, a.size, a.lights, a.samples, a.mask, a.depth_noise, a.data, a.streams, from_depth,
-                    a.argmin, knobs, graph=not a.no_graph, mode=mode, pixels=a.pixels, normals_stage=a.normals_stage)
+                    a.argmin, knobs, graph=not a.no_graph, mode=mode, pixels=a.pixels, normals_stage=a.normals_stage,
+                    n_batches=a.batches or None)
     n_streams, world, rank = rig.n_streams, rk.world, rk.rank
     ev = HipEvents()
     legs = {"setup_s": time.perf_counter() - T_START}           # wall seconds per leg of this run (how the default run spends its minutes)
@@ -1330,6 +1332,9 @@ def main():
                     help="mask = RenderParams(pixels='mask') / gcfr_options.pixels = 1: pixels outside the mask are not marched (opt-in "
                          "deviation, include/gcfr.h; every loss of the training script multiplies them by the mask).  Non-headline.")
     ap.add_argument("--argmin", action="store_true", help="the training-time march (argmin tracked, 5 waves/SIMD)")
+    ap.add_argument("--batches", type=int, default=0,
+                    help="distinct batches resident in HBM the steps cycle through (default: one per stream -- 4 x 8 faces, inside the "
+                         "Infinity Cache; 64: 512 faces = 2.4 GB, the `many_batches` leg's form)")
     ap.add_argument("--streams", type=int, default=4,
                     help="batches in flight: successive steps go round-robin to this many HIP streams, one RenderFwdPlan (own "
                          "outputs and workspace) per stream.  One launch cannot fill the chip to its end -- its duration is "
