@@ -377,6 +377,22 @@ def regions_needed(steps, est_ms_per_step):
 # ------------------------------------------------------------------------------------------------
 # workload "render": BASELINE configs[1]
 # ------------------------------------------------------------------------------------------------
+_RIG_STREAMS = {}
+
+
+def rig_streams(dev, n):
+    """The process's HIP streams for batches in flight: created ONCE per device and shared by every rig / leg of the run.
+    torch hands out pooled streams round-robin and HIP maps streams onto a handful of hardware queues; a rig that created its own
+    four streams late in a run (dozens of streams created before it: plans' capture streams, earlier rigs) was seen to lose its
+    overlap -- the `many_batches` leg read 1.57 T on its own late streams and 1.97 T on these, reproducibly; the relight leg's
+    eleven-light pair 28.7 k against 41.3 k images/s.  Streams are plumbing: one set per process."""
+    key = (dev.type, dev.index)
+    have = _RIG_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=dev))
+    return have[:n]
+
+
 class RenderRig:
     """One render workload on one rank: `streams` batches of B faces resident in HBM, one RenderFwdPlan (own outputs and
     workspace) per batch, each captured into a hipGraph; `timed(steps, streams)` issues `steps` steps round-robin and
@@ -415,7 +431,7 @@ class RenderRig:
             except Exception as e:      # a runtime that cannot capture: same kernels, issued call by call
                 self.graph_error, self.use_graph = repr(e), False
                 torch.cuda.synchronize()
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
+        self.streams = rig_streams(dev, self.n_streams)
 
     # -- data ----------------------------------------------------------------------------------
     def _device_batch(self, j):
@@ -630,10 +646,9 @@ def relight_e2e_leg(dev, B=FACES_PER_GPU, n_lights=11, iters=20, warmup=4):
         find_s, find_err = time.perf_counter() - t0, None
     except Exception as e:
         find_s, find_err = None, repr(e)[:200]
-    # the two streams of every "2 in flight" measurement below: created ONCE.  (torch hands out pooled streams round-robin and HIP
-    # maps streams onto a handful of hardware queues; this process has created dozens by now, and a pair created later in the leg
-    # was seen to serialise -- 28.7 k instead of 41.3 k images/s at eleven lights, reproducibly -- while this pair overlaps.)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    # the two streams of every "2 in flight" measurement below: the process's own (rig_streams: a pair created late in the run was
+    # seen to serialise -- 28.7 k instead of 41.3 k images/s at eleven lights, reproducibly)
+    streams = rig_streams(dev, 2)
     with torch.no_grad():
         t_feat = timed(lambda: net.features(x, 200), iters)
         for L in (1, n_lights):
@@ -845,8 +860,9 @@ def run_render(a, rk):
             except Exception as e:                                                # never lose the headline to a side measurement
                 worst[key] = {"error": repr(e)}
         worst["note"] = ("many_batches: the headline's workload cycling through 64 DISTINCT batches of 8 faces (512 faces, ~2.4 GB of "
-                         "inputs, outputs and workspaces) instead of 4 (~154 MB, inside the 256-MB Infinity Cache), four in flight: the rate "
-                         "does not rest on cache residency.  Otherwise: "
+                         "inputs, outputs and workspaces) instead of 4 (~154 MB, inside the 256-MB Infinity Cache), four in flight and one "
+                         "at a time: whether the rate rests on cache residency (it does not with four in flight; a lone launch pays ~5 %).  "
+                         "Otherwise: "
                          "same kernels, same run: all-ones masks (nothing is ever masked), uniform depth noise of amplitude 400 "
                          "(what an untrained network emits: the depth bounds never separate ray and surface), the three "
                          "checkpoint-derived FFHQ fixture faces tiled to the batch (--data ffhq), and the training step's "
