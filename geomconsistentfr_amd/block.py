@@ -714,8 +714,8 @@ _CAMERA_CACHE = {}      # id(tensor) -> (weakref to the tensor, its in-place ver
 def camera_scalars(camera_matrix: torch.Tensor):
     """(fx, fy, cx, cy) of a (1|B,3,3) camera matrix as host floats, or None if the B matrices differ.
     The reference builds K on the host and passes `intrinsic_matrix.cuda()` to every forward (T8:571-577, 618).
-    A host tensor is simply read.  A DEVICE tensor has to be copied back -- a device-to-host sync -- so its scalars
-    are cached per tensor OBJECT: the entry holds a weak reference and the tensor's in-place version counter, and is
+    A host tensor is simply read (10 us of tensor arithmetic; cached like a device tensor's so that a caller that keeps one K
+    pays it once).  A DEVICE tensor has to be copied back -- a device-to-host sync -- so its scalars are cached per tensor OBJECT: the entry holds a weak reference and the tensor's in-place version counter, and is
     only trusted while that very object is alive and unmodified (an address- or id-keyed cache would hand a freed
     tensor's scalars to whatever is allocated in its place).  Callers that keep one K on the device (Trainer does)
     therefore synchronise once; callers that upload a fresh K every step should pass the host tensor instead."""
@@ -726,8 +726,6 @@ def camera_scalars(camera_matrix: torch.Tensor):
         same = K.shape[0] == 1 or bool((K == K[:1]).all())
         return (float(K[0, 0, 0]), float(K[0, 1, 1]), float(K[0, 0, 2]), float(K[0, 1, 2])) if same else None
 
-    if camera_matrix.device.type == "cpu":
-        return read(camera_matrix)
     key = id(camera_matrix)
     ent = _CAMERA_CACHE.get(key)
     if ent is not None and ent[0]() is camera_matrix and ent[1] == camera_matrix._version:

@@ -54,3 +54,26 @@ def test_normals_stage_rule_and_result_shapes():
     r = R._result_dict(B, H, W, False, z(B, 1), z(B, 1, H, W), z(B, 1, H, W), z(B, 1, H, W), z(B, 1, 3, H, W), z(B, 1, 3), z(B, 1, H, W))
     assert tuple(r["rendered_images"].shape) == (B, 3, H, W) and tuple(r["unit_light_direction"].shape) == (B, 3, 1, 1)   # T8:524
     assert tuple(r["ambient_light"].shape) == (B, H, W) and tuple(r["ambient_values"].shape) == (B, 1, 1)
+
+
+def test_camera_scalars_cache_follows_the_tensor_object_and_its_version():
+    """camera_scalars caches per tensor OBJECT (host tensors too since round 6: the read is 10 us of tensor arithmetic per call):
+    an in-place write invalidates the entry, a dead tensor's entry is dropped, per-image matrices give None."""
+    import gc
+    from geomconsistentfr_amd import block as R
+    K = torch.zeros(1, 3, 3, dtype=torch.float64)
+    K[:, 0, 0] = K[:, 1, 1] = 1570.0
+    K[:, 2, 2] = 1.0
+    K[:, 0, 2], K[:, 1, 2] = 128.0, 120.0
+    n0 = len(R._CAMERA_CACHE)
+    assert R.camera_scalars(K) == (1570.0, 1570.0, 128.0, 120.0) and len(R._CAMERA_CACHE) == n0 + 1
+    assert R.camera_scalars(K) == (1570.0, 1570.0, 128.0, 120.0)                     # served from the cache
+    K[:, 0, 0] = 700.0                                                                # in place: the version counter moves
+    assert R.camera_scalars(K)[0] == 700.0
+    two = torch.cat([K, K]).clone()
+    assert R.camera_scalars(two) == (700.0, 1570.0, 128.0, 120.0)                     # B equal matrices
+    two[1, 0, 0] = 900.0
+    assert R.camera_scalars(two) is None                                              # per-image matrices: the three-stage path
+    del K, two
+    gc.collect()
+    assert len(R._CAMERA_CACHE) == n0
